@@ -1,0 +1,84 @@
+"""ctypes binding of libheatnet_hip.so (declared in include/heatnet_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C heatnet-pub_amd/csrc`.
+There is NO fallback: if the shared object is missing or a symbol is absent, importing
+the operators raises, and every operator refuses CPU tensors.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libheatnet_hip.so")
+
+c_int, c_i64, c_float, c_void_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+P = c_void_p  # every device pointer crosses the ABI as a plain address
+
+
+class HnConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("N", "Hin", "Win", "Cin", "ldx", "Hout", "Wout", "Cout", "ldy", "KH", "KW", "stride", "pad", "dil")]
+
+
+DP = ctypes.POINTER(HnConvDesc)
+
+# name -> argtypes, exactly the prototypes of include/heatnet_hip.h
+SIGNATURES = {
+    "hn_conv2d_fwd": [P, P, P, P, P, DP, c_int, c_float, P],
+    "hn_weight_flip_transpose": [P, P, c_int, c_int, c_int, c_int, P],
+    "hn_conv2d_dgrad": [P, P, P, DP, P],
+    "hn_conv2d_wgrad": [P, P, P, DP, c_int, P],
+    "hn_channel_sum": [P, c_int, c_i64, c_int, P, P],
+    "hn_channel_stats": [P, c_int, c_i64, c_int, P, P],
+    "hn_bn_finalize": [P, c_i64, P, P, P, P, c_float, c_float, P, P, P, P, c_int, P],
+    "hn_bn_eval_params": [P, P, P, P, c_float, P, P, P, P, c_int, P],
+    "hn_bn_act_fwd": [P, c_int, P, P, P, c_int, P, c_int, c_i64, c_int, c_int, P, c_float, P],
+    "hn_bn_act_bwd_reduce": [P, c_int, P, c_int, P, c_int, P, P, P, P, c_i64, c_int, c_int, P, c_float, P, P],
+    "hn_bn_act_bwd_apply": [P, c_int, P, c_int, P, c_int, P, P, P, P, P, P, c_i64, c_int, P, c_int, P, c_int,
+                            c_i64, c_int, c_int, P, c_float, P],
+    "hn_act_bwd": [P, c_int, P, c_int, P, c_int, c_i64, c_int, c_int, c_float, P],
+    "hn_scale_nc": [P, c_int, P, P, c_int, c_int, c_i64, c_int, P],
+    "hn_add": [P, c_int, P, c_int, P, c_int, c_i64, c_int, P],
+    "hn_copy": [P, c_int, P, c_int, c_i64, c_int, P],
+    "hn_maxpool3x3s2_fwd": [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "hn_maxpool3x3s2_bwd": [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "hn_adaptive_avgpool_fwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "hn_adaptive_avgpool_bwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "hn_bilinear_fwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "hn_bilinear_bwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "hn_ce_fwd": [P, c_int, P, c_i64, c_int, c_i64, P, P],
+    "hn_ce_bwd": [P, c_int, P, c_i64, c_int, c_i64, P, P, P, c_int, P],
+    "hn_adv_loss_fwd": [P, c_i64, c_float, c_int, P, P],
+    "hn_adv_loss_bwd": [P, c_i64, c_float, c_int, P, P, P],
+    "hn_argmax_confusion": [P, c_int, P, c_i64, c_int, c_int, P, P, P],
+    "hn_rmsprop_step": [P, P, P, c_i64, c_float, c_float, c_float, c_float, P],
+    "hn_adam_step": [P, P, P, P, c_i64, c_float, c_float, c_float, c_float, c_float, c_int, P],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared object once; raise (never fall back) when it is unusable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "heatnet_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C heatnet-pub_amd/csrc`). There is no CPU/PyTorch fallback for the hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.hn_strerror.argtypes = [c_int]
+    lib.hn_strerror.restype = ctypes.c_char_p
+    lib.hn_version.argtypes = []
+    lib.hn_version.restype = c_int
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError("heatnet_amd: %s failed: %s (%d)" % (what, load().hn_strerror(code).decode(), code))

@@ -1,0 +1,81 @@
+"""Segmentation network + domain critics wrapper (the object the HeatNet trainer drives).
+
+models/confusion_maximization/models/conf_segnet.py:22-140 for arch='pspnet', disc_arch='cyclegan'.  The optional
+branches of the reference (ResNeXt 'custom' arch, ResNet critics, feedback_seg, input adapter, cert branch) are
+outside the hot path and raise NotImplementedError.
+"""
+import torch
+import torch.nn as nn
+
+from . import build_net
+from .critics import FCDiscriminator
+
+
+def weights_init_normal(m):
+    """models/confusion_maximization/utils.py:126-132."""
+    classname = m.__class__.__name__
+    if classname.find("Conv") != -1:
+        torch.nn.init.normal_(m.weight.data, 0.0, 0.02)
+    elif classname.find("BatchNorm2d") != -1:
+        torch.nn.init.normal_(m.weight.data, 1.0, 0.02)
+        torch.nn.init.constant_(m.bias.data, 0.0)
+
+
+def create_critic(disc_arch, input_num):
+    if disc_arch == "cyclegan":
+        return FCDiscriminator(input_num)
+    raise NotImplementedError("critic architecture %r is outside the MI355X hot path (only 'cyclegan')" % disc_arch)
+
+
+class conv_segnet(nn.Module):
+    def __init__(self, pretrained=True, disc_arch="resnet", num_critics=6, feedback_seg=False, no_conf=False,
+                 modalities="ir_rgb", input_adapter=False, cert_branch=False, arch="custom", late_fusion=False):
+        super().__init__()
+        if arch != "pspnet":
+            raise NotImplementedError("arch=%r: only the PSPNet path is built for MI355X" % arch)
+        if feedback_seg or input_adapter or cert_branch:
+            raise NotImplementedError("feedback_seg / input_adapter / cert_branch are outside the MI355X hot path")
+        num_input_channels = (3 if "rgb" in modalities else 0) + (1 if "ir" in modalities else 0)
+        self.trgb_segnet = build_net.build_network(None, "resnet50", in_channels=num_input_channels,
+                                                   late_fusion=late_fusion)
+        critic_num = [13, 2048, 1024, 512 * 2, 256 * 2, 64 * 2] if late_fusion else [13, 2048, 1024, 512, 256, 64]
+        self.trgb_segnet.apply(weights_init_normal)
+        self.feedback_seg = False
+        self.input_adapter = False
+        if not no_conf:
+            self.critics = nn.ModuleList([create_critic(disc_arch, c) for c in critic_num[0:num_critics]])
+        if pretrained:
+            # the reference loads 'models_finished/training_nc_irrgb_best.pth' relative to the cwd here
+            from .checkpoint import init_model_renamed
+            init_model_renamed(self.trgb_segnet, "models_finished/training_nc_irrgb_best.pth", "module.", "")
+        self.phase = "train_seg"
+        self.no_conf = no_conf
+
+    def setLearningModel(self, module, val):
+        for p in module.parameters():
+            p.requires_grad = val
+
+    def setPhase(self, phase):
+        self.phase = phase
+        print("Switching to phase: %s" % self.phase)
+        if phase not in ("train_seg", "train_critic"):
+            return
+        seg = phase == "train_seg"
+        if not self.no_conf:
+            for c in self.critics:
+                self.setLearningModel(c, not seg)
+        self.setLearningModel(self.trgb_segnet, seg)
+
+    def forward(self, input_a, input_b):
+        output = {}
+        pred_label_day, inter_f_a, cert_a = self.trgb_segnet(*input_a)
+        pred_label_night, inter_f_b, cert_b = self.trgb_segnet(*input_b)
+        if not self.no_conf:
+            output["critics_a"] = [c(inter_f_a[i]) for i, c in enumerate(self.critics)]
+            output["critics_b"] = [c(inter_f_b[i]) for i, c in enumerate(self.critics)]
+        output["pred_label_a"] = pred_label_day
+        output["pred_label_b"] = pred_label_night
+        output["cert_a"] = cert_a
+        output["cert_b"] = cert_b
+        output["inter_f_b"] = inter_f_b
+        return output

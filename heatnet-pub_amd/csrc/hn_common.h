@@ -1,0 +1,29 @@
+// Shared helpers for the gfx950 kernels of libheatnet_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/heatnet_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define HN_CHECK_LAUNCH() \
+    do { if (hipGetLastError() != hipSuccess) return HN_ELAUNCH; } while (0)
+
+static inline bool hn_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Blocks are dealt round-robin over the 8 XCDs (each with a private L2).  Remap the linear block id so
+// that blocks sharing an XCD walk a CONTIGUOUS range of logical tile ids and re-use each other's
+// operand panels from that L2.  Bijective for any block count (speed only, never correctness).
+__device__ __forceinline__ int hn_xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, k = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+__device__ __forceinline__ float hn_apply_act(float v, int act, float slope) {
+    if (act == HN_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == HN_ACT_PRELU || act == HN_ACT_LEAKY) return v > 0.f ? v : v * slope;
+    return v;
+}

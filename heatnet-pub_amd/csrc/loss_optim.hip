@@ -1,0 +1,252 @@
+// Loss kernels (per-pixel cross entropy, adversarial MSE / BCE-with-logits against a constant map),
+// argmax + confusion-matrix histogram for mIoU, and the elementwise optimizer updates.  All HBM-bound.
+#include "hn_common.h"
+
+namespace {
+
+constexpr int MAXC = 32;  // class count handled in registers by the per-pixel kernels
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    // 256 threads: wave shuffle, then LDS across the 4 waves
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
+                                                    int64_t npix, int C, int64_t ignore, float* __restrict__ out) {
+    __shared__ float red[4];
+    float loss = 0.f, cnt = 0.f;
+    for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t lab = labels[pix];
+        if (lab == ignore || lab < 0 || lab >= C) continue;
+        const float* row = logits + pix * ld;
+        float v[MAXC];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) { v[c] = row[c]; mx = fmaxf(mx, v[c]); }
+        float se = 0.f, xl = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) { se += expf(v[c] - mx); if (c == (int)lab) xl = v[c]; }
+        loss += (mx + logf(se)) - xl;
+        cnt += 1.f;
+    }
+    const float l = block_sum(loss, red);
+    const float n = block_sum(cnt, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(out + 0, l);
+        atomicAdd(out + 1, n);
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
+                                                    int64_t npix, int C, int64_t ignore, const float* __restrict__ out,
+                                                    const float* __restrict__ gout, float* __restrict__ dl, int lddl) {
+    const float cnt = out[1];
+    const float g = cnt > 0.f ? gout[0] / cnt : 0.f;
+    for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t lab = labels[pix];
+        float* drow = dl + pix * lddl;
+        if (lab == ignore || lab < 0 || lab >= C) {
+            for (int c = 0; c < C; ++c) drow[c] = 0.f;
+            continue;
+        }
+        const float* row = logits + pix * ld;
+        float v[MAXC];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) { v[c] = row[c]; mx = fmaxf(mx, v[c]); }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) { v[c] = expf(v[c] - mx); se += v[c]; }
+        const float inv = g / se;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) drow[c] = v[c] * inv - (c == (int)lab ? g : 0.f);
+    }
+}
+
+__device__ __forceinline__ float adv_value(float x, float t, int kind) {
+    if (kind == HN_LOSS_MSE) return (x - t) * (x - t);
+    // BCEWithLogits: max(x,0) - x*t + log1p(exp(-|x|))
+    return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float adv_grad(float x, float t, int kind) {
+    if (kind == HN_LOSS_MSE) return 2.f * (x - t);
+    return 1.f / (1.f + expf(-x)) - t;
+}
+
+__global__ __launch_bounds__(256) void adv_fwd_kernel(const float* __restrict__ x, int64_t n, float t, int kind, float inv_n,
+                                                     float* __restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        acc += adv_value(x[i], t, kind);
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, s * inv_n);
+}
+
+__global__ __launch_bounds__(256) void adv_bwd_kernel(const float* __restrict__ x, int64_t n, float t, int kind, float inv_n,
+                                                     const float* __restrict__ gout, float* __restrict__ dx) {
+    const float g = gout[0] * inv_n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] = g * adv_grad(x[i], t, kind);
+}
+
+__global__ __launch_bounds__(256) void argmax_conf_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
+                                                         int64_t npix, int C, int K, unsigned long long* __restrict__ conf,
+                                                         uint8_t* __restrict__ pred_out) {
+    extern __shared__ unsigned int hist[];  // K*K
+    for (int i = threadIdx.x; i < K * K; i += blockDim.x) hist[i] = 0u;
+    __syncthreads();
+    for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
+        const float* row = logits + pix * ld;
+        float best = row[0];
+        int bi = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = row[c];
+            if (v > best) { best = v; bi = c; }
+        }
+        if (pred_out != nullptr) pred_out[pix] = (uint8_t)bi;
+        if (labels != nullptr) {
+            const int64_t lab = labels[pix];
+            if (lab >= 0 && lab < K && bi < K) atomicAdd(&hist[(int)lab * K + bi], 1u);
+        }
+    }
+    __syncthreads();
+    if (labels != nullptr)
+        for (int i = threadIdx.x; i < K * K; i += blockDim.x)
+            if (hist[i] != 0u) atomicAdd(conf + i, (unsigned long long)hist[i]);
+}
+
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
+                                                     int64_t n, float lr, float alpha, float eps, float wd) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float s = alpha * sq[i] + (1.f - alpha) * gi * gi;
+        sq[i] = s;
+        p[i] = pi - lr * gi / (sqrtf(s) + eps);
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, int64_t n, float step_size, float beta1, float beta2,
+                                                  float eps, float wd, float inv_sqrt_bc2) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+inline int flat_grid(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int hn_ce_fwd(const float* logits, int ld, const int64_t* labels, int64_t npix, int C, int64_t ignore_index,
+                         float* out, void* stream) {
+    if (!logits || !labels || !out || npix <= 0 || C <= 0 || C > MAXC || ld < C) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(out, 0, 2 * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, ignore_index, out);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_ce_bwd(const float* logits, int ld, const int64_t* labels, int64_t npix, int C, int64_t ignore_index,
+                         const float* out, const float* gout, float* dlogits, int lddl, void* stream) {
+    if (!logits || !labels || !out || !gout || !dlogits || npix <= 0 || C <= 0 || C > MAXC || ld < C || lddl < C)
+        return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, ignore_index, out,
+                       gout, dlogits, lddl);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_adv_loss_fwd(const float* x, int64_t n, float target, int kind, float* out, void* stream) {
+    if (!x || !out || n <= 0 || (kind != HN_LOSS_MSE && kind != HN_LOSS_BCE)) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
+    int grid = flat_grid(n);
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(adv_fwd_kernel, dim3(grid), dim3(256), 0, s, x, n, target, kind, (float)(1.0 / (double)n), out);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_adv_loss_bwd(const float* x, int64_t n, float target, int kind, const float* gout, float* dx,
+                               void* stream) {
+    if (!x || !gout || !dx || n <= 0 || (kind != HN_LOSS_MSE && kind != HN_LOSS_BCE)) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(adv_bwd_kernel, dim3(flat_grid(n)), dim3(256), 0, s, x, n, target, kind, (float)(1.0 / (double)n),
+                       gout, dx);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_argmax_confusion(const float* logits, int ld, const int64_t* labels, int64_t npix, int C, int K,
+                                   int64_t* conf, uint8_t* pred_out, void* stream) {
+    if (!logits || npix <= 0 || C <= 0 || C > 255 || ld < C || K <= 0 || K > 64) return HN_EINVAL;
+    if (labels != nullptr && conf == nullptr) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int grid = flat_grid(npix);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(argmax_conf_kernel, dim3(grid), dim3(256), (size_t)K * K * sizeof(unsigned int), s, logits, ld, labels,
+                       npix, C, K, reinterpret_cast<unsigned long long*>(conf), pred_out);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_rmsprop_step(float* param, const float* grad, float* square_avg, int64_t n, float lr, float alpha,
+                               float eps, float weight_decay, void* stream) {
+    if (!param || !grad || !square_avg || n <= 0) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(flat_grid(n)), dim3(256), 0, s, param, grad, square_avg, n, lr, alpha, eps,
+                       weight_decay);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n,
+                       (float)((double)lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)));
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" const char* hn_strerror(int code) {
+    switch (code) {
+        case HN_OK: return "ok";
+        case HN_EINVAL: return "invalid argument";
+        case HN_EALIGN: return "operand not aligned as required";
+        case HN_ELAUNCH: return "HIP launch failed";
+        case HN_ESHAPE: return "inconsistent shapes";
+        default: return "unknown heatnet_hip error";
+    }
+}
+
+extern "C" int hn_version(void) { return 1; }

@@ -1,0 +1,522 @@
+// HBM-bound per-channel kernels: BatchNorm apply / backward fused with the activation and the residual
+// add, per-channel column reductions, Dropout2d scaling, strided copy / add.
+//
+// Every tensor is (ptr, ld) NHWC.  Thread layout: threadIdx.x walks the channel axis in 16-B pieces
+// (coalesced), threadIdx.y walks pixels; a block is bx x by = 256 threads with bx = the smallest power
+// of two covering the channel pieces (<= 64), so narrow tensors (C = 64) still fill their waves.
+// Column reductions finish through LDS across threadIdx.y and one global_atomic_add_f32 per channel.
+#include "hn_common.h"
+
+namespace {
+
+template <int V>
+__device__ __forceinline__ void ldv(const float* p, float (&v)[V]) {
+    if constexpr (V == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else {
+        v[0] = *p;
+    }
+}
+template <int V>
+__device__ __forceinline__ void stv(float* p, const float (&v)[V]) {
+    if constexpr (V == 4) {
+        f32x4 t = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p) = t;
+    } else {
+        *p = v[0];
+    }
+}
+
+struct RowLaunch {
+    dim3 grid, block;
+    int V;
+};
+
+// Decide vector width and block shape.  `ptrs`/`lds` list every strided operand.
+RowLaunch plan_rows(int64_t npix, int C, std::initializer_list<const void*> ptrs, std::initializer_list<int> lds,
+                    int target_blocks = 2048) {
+    bool v4 = (C % 4) == 0;
+    for (const void* p : ptrs) v4 = v4 && (p == nullptr || hn_aligned16(p));
+    for (int ld : lds) v4 = v4 && (ld % 4 == 0);
+    RowLaunch r;
+    r.V = v4 ? 4 : 1;
+    const int pieces = C / r.V;
+    int bx = 1;
+    while (bx < pieces && bx < 64) bx <<= 1;
+    const int by = 256 / bx;
+    const int gx = (pieces + bx - 1) / bx;
+    int64_t gy = (npix + by - 1) / by;
+    const int64_t cap = (target_blocks + gx - 1) / gx;
+    if (gy > cap) gy = cap;
+    if (gy < 1) gy = 1;
+    r.grid = dim3(gx, (unsigned)gy);
+    r.block = dim3(bx, by);
+    return r;
+}
+
+// du = dz * act'(u)
+template <int V>
+__device__ __forceinline__ void act_grad(const float (&dz)[V], const float (&z)[V], const float (&y)[V],
+                                         const float (&sc)[V], const float (&sh)[V], int act, float slope,
+                                         float (&du)[V], float& dslope) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        if (act == HN_ACT_RELU) {
+            du[i] = z[i] > 0.f ? dz[i] : 0.f;
+        } else if (act == HN_ACT_PRELU || act == HN_ACT_LEAKY) {
+            const float u = y[i] * sc[i] + sh[i];
+            du[i] = u > 0.f ? dz[i] : dz[i] * slope;
+            dslope += u > 0.f ? 0.f : dz[i] * u;
+        } else {
+            du[i] = dz[i];
+        }
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, int ldy,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        const float* __restrict__ res, int ldr, float* __restrict__ z,
+                                                        int ldz, int64_t npix, int C, int act, const float* slope_p,
+                                                        float leaky) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (c >= C) return;
+    float sc[V], sh[V];
+    ldv<V>(scale + c, sc);
+    ldv<V>(shift + c, sh);
+    const float slope = act == HN_ACT_PRELU ? *slope_p : leaky;
+    for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
+        float v[V], r[V], o[V];
+        ldv<V>(y + pix * ldy + c, v);
+        if (res != nullptr) ldv<V>(res + pix * ldr + c, r);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float u = v[i] * sc[i] + sh[i];
+            if (res != nullptr) u += r[i];
+            o[i] = hn_apply_act(u, act, slope);
+        }
+        stv<V>(z + pix * ldz + c, o);
+    }
+}
+
+// sums[0:C] += sum du ; sums[C:2C] += sum du*xhat ; sums[2C] += dslope
+template <int V>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ dz, int lddz,
+                                                               const float* __restrict__ z, int ldz,
+                                                               const float* __restrict__ y, int ldy,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               int64_t npix, int C, int act, const float* slope_p, float leaky,
+                                                               float* __restrict__ sums) {
+    __shared__ float red[2 * 256 * 4 + 256];
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const bool live = c < C;
+    float sc[V], sh[V], mu[V], is[V], s1[V], s2[V];
+    float dslope = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) { sc[i] = sh[i] = mu[i] = is[i] = s1[i] = s2[i] = 0.f; }
+    if (live) {
+        ldv<V>(scale + c, sc);
+        ldv<V>(shift + c, sh);
+        ldv<V>(mean + c, mu);
+        ldv<V>(invstd + c, is);
+    }
+    const float slope = act == HN_ACT_PRELU ? *slope_p : leaky;
+    if (live) {
+        for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix;
+             pix += (int64_t)gridDim.y * blockDim.y) {
+            float g[V], zz[V], yy[V], du[V];
+            ldv<V>(dz + pix * lddz + c, g);
+            ldv<V>(y + pix * ldy + c, yy);
+            if (act == HN_ACT_RELU) ldv<V>(z + pix * ldz + c, zz);
+            else {
+#pragma unroll
+                for (int i = 0; i < V; ++i) zz[i] = 0.f;
+            }
+            act_grad<V>(g, zz, yy, sc, sh, act, slope, du, dslope);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                s1[i] += du[i];
+                s2[i] += du[i] * (yy[i] - mu[i]) * is[i];
+            }
+        }
+    }
+    // reduce over threadIdx.y
+    const int bx = blockDim.x, by = blockDim.y, tx = threadIdx.x, ty = threadIdx.y;
+    float* r1 = red;
+    float* r2 = red + 256 * 4;
+    float* r3 = red + 2 * 256 * 4;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        r1[(ty * bx + tx) * V + i] = s1[i];
+        r2[(ty * bx + tx) * V + i] = s2[i];
+    }
+    r3[ty * bx + tx] = dslope;
+    __syncthreads();
+    if (ty == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < by; ++k) {
+                a += r1[(k * bx + tx) * V + i];
+                b += r2[(k * bx + tx) * V + i];
+            }
+            atomicAdd(sums + c + i, a);
+            atomicAdd(sums + C + c + i, b);
+        }
+    }
+    if (act == HN_ACT_PRELU) {
+        if (ty == 0 && tx == 0) {
+            float a = 0.f;
+            for (int k = 0; k < bx * by; ++k) a += r3[k];
+            atomicAdd(sums + 2 * C, a);
+        }
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __restrict__ dz, int lddz,
+                                                              const float* __restrict__ z, int ldz,
+                                                              const float* __restrict__ y, int ldy,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const float* __restrict__ sums,
+                                                              float inv_count, int training, float* __restrict__ dy, int lddy,
+                                                              float* __restrict__ dres, int lddr, int64_t npix, int C, int act,
+                                                              const float* slope_p, float leaky) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (c >= C) return;
+    float sc[V], sh[V], mu[V], is[V], ga[V], m1[V], m2[V];
+    ldv<V>(scale + c, sc);
+    ldv<V>(shift + c, sh);
+    ldv<V>(mean + c, mu);
+    ldv<V>(invstd + c, is);
+    ldv<V>(gamma + c, ga);
+    if (training) {
+        ldv<V>(sums + c, m1);
+        ldv<V>(sums + C + c, m2);
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        m1[i] = training ? m1[i] * inv_count : 0.f;
+        m2[i] = training ? m2[i] * inv_count : 0.f;
+        ga[i] *= is[i];
+    }
+    const float slope = act == HN_ACT_PRELU ? *slope_p : leaky;
+    float unused = 0.f;
+    for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
+        float g[V], zz[V], yy[V], du[V], o[V];
+        ldv<V>(dz + pix * lddz + c, g);
+        ldv<V>(y + pix * ldy + c, yy);
+        if (act == HN_ACT_RELU) ldv<V>(z + pix * ldz + c, zz);
+        else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) zz[i] = 0.f;
+        }
+        act_grad<V>(g, zz, yy, sc, sh, act, slope, du, unused);
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] = ga[i] * (du[i] - m1[i] - (yy[i] - mu[i]) * is[i] * m2[i]);
+        stv<V>(dy + pix * lddy + c, o);
+        if (dres != nullptr) stv<V>(dres + pix * lddr + c, du);
+    }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, float inv_count, float unbias,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                   float* running_var, float momentum, float eps, float* __restrict__ mean,
+                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = (double)stats[c] * inv_count;
+    double var = (double)stats[C + c] * inv_count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float mf = (float)m;
+    mean[c] = mf;
+    invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - mf * sc;
+    if (running_mean != nullptr) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+    if (running_var != nullptr) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+}
+
+__global__ void bn_eval_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                      float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                      float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.f / sqrtf(rv[c] + eps);
+    mean[c] = rm[c];
+    invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, int ld, int64_t npix, int C,
+                                                         float* __restrict__ out) {
+    __shared__ float red[256 * 4];
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const bool live = c < C;
+    float s[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) s[i] = 0.f;
+    if (live) {
+        for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix;
+             pix += (int64_t)gridDim.y * blockDim.y) {
+            float v[V];
+            ldv<V>(x + pix * ld + c, v);
+#pragma unroll
+            for (int i = 0; i < V; ++i) s[i] += v[i];
+        }
+    }
+    const int bx = blockDim.x, by = blockDim.y, tx = threadIdx.x, ty = threadIdx.y;
+#pragma unroll
+    for (int i = 0; i < V; ++i) red[(ty * bx + tx) * V + i] = s[i];
+    __syncthreads();
+    if (ty == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float a = 0.f;
+            for (int k = 0; k < by; ++k) a += red[(k * bx + tx) * V + i];
+            atomicAdd(out + c + i, a);
+        }
+    }
+}
+
+// stats[0:C] += sum x ; stats[C:2C] += sum x*x  (batch statistics when the producer was not our conv)
+template <int V>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, int ld, int64_t npix, int C,
+                                                           float* __restrict__ out) {
+    __shared__ float red[2 * 256 * 4];
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const bool live = c < C;
+    float s[V], q[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) s[i] = q[i] = 0.f;
+    if (live) {
+        for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix;
+             pix += (int64_t)gridDim.y * blockDim.y) {
+            float v[V];
+            ldv<V>(x + pix * ld + c, v);
+#pragma unroll
+            for (int i = 0; i < V; ++i) { s[i] += v[i]; q[i] += v[i] * v[i]; }
+        }
+    }
+    const int bx = blockDim.x, by = blockDim.y, tx = threadIdx.x, ty = threadIdx.y;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        red[(ty * bx + tx) * V + i] = s[i];
+        red[256 * 4 + (ty * bx + tx) * V + i] = q[i];
+    }
+    __syncthreads();
+    if (ty == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < by; ++k) {
+                a += red[(k * bx + tx) * V + i];
+                b += red[256 * 4 + (k * bx + tx) * V + i];
+            }
+            atomicAdd(out + c + i, a);
+            atomicAdd(out + C + c + i, b);
+        }
+    }
+}
+
+// mode 0: dx = dy * act'(out) ; 1: y = a + b ; 2: y = a
+template <int V, int MODE>
+__global__ __launch_bounds__(256) void rowwise_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b,
+                                                     int ldb, float* __restrict__ o, int ldo, int64_t npix, int C, int act,
+                                                     float slope) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (c >= C) return;
+    for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
+        float va[V], vb[V], vo[V];
+        ldv<V>(a + pix * lda + c, va);
+        if constexpr (MODE != 2) ldv<V>(b + pix * ldb + c, vb);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            if constexpr (MODE == 0) {
+                const float k = vb[i] > 0.f ? 1.f : (act == HN_ACT_RELU ? 0.f : (act == HN_ACT_NONE ? 1.f : slope));
+                vo[i] = va[i] * k;
+            } else if constexpr (MODE == 1) {
+                vo[i] = va[i] + vb[i];
+            } else {
+                vo[i] = va[i];
+            }
+        }
+        stv<V>(o + pix * ldo + c, vo);
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void scale_nc_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mask,
+                                                      float* __restrict__ y, int ldy, int64_t npix, int64_t hw, int C) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (c >= C) return;
+    for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
+        const int64_t n = pix / hw;
+        float v[V], m[V];
+        ldv<V>(x + pix * ldx + c, v);
+        ldv<V>(mask + n * C + c, m);
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] *= m[i];
+        stv<V>(y + pix * ldy + c, v);
+    }
+}
+
+bool bad_rows(int64_t npix, int C, std::initializer_list<int> lds) {
+    if (npix <= 0 || C <= 0) return true;
+    for (int ld : lds)
+        if (ld < C) return true;
+    return false;
+}
+
+}  // namespace
+
+#define HN_LAUNCH_V(plan, kern, ...)                                                                     \
+    do {                                                                                                 \
+        if ((plan).V == 4) hipLaunchKernelGGL((kern<4>), (plan).grid, (plan).block, 0, s, __VA_ARGS__);  \
+        else hipLaunchKernelGGL((kern<1>), (plan).grid, (plan).block, 0, s, __VA_ARGS__);                \
+    } while (0)
+
+extern "C" int hn_bn_finalize(const float* stats, int64_t count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                              float* invstd, float* scale, float* shift, int C, void* stream) {
+    if (!stats || !gamma || !beta || !mean || !invstd || !scale || !shift || C <= 0 || count <= 0) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, (float)(1.0 / (double)count),
+                       unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_bn_eval_params(const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, float* mean, float* invstd, float* scale,
+                                 float* shift, int C, void* stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !mean || !invstd || !scale || !shift || C <= 0)
+        return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bn_eval_params_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gamma, beta, running_mean,
+                       running_var, eps, mean, invstd, scale, shift, C);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_bn_act_fwd(const float* y, int ldy, const float* scale, const float* shift, const float* residual,
+                             int ldr, float* z, int ldz, int64_t npix, int C, int act, const float* slope,
+                             float leaky_slope, void* stream) {
+    if (!y || !scale || !shift || !z || act < 0 || act > 3 || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
+    if (bad_rows(npix, C, {ldy, ldz}) || (residual && ldr < C)) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const RowLaunch pl = plan_rows(npix, C, {y, z, residual, scale, shift}, {ldy, ldz, residual ? ldr : 4});
+    HN_LAUNCH_V(pl, bn_act_fwd_kernel, y, ldy, scale, shift, residual, ldr, z, ldz, npix, C, act, slope, leaky_slope);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                                    const float* mean, const float* invstd, const float* scale, const float* shift,
+                                    int64_t npix, int C, int act, const float* slope, float leaky_slope, float* sums,
+                                    void* stream) {
+    if (!dz || !y || !mean || !invstd || !scale || !shift || !sums || act < 0 || act > 3) return HN_EINVAL;
+    if ((act == HN_ACT_RELU && !z) || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
+    if (bad_rows(npix, C, {lddz, ldy}) || (act == HN_ACT_RELU && ldz < C)) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(sums, 0, (size_t)(2 * C + 1) * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
+    const RowLaunch pl = plan_rows(npix, C, {dz, y, act == HN_ACT_RELU ? z : nullptr, mean, invstd, scale, shift},
+                                   {lddz, ldy, act == HN_ACT_RELU ? ldz : 4}, 1024);
+    HN_LAUNCH_V(pl, bn_act_bwd_reduce_kernel, dz, lddz, z, ldz, y, ldy, mean, invstd, scale, shift, npix, C, act, slope,
+                leaky_slope, sums);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                                   const float* mean, const float* invstd, const float* gamma, const float* scale,
+                                   const float* shift, const float* sums, int64_t count, int training, float* dy,
+                                   int lddy, float* dres, int lddr, int64_t npix, int C, int act, const float* slope,
+                                   float leaky_slope, void* stream) {
+    if (!dz || !y || !mean || !invstd || !gamma || !scale || !shift || !dy || act < 0 || act > 3) return HN_EINVAL;
+    if ((training && (!sums || count <= 0)) || (act == HN_ACT_RELU && !z) || (act == HN_ACT_PRELU && !slope))
+        return HN_EINVAL;
+    if (bad_rows(npix, C, {lddz, ldy, lddy}) || (dres && lddr < C) || (act == HN_ACT_RELU && ldz < C)) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const RowLaunch pl =
+        plan_rows(npix, C, {dz, y, dy, dres, act == HN_ACT_RELU ? z : nullptr, mean, invstd, gamma, scale, shift, sums},
+                  {lddz, ldy, lddy, dres ? lddr : 4, act == HN_ACT_RELU ? ldz : 4});
+    const float inv_count = training ? (float)(1.0 / (double)count) : 0.f;
+    HN_LAUNCH_V(pl, bn_act_bwd_apply_kernel, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, sums, inv_count,
+                training, dy, lddy, dres, lddr, npix, C, act, slope, leaky_slope);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_channel_sum(const float* x, int ld, int64_t npix, int C, float* out, void* stream) {
+    if (!x || !out || bad_rows(npix, C, {ld})) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
+    const RowLaunch pl = plan_rows(npix, C, {x}, {ld}, 1024);
+    HN_LAUNCH_V(pl, channel_sum_kernel, x, ld, npix, C, out);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_channel_stats(const float* x, int ld, int64_t npix, int C, float* stats, void* stream) {
+    if (!x || !stats || bad_rows(npix, C, {ld})) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(stats, 0, (size_t)2 * C * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
+    const RowLaunch pl = plan_rows(npix, C, {x}, {ld}, 1024);
+    HN_LAUNCH_V(pl, channel_stats_kernel, x, ld, npix, C, stats);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_act_bwd(const float* dy, int lddy, const float* out, int ldo, float* dx, int lddx, int64_t npix, int C,
+                          int act, float leaky_slope, void* stream) {
+    if (!dy || !out || !dx || act < 0 || act > 3 || bad_rows(npix, C, {lddy, ldo, lddx})) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const RowLaunch pl = plan_rows(npix, C, {dy, out, dx}, {lddy, ldo, lddx});
+    if (pl.V == 4) hipLaunchKernelGGL((rowwise_kernel<4, 0>), pl.grid, pl.block, 0, s, dy, lddy, out, ldo, dx, lddx, npix, C, act, leaky_slope);
+    else hipLaunchKernelGGL((rowwise_kernel<1, 0>), pl.grid, pl.block, 0, s, dy, lddy, out, ldo, dx, lddx, npix, C, act, leaky_slope);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int64_t npix, int C,
+                      void* stream) {
+    if (!a || !b || !y || bad_rows(npix, C, {lda, ldb, ldy})) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const RowLaunch pl = plan_rows(npix, C, {a, b, y}, {lda, ldb, ldy});
+    if (pl.V == 4) hipLaunchKernelGGL((rowwise_kernel<4, 1>), pl.grid, pl.block, 0, s, a, lda, b, ldb, y, ldy, npix, C, 0, 0.f);
+    else hipLaunchKernelGGL((rowwise_kernel<1, 1>), pl.grid, pl.block, 0, s, a, lda, b, ldb, y, ldy, npix, C, 0, 0.f);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_copy(const float* x, int ldx, float* y, int ldy, int64_t npix, int C, void* stream) {
+    if (!x || !y || bad_rows(npix, C, {ldx, ldy})) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const RowLaunch pl = plan_rows(npix, C, {x, y}, {ldx, ldy});
+    if (pl.V == 4) hipLaunchKernelGGL((rowwise_kernel<4, 2>), pl.grid, pl.block, 0, s, x, ldx, nullptr, 0, y, ldy, npix, C, 0, 0.f);
+    else hipLaunchKernelGGL((rowwise_kernel<1, 2>), pl.grid, pl.block, 0, s, x, ldx, nullptr, 0, y, ldy, npix, C, 0, 0.f);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_scale_nc(const float* x, int ldx, const float* mask, float* y, int ldy, int N, int64_t hw, int C,
+                           void* stream) {
+    if (!x || !mask || !y || N <= 0 || hw <= 0 || bad_rows((int64_t)N * hw, C, {ldx, ldy})) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t npix = (int64_t)N * hw;
+    const RowLaunch pl = plan_rows(npix, C, {x, y, mask}, {ldx, ldy});
+    HN_LAUNCH_V(pl, scale_nc_kernel, x, ldx, mask, y, ldy, npix, hw, C);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}

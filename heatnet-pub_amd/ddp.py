@@ -1,0 +1,129 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL all-reduce over xGMI overlapped with backward.
+
+Replaces what the reference gets from `nn.DataParallel` / `DistributedDataParallel`
+(scripts/main.py:103-123, models/confusion_maximization/train_trgb_segnet_conf.py:234): every rank holds a full
+replica, BatchNorm statistics stay per-replica (the reference never uses SyncBN), and the mean-reduced loss makes
+"average the gradients over ranks" equal to the reference's single large batch.
+
+Design for MI355X: gradients live as views into a few large flat fp32 buckets that are allocated once per
+training phase (train_seg: the 54 M segnet parameters, train_critic: the 21 M critic parameters), filled in
+reverse-registration order (~ the order backward produces them).  A post-accumulate-grad hook counts arrivals;
+when a bucket is complete its all-reduce is issued on a dedicated communication stream behind an event, so the
+collective runs while backward continues.  xGMI is point-to-point, so few large messages (default 64 MiB) beat
+many small ones.  No data-path collective other than this one exists.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradBuckets:
+    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, average=True):
+        self.group = process_group
+        self.average = average
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("GradBuckets: no trainable parameters")
+        self.device = self.params[0].device
+        self.on_gpu = self.device.type == "cuda"
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        order = list(reversed(self.params))  # backward reaches the last-registered parameters first
+        self.buckets = []  # dicts: flat, params, pending, work, event
+        cur, cur_bytes = [], 0
+        for p in order:
+            cur.append(p)
+            cur_bytes += p.numel() * 4
+            if cur_bytes >= bucket_bytes:
+                self._seal(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            self._seal(cur)
+        self._hooks = []
+        self._index = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b["params"]:
+                self._index[p] = bi
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._active = False
+
+    def _seal(self, plist):
+        n = sum(p.numel() for p in plist)
+        flat = torch.zeros(n, device=self.device, dtype=torch.float32)
+        off = 0
+        for p in plist:
+            # the view keeps the parameter's own memory layout (channels-last conv weights stay channels-last)
+            view = flat[off:off + p.numel()].as_strided(p.size(), p.stride())
+            p.grad = view
+            off += p.numel()
+        self.buckets.append({"flat": flat, "params": list(plist), "pending": 0, "work": None, "event": None})
+
+    # -- per-step protocol -------------------------------------------------------------------------------
+    def begin_step(self):
+        """Call after optimizer.zero_grad(set_to_none=False): re-arms the arrival counters."""
+        for b in self.buckets:
+            b["pending"] = len(b["params"])
+            b["work"] = None
+            for p in b["params"]:
+                if p.grad is None or p.grad.data_ptr() < b["flat"].data_ptr() or \
+                        p.grad.data_ptr() >= b["flat"].data_ptr() + b["flat"].numel() * 4:
+                    raise RuntimeError("GradBuckets: a gradient left its bucket (use zero_grad(set_to_none=False))")
+        self._active = True
+
+    def _on_grad(self, p):
+        if not self._active:
+            return
+        b = self.buckets[self._index[p]]
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        if self.world == 1:
+            return
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                if self.average:
+                    b["flat"].mul_(1.0 / self.world)
+                b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            if self.average:
+                b["flat"].mul_(1.0 / self.world)
+            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish_step(self):
+        """Call after backward: launches buckets that never filled (unused parameters keep zero gradients) and makes
+        the compute stream wait for every collective before the optimizer reads the gradients."""
+        self._active = False
+        for b in self.buckets:
+            if b["pending"] != 0 and b["work"] is None:
+                b["pending"] = 0
+                self._launch(b)
+        for b in self.buckets:
+            if b["work"] is not None:
+                b["work"].wait()
+                b["work"] = None
+        if self.on_gpu and self.world > 1:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def broadcast_module_state(module, src=0, process_group=None):
+    """Rank `src`'s parameters and buffers to every rank (what DDP does at construction, and what keeps the
+    DataParallel convention that replica 0's BatchNorm running statistics are the ones that persist)."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            if t.is_contiguous():
+                dist.broadcast(t, src, group=process_group)
+            else:
+                tmp = t.contiguous()
+                dist.broadcast(tmp, src, group=process_group)
+                t.copy_(tmp)

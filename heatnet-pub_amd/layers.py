@@ -1,0 +1,112 @@
+"""nn.Module building blocks whose arithmetic is the HIP kernels in `ops`.
+
+They subclass the stock torch modules they replace and keep the same parameter names and logical shapes,
+because the reference's callers re-initialise networks by type / class name (`isinstance(m, nn.Conv2d)` in
+scripts/main.py:361-385; `'Conv'` / `'BatchNorm2d'` in the class name in
+models/confusion_maximization/utils.py:126-132) and exchange `state_dict`s.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _square(v, what):
+    if isinstance(v, (tuple, list)):
+        if len(set(v)) != 1:
+            raise ValueError("HnConv2d supports equal %s in both dimensions, got %r" % (what, v))
+        return int(v[0])
+    return int(v)
+
+
+class HnConv2d(nn.Conv2d):
+    """nn.Conv2d on the implicit-GEMM MFMA kernels.  Weights live in channels-last (OHWI) memory."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.groups != 1 or self.padding_mode != "zeros" or isinstance(self.padding, str):
+            raise ValueError("HnConv2d: groups=1 and numeric zero padding only")
+        self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+
+    def geometry(self):
+        return (_square(self.stride, "stride"), _square(self.padding, "padding"), _square(self.dilation, "dilation"))
+
+    def forward(self, x, act=ops.ACT_NONE, slope=0.0):
+        s, p, d = self.geometry()
+        return ops.conv2d(x, self.weight, self.bias, s, p, d, act, slope)
+
+
+class HnBatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (affine, tracked running stats) on the fused BN kernels."""
+
+    _pending_batches = 0  # forward passes not yet added to `num_batches_tracked` (flushed on state_dict())
+
+    def _flush_batches(self):
+        if self._pending_batches and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(self._pending_batches)
+        self._pending_batches = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush_batches()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._pending_batches = 0
+        super()._load_from_state_dict(*args, **kwargs)
+
+    def forward(self, x, residual=None, act=ops.ACT_NONE, stats=None, prelu_weight=None):
+        training = self.training or self.running_mean is None
+        if training and self.num_batches_tracked is not None:
+            self._pending_batches += 1  # host-side counter: no 1-element kernel per layer per step
+        momentum = 0.1 if self.momentum is None else self.momentum
+        return ops.bn_act(x, stats, self.weight, self.bias, self.running_mean, self.running_var, residual,
+                          prelu_weight, training, momentum, self.eps, act)
+
+
+def conv_bn_act(x, conv, bn, act=ops.ACT_NONE, residual=None, prelu_weight=None):
+    """conv -> BatchNorm (batch statistics from the conv epilogue) -> (+residual) -> activation."""
+    s, p, d = conv.geometry()
+    if bn.training:
+        y, stats = ops.conv2d(x, conv.weight, conv.bias, s, p, d, want_stats=True)
+    else:
+        y, stats = ops.conv2d(x, conv.weight, conv.bias, s, p, d), None
+    return bn(y, residual=residual, act=act, stats=stats, prelu_weight=prelu_weight)
+
+
+class HnPReLU(nn.PReLU):
+    """Single-slope nn.PReLU.  Inside PSPUpsample it is fused behind the BatchNorm; standalone it is an
+    identity-affine BN-free activation pass."""
+
+    def forward(self, x):
+        raise RuntimeError("HnPReLU is fused into the preceding BatchNorm kernel; call the parent block instead")
+
+
+class HnDropout2d(nn.Dropout2d):
+    def forward(self, x, mask=None):
+        return ops.dropout2d(x, self.p, self.training, mask)
+
+
+class HnMaxPool3x3s2(nn.Module):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1)."""
+
+    def forward(self, x):
+        return ops.maxpool3x3s2(x)
+
+
+class HnAdaptiveAvgPool2d(nn.Module):
+    def __init__(self, output_size):
+        super().__init__()
+        self.output_size = output_size
+
+    def forward(self, x):
+        return ops.adaptive_avg_pool(x, self.output_size)
+
+
+def ensure_channels_last_(module):
+    """Re-lay conv weights as OHWI after something (a checkpoint load, `.to()`) made them NCHW-contiguous."""
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d) and m.weight.dim() == 4:
+            w = m.weight.data
+            if not w.is_contiguous(memory_format=torch.channels_last):
+                m.weight.data = w.contiguous(memory_format=torch.channels_last)
+    return module

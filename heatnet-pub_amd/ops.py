@@ -1,0 +1,492 @@
+"""Operators of the HeatNet hot path: `torch.autograd.Function`s whose forward and backward are the
+hand-written gfx950 kernels of libheatnet_hip.so, called through the C ABI (see `_lib.py`).
+
+Tensors keep the reference's LOGICAL NCHW shape (so callers, `state_dict`s and losses see what the
+reference produces) but are physically NHWC: a 4-D tensor here has stride(1) == 1 and a pixel stride
+`ld >= C`, i.e. torch's channels-last format or a channel slice of such a buffer.  PyTorch is used for
+allocation, autograd bookkeeping and streams only -- no arithmetic of the hot path runs in ATen.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import HnConvDesc, check
+
+ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY = 0, 1, 2, 3
+LOSS_MSE, LOSS_BCE = 0, 1
+
+
+# ------------------------------------------------------------------------------------------------------
+# tensor plumbing
+# ------------------------------------------------------------------------------------------------------
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("heatnet_amd operators run on the MI355X only (got a %s tensor); there is no CPU fallback"
+                           % t.device)
+    if t.dtype != torch.float32:
+        raise RuntimeError("heatnet_amd operators compute in fp32, got %s" % t.dtype)
+
+
+def nhwc_ld(t):
+    """Pixel stride of `t` if it is NHWC-strided (see module docstring), else None."""
+    n, c, h, w = t.shape
+    if c > 1 and t.stride(1) != 1:
+        return None
+    if w > 1:
+        ld = t.stride(3)
+    elif h > 1:
+        ld = t.stride(2)
+    elif n > 1:
+        ld = t.stride(0)
+    else:
+        ld = c
+    if ld < c:
+        return None
+    if (w > 1 and t.stride(3) != ld) or (h > 1 and t.stride(2) != w * ld) or (n > 1 and t.stride(0) != h * w * ld):
+        return None
+    return ld
+
+
+def as_nhwc(t):
+    """Return (tensor, ld) with NHWC strides, copying only when `t` is laid out otherwise."""
+    _require_gpu(t)
+    ld = nhwc_ld(t)
+    if ld is None:
+        t = t.contiguous(memory_format=torch.channels_last)
+        ld = nhwc_ld(t)
+        if ld is None:  # degenerate sizes for which torch reports ambiguous strides
+            n, c, h, w = t.shape
+            t = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+            ld = c
+    return t, ld
+
+
+def new_nhwc(n, c, h, w, device, dtype=torch.float32):
+    return torch.empty((n, h, w, c), device=device, dtype=dtype).permute(0, 3, 1, 2)
+
+
+def weight_ohwi(w):
+    """Conv weight (logical OIHW) as a dense [O][KH][KW][I] buffer; a no-op for channels-last parameters."""
+    _require_gpu(w)
+    o, i, kh, kw = w.shape
+    expect = (kh * kw * i, 1, kw * i, i)
+    ok = all(w.shape[d] == 1 or w.stride(d) == expect[d] for d in range(4))
+    if not ok:
+        w = w.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return w
+
+
+def conv_out_size(h, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def _desc(n, h, w, cin, ldx, ho, wo, cout, ldy, kh, kw, stride, pad, dil):
+    return HnConvDesc(n, h, w, cin, ldx, ho, wo, cout, ldy, kh, kw, stride, pad, dil)
+
+
+# ------------------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------------------
+
+class _Conv2d(torch.autograd.Function):
+    """y = act(conv(x, w) + b) [+ per-channel batch statistics of the pre-activation output]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, dil, act, slope, want_stats):
+        lib = _lib.load()
+        x, ldx = as_nhwc(x)
+        w = weight_ohwi(w)
+        n, cin, h, wd = x.shape
+        cout, cin_w, kh, kw = w.shape
+        if cin_w != cin:
+            raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (cin, cin_w))
+        ho, wo = conv_out_size(h, kh, stride, pad, dil), conv_out_size(wd, kw, stride, pad, dil)
+        y = new_nhwc(n, cout, ho, wo, x.device)
+        stats = torch.zeros(2 * cout, device=x.device, dtype=torch.float32) if want_stats else None
+        d = _desc(n, h, wd, cin, ldx, ho, wo, cout, cout, kh, kw, stride, pad, dil)
+        check(lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(stats), ctypes.byref(d), act, slope,
+                                _stream()), "hn_conv2d_fwd")
+        ctx.geom = (stride, pad, dil, act, slope)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, *unused):
+        lib = _lib.load()
+        x, w, y = ctx.saved_tensors
+        stride, pad, dil, act, slope = ctx.geom
+        x, ldx = as_nhwc(x)
+        dy, lddy = as_nhwc(dy)
+        n, cin, h, wd = x.shape
+        cout, _, kh, kw = w.shape
+        _, _, ho, wo = dy.shape
+        npix = n * ho * wo
+        s = _stream()
+        if act != ACT_NONE:
+            dpre = new_nhwc(n, cout, ho, wo, x.device)
+            check(lib.hn_act_bwd(_ptr(dy), lddy, _ptr(y), cout, _ptr(dpre), cout, npix, cout, act, slope, s),
+                  "hn_act_bwd")
+            dy, lddy = dpre, cout
+        d = _desc(n, h, wd, cin, ldx, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.empty(cin * kh * kw * cout, device=x.device, dtype=torch.float32)
+            check(lib.hn_weight_flip_transpose(_ptr(w), _ptr(wt), cout, kh, kw, cin, s), "hn_weight_flip_transpose")
+            dx = new_nhwc(n, cin, h, wd, x.device)
+            dd = _desc(n, h, wd, cin, cin, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
+            check(lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(dx), ctypes.byref(dd), s), "hn_conv2d_dgrad")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((cout, kh, kw, cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
+            check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), 0, s), "hn_conv2d_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(cout, device=x.device, dtype=torch.float32)
+            check(lib.hn_channel_sum(_ptr(dy), lddy, npix, cout, _ptr(db), s), "hn_channel_sum")
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def conv2d(x, w, b=None, stride=1, pad=0, dil=1, act=ACT_NONE, slope=0.0, want_stats=False):
+    return _Conv2d.apply(x, w, b, int(stride), int(pad), int(dil), int(act), float(slope), bool(want_stats))
+
+
+# ------------------------------------------------------------------------------------------------------
+# batch norm (+ residual) (+ activation)
+# ------------------------------------------------------------------------------------------------------
+
+class _BnAct(torch.autograd.Function):
+    """z = act(bn(y) + residual).  Training mode takes the batch statistics produced by the conv epilogue
+    (or computes them when `stats` is None) and updates the running buffers in place, as nn.BatchNorm2d does."""
+
+    @staticmethod
+    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, residual, prelu_w, training, momentum, eps,
+                act, leaky):
+        lib = _lib.load()
+        y, ldy = as_nhwc(y)
+        n, c, h, w = y.shape
+        npix = n * h * w
+        s = _stream()
+        dev = y.device
+        par = torch.empty(4 * c, device=dev, dtype=torch.float32)  # mean | invstd | scale | shift
+        mean, invstd, scale, shift = par[0:c], par[c:2 * c], par[2 * c:3 * c], par[3 * c:4 * c]
+        if training:
+            if stats is None:
+                stats = torch.empty(2 * c, device=dev, dtype=torch.float32)
+                check(lib.hn_channel_stats(_ptr(y), ldy, npix, c, _ptr(stats), s), "hn_channel_stats")
+            check(lib.hn_bn_finalize(_ptr(stats), npix, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                     momentum, eps, _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift), c, s),
+                  "hn_bn_finalize")
+        else:
+            check(lib.hn_bn_eval_params(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), eps,
+                                        _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift), c, s), "hn_bn_eval_params")
+        ldr = 0
+        if residual is not None:
+            if act in (ACT_PRELU, ACT_LEAKY):
+                raise RuntimeError("bn_act: a residual input is only supported with ReLU / no activation")
+            residual, ldr = as_nhwc(residual)
+        z = new_nhwc(n, c, h, w, dev)
+        check(lib.hn_bn_act_fwd(_ptr(y), ldy, _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(z), c, npix, c, act,
+                                _ptr(prelu_w), leaky, s), "hn_bn_act_fwd")
+        ctx.cfg = (training, act, leaky, residual is not None)
+        ctx.save_for_backward(y, z if act == ACT_RELU else None, par, gamma, prelu_w)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        y, z, par, gamma, prelu_w = ctx.saved_tensors
+        training, act, leaky, has_res = ctx.cfg
+        y, ldy = as_nhwc(y)
+        dz, lddz = as_nhwc(dz)
+        n, c, h, w = y.shape
+        npix = n * h * w
+        s = _stream()
+        mean, invstd, scale, shift = par[0:c], par[c:2 * c], par[2 * c:3 * c], par[3 * c:4 * c]
+        ldz = c
+        sums = torch.empty(2 * c + 1, device=y.device, dtype=torch.float32)
+        check(lib.hn_bn_act_bwd_reduce(_ptr(dz), lddz, _ptr(z), ldz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(scale),
+                                       _ptr(shift), npix, c, act, _ptr(prelu_w), leaky, _ptr(sums), s),
+              "hn_bn_act_bwd_reduce")
+        dy = new_nhwc(n, c, h, w, y.device) if ctx.needs_input_grad[0] else None
+        dres = new_nhwc(n, c, h, w, y.device) if (has_res and ctx.needs_input_grad[6]) else None
+        if dy is not None or dres is not None:
+            if dy is None:
+                dy = new_nhwc(n, c, h, w, y.device)
+            check(lib.hn_bn_act_bwd_apply(_ptr(dz), lddz, _ptr(z), ldz, _ptr(y), ldy, _ptr(mean), _ptr(invstd),
+                                          _ptr(gamma), _ptr(scale), _ptr(shift), _ptr(sums), npix, int(training),
+                                          _ptr(dy), c, _ptr(dres), c, npix, c, act, _ptr(prelu_w), leaky, s),
+                  "hn_bn_act_bwd_apply")
+        dgamma = sums[c:2 * c] if ctx.needs_input_grad[2] else None
+        dbeta = sums[0:c] if ctx.needs_input_grad[3] else None
+        dprelu = sums[2 * c:2 * c + 1] if (prelu_w is not None and ctx.needs_input_grad[7]) else None
+        return dy, None, dgamma, dbeta, None, None, dres, dprelu, None, None, None, None, None
+
+
+def bn_act(y, stats, gamma, beta, running_mean, running_var, residual=None, prelu_weight=None, training=True,
+           momentum=0.1, eps=1e-5, act=ACT_NONE, leaky=0.0):
+    return _BnAct.apply(y, stats, gamma, beta, running_mean, running_var, residual, prelu_weight, bool(training),
+                        float(momentum), float(eps), int(act), float(leaky))
+
+
+# ------------------------------------------------------------------------------------------------------
+# spatial operators
+# ------------------------------------------------------------------------------------------------------
+
+class _MaxPool3x3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x, ldx = as_nhwc(x)
+        n, c, h, w = x.shape
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = new_nhwc(n, c, ho, wo, x.device)
+        idx = torch.empty(n * ho * wo * c, device=x.device, dtype=torch.uint8)
+        check(lib.hn_maxpool3x3s2_fwd(_ptr(x), ldx, _ptr(y), c, _ptr(idx), n, h, w, c, ho, wo, _stream()),
+              "hn_maxpool3x3s2_fwd")
+        ctx.shape = (n, c, h, w, ho, wo)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        n, c, h, w, ho, wo = ctx.shape
+        dy, lddy = as_nhwc(dy)
+        dx = new_nhwc(n, c, h, w, dy.device)
+        check(lib.hn_maxpool3x3s2_bwd(_ptr(dy), lddy, _ptr(idx), _ptr(dx), c, n, h, w, c, ho, wo, _stream()),
+              "hn_maxpool3x3s2_bwd")
+        return dx
+
+
+def maxpool3x3s2(x):
+    return _MaxPool3x3s2.apply(x)
+
+
+class _AdaptiveAvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ho, wo):
+        lib = _lib.load()
+        x, ldx = as_nhwc(x)
+        n, c, h, w = x.shape
+        y = new_nhwc(n, c, ho, wo, x.device)
+        check(lib.hn_adaptive_avgpool_fwd(_ptr(x), ldx, _ptr(y), c, n, h, w, c, ho, wo, _stream()),
+              "hn_adaptive_avgpool_fwd")
+        ctx.shape = (n, c, h, w, ho, wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        n, c, h, w, ho, wo = ctx.shape
+        dy, lddy = as_nhwc(dy)
+        dx = new_nhwc(n, c, h, w, dy.device)
+        check(lib.hn_adaptive_avgpool_bwd(_ptr(dy), lddy, _ptr(dx), c, n, h, w, c, ho, wo, _stream()),
+              "hn_adaptive_avgpool_bwd")
+        return dx, None, None
+
+
+def adaptive_avg_pool(x, size):
+    ho, wo = (size, size) if isinstance(size, int) else size
+    return _AdaptiveAvgPool.apply(x, int(ho), int(wo))
+
+
+class _Bilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ho, wo):
+        lib = _lib.load()
+        x, ldx = as_nhwc(x)
+        n, c, h, w = x.shape
+        y = new_nhwc(n, c, ho, wo, x.device)
+        check(lib.hn_bilinear_fwd(_ptr(x), ldx, _ptr(y), c, n, h, w, c, ho, wo, _stream()), "hn_bilinear_fwd")
+        ctx.shape = (n, c, h, w, ho, wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        n, c, h, w, ho, wo = ctx.shape
+        dy, lddy = as_nhwc(dy)
+        dx = new_nhwc(n, c, h, w, dy.device)
+        check(lib.hn_bilinear_bwd(_ptr(dy), lddy, _ptr(dx), c, n, h, w, c, ho, wo, _stream()), "hn_bilinear_bwd")
+        return dx, None, None
+
+
+def bilinear(x, size):
+    return _Bilinear.apply(x, int(size[0]), int(size[1]))
+
+
+class _ScaleNC(torch.autograd.Function):
+    """x * mask[n, c] -- Dropout2d with a pre-drawn keep/(1-p) mask."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        lib = _lib.load()
+        x, ldx = as_nhwc(x)
+        n, c, h, w = x.shape
+        mask = mask.contiguous()
+        y = new_nhwc(n, c, h, w, x.device)
+        check(lib.hn_scale_nc(_ptr(x), ldx, _ptr(mask), _ptr(y), c, n, h * w, c, _stream()), "hn_scale_nc")
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (mask,) = ctx.saved_tensors
+        dy, lddy = as_nhwc(dy)
+        n, c, h, w = dy.shape
+        dx = new_nhwc(n, c, h, w, dy.device)
+        check(lib.hn_scale_nc(_ptr(dy), lddy, _ptr(mask), _ptr(dx), c, n, h * w, c, _stream()), "hn_scale_nc")
+        return dx, None
+
+
+def dropout2d(x, p, training, mask=None):
+    """nn.Dropout2d: whole (n, c) maps dropped with probability p and survivors scaled by 1/(1-p)."""
+    if mask is None:
+        if not training or p == 0.0:
+            return x
+        n, c = x.shape[0], x.shape[1]
+        mask = torch.bernoulli(torch.full((n, c), 1.0 - p, device=x.device, dtype=torch.float32)) / (1.0 - p)
+    return _ScaleNC.apply(x, mask)
+
+
+class _Concat(torch.autograd.Function):
+    """torch.cat(dim=1) as strided copies into one NHWC buffer; backward hands out channel-slice views."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        lib = _lib.load()
+        xs = [as_nhwc(x) for x in xs]
+        n, _, h, w = xs[0][0].shape
+        ctot = sum(x.shape[1] for x, _ in xs)
+        out = new_nhwc(n, ctot, h, w, xs[0][0].device)
+        c0, s = 0, _stream()
+        ctx.splits = []
+        for x, ld in xs:
+            c = x.shape[1]
+            check(lib.hn_copy(_ptr(x), ld, ctypes.c_void_p(out.data_ptr() + 4 * c0), ctot, n * h * w, c, s), "hn_copy")
+            ctx.splits.append((c0, c))
+            c0 += c
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return tuple(dy[:, c0:c0 + c] for c0, c in ctx.splits)
+
+
+def concat(xs):
+    return _Concat.apply(*xs)
+
+
+# ------------------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------------------
+
+class _CrossEntropy(torch.autograd.Function):
+    """nn.CrossEntropyLoss(ignore_index=...) with mean reduction over the counted pixels."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        lib = _lib.load()
+        logits, ld = as_nhwc(logits)
+        n, c, h, w = logits.shape
+        if labels.dtype != torch.int64 or not labels.is_cuda:
+            raise RuntimeError("cross_entropy: labels must be a cuda int64 tensor")
+        labels = labels.contiguous()
+        if labels.numel() != n * h * w:
+            raise RuntimeError("cross_entropy: labels do not match logits")
+        out = torch.empty(2, device=logits.device, dtype=torch.float32)
+        check(lib.hn_ce_fwd(_ptr(logits), ld, _ptr(labels), n * h * w, c, ignore_index, _ptr(out), _stream()),
+              "hn_ce_fwd")
+        ctx.save_for_backward(logits, labels, out)
+        ctx.ignore = ignore_index
+        return out[0] / out[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        logits, labels, out = ctx.saved_tensors
+        logits, ld = as_nhwc(logits)
+        n, c, h, w = logits.shape
+        g = g.contiguous().reshape(1)
+        dl = new_nhwc(n, c, h, w, logits.device)
+        check(lib.hn_ce_bwd(_ptr(logits), ld, _ptr(labels), n * h * w, c, ctx.ignore, _ptr(out), _ptr(g), _ptr(dl), c,
+                            _stream()), "hn_ce_bwd")
+        return dl, None, None
+
+
+def cross_entropy(logits, labels, ignore_index=-100):
+    return _CrossEntropy.apply(logits, labels, int(ignore_index))
+
+
+class _AdvLoss(torch.autograd.Function):
+    """mean over all elements of MSE / BCE-with-logits against a constant target map."""
+
+    @staticmethod
+    def forward(ctx, x, target, kind):
+        lib = _lib.load()
+        _require_gpu(x)
+        x = x.contiguous()
+        out = torch.empty(1, device=x.device, dtype=torch.float32)
+        check(lib.hn_adv_loss_fwd(_ptr(x), x.numel(), target, kind, _ptr(out), _stream()), "hn_adv_loss_fwd")
+        ctx.save_for_backward(x)
+        ctx.cfg = (target, kind)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        target, kind = ctx.cfg
+        g = g.contiguous().reshape(1)
+        dx = torch.empty_like(x)
+        check(lib.hn_adv_loss_bwd(_ptr(x), x.numel(), target, kind, _ptr(g), _ptr(dx), _stream()), "hn_adv_loss_bwd")
+        return dx, None, None
+
+
+def adv_loss(x, target, kind):
+    if isinstance(kind, str):
+        kind = {"MSE": LOSS_MSE, "BCE": LOSS_BCE}[kind]
+    return _AdvLoss.apply(x, float(target), int(kind))
+
+
+# ------------------------------------------------------------------------------------------------------
+# evaluation / optimizer helpers (no autograd)
+# ------------------------------------------------------------------------------------------------------
+
+def argmax_confusion(logits, labels, num_classes):
+    """(pred uint8 [N,H,W], conf int64 [K,K]) with conf[label, pred] counts; labels outside [0,K) are skipped."""
+    lib = _lib.load()
+    logits, ld = as_nhwc(logits)
+    n, c, h, w = logits.shape
+    pred = torch.empty((n, h, w), device=logits.device, dtype=torch.uint8)
+    conf = torch.zeros((num_classes, num_classes), device=logits.device, dtype=torch.int64)
+    lab = labels.contiguous() if labels is not None else None
+    check(lib.hn_argmax_confusion(_ptr(logits), ld, _ptr(lab), n * h * w, c, num_classes, _ptr(conf), _ptr(pred),
+                                  _stream()), "hn_argmax_confusion")
+    return pred, conf
+
+
+def rmsprop_step_(param, grad, square_avg, lr, alpha=0.99, eps=1e-8, weight_decay=0.0):
+    lib = _lib.load()
+    check(lib.hn_rmsprop_step(_ptr(param), _ptr(grad), _ptr(square_avg), param.numel(), lr, alpha, eps, weight_decay,
+                              _stream()), "hn_rmsprop_step")
+
+
+def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    lib = _lib.load()
+    check(lib.hn_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), lr, beta1, beta2,
+                           eps, weight_decay, step, _stream()), "hn_adam_step")

@@ -1,0 +1,83 @@
+"""PSPNet head and decoder of HeatNet on the HIP kernels.
+
+Operator surface and `state_dict` keys follow
+    models/confusion_maximization/models/pspnet.py:8-76   (HeatNet: forward(modal_1, modal_2) -> (out, feats, None))
+    models/pspnet.py:8-75                                 (RGB-only: forward(x) -> logits, 18 classes)
+"""
+import torch.nn as nn
+
+from . import ops
+from . import resnet as extractors
+from .layers import HnAdaptiveAvgPool2d, HnBatchNorm2d, HnConv2d, HnDropout2d, HnPReLU, conv_bn_act
+
+
+class PSPModule(nn.Module):
+    """Pyramid pooling: 4 x (adaptive avg pool -> 1x1 conv -> bilinear up), concat with the input, 1x1 + ReLU."""
+
+    def __init__(self, features, out_features=1024, sizes=(1, 2, 3, 6)):
+        super().__init__()
+        self.stages = nn.ModuleList([self._make_stage(features, size) for size in sizes])
+        self.bottleneck = HnConv2d(features * (len(sizes) + 1), out_features, kernel_size=1)
+        self.relu = nn.ReLU()
+
+    @staticmethod
+    def _make_stage(features, size):
+        return nn.Sequential(HnAdaptiveAvgPool2d((size, size)), HnConv2d(features, features, kernel_size=1, bias=False))
+
+    def forward(self, feats):
+        hw = (feats.size(2), feats.size(3))
+        priors = [ops.bilinear(stage[1](stage[0](feats)), hw) for stage in self.stages]
+        bottle = ops.concat(priors + [feats])
+        return self.bottleneck(bottle, act=ops.ACT_RELU)  # ReLU fused in the conv epilogue
+
+
+class PSPUpsample(nn.Module):
+    """bilinear x2 -> conv3x3(+bias) -> BatchNorm -> PReLU (one fused BN/PReLU kernel)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Sequential(HnConv2d(in_channels, out_channels, 3, padding=1), HnBatchNorm2d(out_channels),
+                                  HnPReLU())
+
+    def forward(self, x):
+        p = ops.bilinear(x, (2 * x.size(2), 2 * x.size(3)))
+        return conv_bn_act(p, self.conv[0], self.conv[1], ops.ACT_PRELU, prelu_weight=self.conv[2].weight)
+
+
+class PSPNet(nn.Module):
+    """`rgb_only=False`: HeatNet signature; `rgb_only=True`: the top-level models/pspnet.py signature."""
+
+    def __init__(self, n_classes=13, sizes=(1, 2, 3, 6), psp_size=2048, deep_features_size=1024, backend="resnet34",
+                 pretrained=True, late_fusion=False, in_channels=3, rgb_only=False):
+        super().__init__()
+        self.rgb_only = rgb_only
+        ctor = getattr(extractors, backend)
+        if rgb_only:
+            self.feats = ctor(pretrained, dual=False)
+        elif backend == "resnet50":
+            self.feats = ctor(pretrained, late_fusion=late_fusion, in_channels=in_channels)
+        else:
+            self.feats = ctor(pretrained)
+        self.psp = PSPModule(psp_size, 1024, sizes)
+        self.drop_1 = HnDropout2d(p=0.3)
+        self.up_1 = PSPUpsample(1024, 256)
+        self.up_2 = PSPUpsample(256, 64)
+        self.up_3 = PSPUpsample(64, 64)
+        self.drop_2 = HnDropout2d(p=0.15)
+        self.final = nn.Sequential(HnConv2d(64, n_classes, kernel_size=1))
+
+    def forward(self, modal_1, modal_2=None):
+        if self.rgb_only:
+            top, _ = self.feats(modal_1)
+            f = None
+        else:
+            f = self.feats(modal_1, modal_2)
+            top = f[0]
+        p = self.drop_1(self.psp(top))
+        p = self.drop_2(self.up_1(p))
+        p = self.drop_2(self.up_2(p))
+        p = self.drop_2(self.up_3(p))
+        out = self.final(p)
+        if self.rgb_only:
+            return out
+        return out, [out, f[0], f[1], f[2], f[3], f[4]], None

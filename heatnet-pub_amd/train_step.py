@@ -1,0 +1,108 @@
+"""The HeatNet training iteration (losses + phase machine) on the HIP kernels.
+
+Restates the body of the hot loop of models/confusion_maximization/train_trgb_segnet_conf.py:383-592 for the default
+configuration (no night supervision, no cert branch, critic weights all 1): the reference trainer itself is a
+module-level script that cannot be imported (wandb.init at import), so this module is what a caller drives.
+"""
+import torch
+
+from . import ops
+
+
+def critic_loss(out, adv="MSE"):
+    """:437-446 -- critics learn day -> 1, night -> 0."""
+    total = None
+    for c in out["critics_a"]:
+        term = ops.adv_loss(c, 1.0, adv)
+        total = term if total is None else total + term
+    for c in out["critics_b"]:
+        total = total + ops.adv_loss(c, 0.0, adv)
+    return total
+
+
+def confusion_loss(out, adv="MSE", weights=None, multidir=False):
+    """:526-540 -- the segmentation net is trained so that both domains look like 'day' (1) to every critic.
+
+    The reference multiplies the mean-reduced criterion by a bilinear-resized all-ones map and averages again,
+    which is the criterion itself.
+    """
+    n = len(out["critics_a"])
+    weights = [1.0] * n if weights is None else weights
+    total = None
+    for m, c in enumerate(out["critics_a"]):
+        term = ops.adv_loss(c, 0.0 if multidir else 1.0, adv) * weights[m]
+        total = term if total is None else total + term
+    for m, c in enumerate(out["critics_b"]):
+        total = total + ops.adv_loss(c, 1.0, adv) * weights[m]
+    return total
+
+
+def segmentation_loss(logits, labels, ignore_index=-100):
+    """nn.CrossEntropyLoss() of :244,452 (HeatNet) / ignore_index=13 of scripts/main.py:223."""
+    return ops.cross_entropy(logits, labels, ignore_index)
+
+
+class PhaseSchedule:
+    """:361-367,577-592 -- start with `initial_critic` critic iterations, then alternate seg / critic phases."""
+
+    def __init__(self, initial_critic=1000, seg=50, critic=500, no_conf=False):
+        self.state = "train_seg" if no_conf else "train_critic"
+        self.counter = initial_critic
+        self.seg, self.critic, self.no_conf = seg, critic, no_conf
+
+    def tick(self):
+        if self.no_conf:
+            return False
+        self.counter -= 1
+        if self.counter != 0:
+            return False
+        if self.state == "train_seg":
+            self.state, self.counter = "train_critic", self.critic
+        else:
+            self.state, self.counter = "train_seg", self.seg
+        return True
+
+
+def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_weight=0.1, grad_sync=None):
+    """One iteration: zero_grad, forward (day + night passes, critics), loss of the phase, backward, step.
+
+    `model` is a `conv_segnet` (possibly wrapped so that `.module` exists); `grad_sync`, when given, is a
+    `ddp.GradBuckets` whose all-reduce overlaps the backward pass.  Returns the loss tensors (no host sync).
+    """
+    optimizer.zero_grad(set_to_none=grad_sync is None)
+    if grad_sync is not None:
+        grad_sync.begin_step()
+    out = model(day, night)
+    losses = {}
+    if state == "train_seg":
+        seg = segmentation_loss(out["pred_label_a"], label_day)
+        losses["seg"] = seg.detach()
+        if "critics_a" in out:
+            conf = confusion_loss(out, adv)
+            total = seg + conf_weight * conf
+            losses["conf"] = conf.detach()
+        else:
+            total = seg
+    else:
+        total = critic_loss(out, adv)
+    total.backward()
+    if grad_sync is not None:
+        grad_sync.finish_step()
+    optimizer.step()
+    losses["total"] = total.detach()
+    return losses
+
+
+def segmentation_step(model, optimizer, rgb, ir, labels, ignore_index=-100, grad_sync=None):
+    """BASELINE config 2: dual-stream PSPNet forward/backward + CE + optimizer step (no critics)."""
+    optimizer.zero_grad(set_to_none=grad_sync is None)
+    if grad_sync is not None:
+        grad_sync.begin_step()
+    res = model(rgb, ir) if ir is not None else model(rgb)
+    logits = res[0] if isinstance(res, tuple) else res
+    loss = segmentation_loss(logits, labels, ignore_index)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync.finish_step()
+    optimizer.step()
+    return loss.detach()

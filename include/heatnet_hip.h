@@ -1,0 +1,184 @@
+/*
+ * heatnet_hip.h -- C ABI of libheatnet_hip.so, the MI355X (gfx950) kernels behind the
+ * HeatNet training hot path.
+ *
+ * The reference (jzuern/heatnet-pub) has no native layer: every operator below replaces a
+ * `torch.nn` / `torch.nn.functional` call made by the reference's model code, and the
+ * citation on each entry point names that call site (paths relative to the reference root,
+ * "cm/" = models/confusion_maximization/).  The Python host (heatnet-pub_amd/) binds these
+ * symbols with ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - All tensors are fp32, caller-owned device memory, NHWC ("channels-last") physical
+ *     layout.  A tensor is (pointer, ld): `ld` is the distance in ELEMENTS between two
+ *     consecutive pixels (>= channel count), so a channel slice of a wider buffer is a
+ *     valid operand and channel concatenation needs no copy.  Pixels are dense:
+ *     pixel index = (n*H + h)*W + w.
+ *   - Convolution weights are [Cout][KH][KW][Cin] (= an OIHW tensor in channels-last
+ *     memory format), dense.
+ *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant,
+ *     keeps no global mutable state and allocates nothing.
+ *   - Return value: HN_OK or a negative HN_E* code; nothing is thrown across the ABI.
+ */
+#ifndef HEATNET_HIP_H
+#define HEATNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HN_OK 0
+#define HN_EINVAL (-1)   /* bad argument (null pointer, non-positive size, bad enum)        */
+#define HN_EALIGN (-2)   /* pointer / ld not aligned as the kernel requires                  */
+#define HN_ELAUNCH (-3)  /* hipLaunchKernel / hipMemsetAsync reported an error               */
+#define HN_ESHAPE (-4)   /* sizes inconsistent with each other (e.g. Hout vs Hin/stride/pad) */
+
+/* activation fused behind an affine/conv epilogue */
+#define HN_ACT_NONE 0
+#define HN_ACT_RELU 1
+#define HN_ACT_PRELU 2   /* one shared slope read from device memory (nn.PReLU())  */
+#define HN_ACT_LEAKY 3   /* constant slope (nn.LeakyReLU(0.2))                     */
+
+#define HN_LOSS_MSE 0
+#define HN_LOSS_BCE 1
+
+typedef struct HnConvDesc {
+    int32_t N, Hin, Win, Cin, ldx;    /* input  NHWC, pixel stride ldx  */
+    int32_t Hout, Wout, Cout, ldy;    /* output NHWC, pixel stride ldy  */
+    int32_t KH, KW, stride, pad, dil; /* square stride/pad/dilation as used by the reference */
+} HnConvDesc;
+
+const char* hn_strerror(int code);
+int hn_version(void);
+
+/* ---- convolution: nn.Conv2d in cm/models/extractors.py:71-77,111-146, cm/models/pspnet.py:13,18,32,57,
+ *      cm/discriminator_model.py:40-44.  Implicit GEMM on v_mfma_f32_32x32x2_f32. ------------------------- */
+
+/* y = act(conv(x, w) + bias).  `bias` may be NULL.  If `stats` is non-NULL it must hold 2*Cout floats,
+ * zeroed by the caller; the kernel adds per-channel sum and sum of squares of the PRE-activation output
+ * (the batch statistics nn.BatchNorm2d needs, cm/models/extractors.py:72,75,77). */
+int hn_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* stats,
+                  const HnConvDesc* d, int act, float slope, void* stream);
+
+/* wt[Cin][KH][KW][Cout] = w[Cout][KH-1-kh][KW-1-kw][Cin]: operand of hn_conv2d_dgrad. */
+int hn_weight_flip_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
+
+/* dx = conv_transpose(dy, w) for the forward geometry `d` (dy is N x Hout x Wout x Cout with pixel stride
+ * d->ldy, dx is N x Hin x Win x Cin with pixel stride d->ldx); `wt` from hn_weight_flip_transpose.
+ * Overwrites dx. */
+int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, const HnConvDesc* d, void* stream);
+
+/* dw[Cout][KH][KW][Cin] = sum over pixels of dy (x) x.  Overwrites dw.  split_k <= 0 picks one. */
+int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, void* stream);
+
+/* out[c] = sum over npix pixels of x[p*ld + c]  (bias gradient).  `out` is overwritten. */
+int hn_channel_sum(const float* x, int ld, int64_t npix, int C, float* out, void* stream);
+
+/* stats = {sum[C], sumsq[C]} over npix pixels (overwritten): batch statistics of a tensor that did not come
+ * out of hn_conv2d_fwd. */
+int hn_channel_stats(const float* x, int ld, int64_t npix, int C, float* stats, void* stream);
+
+/* ---- batch norm + activation (+ residual): nn.BatchNorm2d / ReLU / PReLU / `out += residual`,
+ *      cm/models/extractors.py:84-100, cm/models/pspnet.py:31-35 ------------------------------------------ */
+
+/* From stats = {sum[C], sumsq[C]} over `count` values per channel: mean, invstd = 1/sqrt(var_biased+eps),
+ * scale = gamma*invstd, shift = beta - mean*scale; running stats updated in place when non-NULL
+ * (momentum 0.1 style, unbiased variance), exactly as nn.BatchNorm2d in training mode. */
+int hn_bn_finalize(const float* stats, int64_t count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps,
+                   float* mean, float* invstd, float* scale, float* shift, int C, void* stream);
+
+/* Inference-mode statistics: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale;
+ * mean/invstd are filled too so that the backward entry points can be shared. */
+int hn_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, float* mean, float* invstd, float* scale, float* shift, int C, void* stream);
+
+/* z = act(y*scale[c] + shift[c] + residual).  residual may be NULL; `slope` is a device pointer for
+ * HN_ACT_PRELU, ignored otherwise (HN_ACT_LEAKY uses leaky_slope). */
+int hn_bn_act_fwd(const float* y, int ldy, const float* scale, const float* shift,
+                  const float* residual, int ldr, float* z, int ldz, int64_t npix, int C,
+                  int act, const float* slope, float leaky_slope, void* stream);
+
+/* First backward pass.  du = dz * act'(u), u = y*scale+shift(+residual).  Writes
+ * sums = {sum du [C], sum du*xhat [C], dslope [1]} (overwritten; xhat = (y-mean)*invstd).
+ * For HN_ACT_RELU the mask is taken from z > 0; for PRELU/LEAKY u is recomputed from y (residual must be NULL). */
+int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                         const float* mean, const float* invstd, const float* scale, const float* shift,
+                         int64_t npix, int C, int act, const float* slope, float leaky_slope,
+                         float* sums, void* stream);
+
+/* Second backward pass: dy = gamma*invstd*(du - sum_du/count - xhat*sum_duxhat/count) when `training`,
+ * dy = gamma*invstd*du otherwise; dres = du when dres != NULL (gradient of the residual input). */
+int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                        const float* mean, const float* invstd, const float* gamma, const float* scale,
+                        const float* shift, const float* sums, int64_t count, int training,
+                        float* dy, int lddy, float* dres, int lddr, int64_t npix, int C,
+                        int act, const float* slope, float leaky_slope, void* stream);
+
+/* dx = dy * act'(y_out) for an activation applied in a conv epilogue (LeakyReLU / ReLU: the sign of the
+ * output equals the sign of the pre-activation).  In place allowed (dx == dy). */
+int hn_act_bwd(const float* dy, int lddy, const float* out, int ldo, float* dx, int lddx,
+               int64_t npix, int C, int act, float leaky_slope, void* stream);
+
+/* y[n,:,:,c] = x[n,:,:,c] * mask[n*C + c]: nn.Dropout2d forward and backward given a host-drawn
+ * keep/(1-p) mask, cm/models/pspnet.py:49,55,63-72. */
+int hn_scale_nc(const float* x, int ldx, const float* mask, float* y, int ldy, int N, int64_t hw, int C, void* stream);
+
+/* y = a + b (elementwise over npix x C): gradient accumulation where two branches meet. */
+int hn_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int64_t npix, int C, void* stream);
+
+/* y = x (strided copy, used to place a tensor into a channel slice). */
+int hn_copy(const float* x, int ldx, float* y, int ldy, int64_t npix, int C, void* stream);
+
+/* ---- spatial operators ------------------------------------------------------------------------------- */
+
+/* nn.MaxPool2d(3, stride 2, padding 1), cm/models/extractors.py:128.  `idx` (uint8, dense N*Ho*Wo*C)
+ * receives the window position kh*3+kw of the first maximum. */
+int hn_maxpool3x3s2_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx,
+                        int N, int H, int W, int C, int Ho, int Wo, void* stream);
+int hn_maxpool3x3s2_bwd(const float* dy, int lddy, const uint8_t* idx, float* dx, int lddx,
+                        int N, int H, int W, int C, int Ho, int Wo, void* stream);
+
+/* nn.AdaptiveAvgPool2d((Ho,Wo)), cm/models/pspnet.py:17: bin i covers [floor(i*H/Ho), ceil((i+1)*H/Ho)). */
+int hn_adaptive_avgpool_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+int hn_adaptive_avgpool_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+
+/* F.upsample(mode='bilinear') == align_corners=False, cm/models/pspnet.py:23,39 and nn.Upsample(32),
+ * cm/discriminator_model.py:47,61.  Source coordinate = max(0, (o+0.5)*Hin/Hout - 0.5). */
+int hn_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int Hin, int Win, int C, int Hout, int Wout, void* stream);
+int hn_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int Hin, int Win, int C, int Hout, int Wout, void* stream);
+
+/* ---- losses ------------------------------------------------------------------------------------------ */
+
+/* nn.CrossEntropyLoss (mean over non-ignored pixels), cm/train_trgb_segnet_conf.py:244,452 and
+ * scripts/main.py:223.  out = {sum of -log softmax[label], number of counted pixels} (overwritten). */
+int hn_ce_fwd(const float* logits, int ld, const int64_t* labels, int64_t npix, int C, int64_t ignore_index,
+              float* out, void* stream);
+/* dlogits = (*gout / out[1]) * (softmax - onehot), 0 on ignored pixels. */
+int hn_ce_bwd(const float* logits, int ld, const int64_t* labels, int64_t npix, int C, int64_t ignore_index,
+              const float* out, const float* gout, float* dlogits, int lddl, void* stream);
+
+/* nn.MSELoss / nn.BCEWithLogitsLoss against a constant map, mean-reduced,
+ * cm/train_trgb_segnet_conf.py:237-240,437-446,536-540.  out[0] = mean loss (overwritten). */
+int hn_adv_loss_fwd(const float* x, int64_t n, float target, int kind, float* out, void* stream);
+/* dx = (*gout / n) * dloss/dx */
+int hn_adv_loss_bwd(const float* x, int64_t n, float target, int kind, const float* gout, float* dx, void* stream);
+
+/* argmax over C + confusion-matrix histogram: conf[label*K + pred] += 1 (int64, caller-zeroed), labels
+ * outside [0,K) skipped.  scripts/iou_eval.py:19-98, cm/utils.py:134-163. */
+int hn_argmax_confusion(const float* logits, int ld, const int64_t* labels, int64_t npix, int C, int K,
+                        int64_t* conf, uint8_t* pred_out, void* stream);
+
+/* ---- optimizers: torch.optim.RMSprop / Adam as configured by cm/train_trgb_segnet_conf.py:270 and
+ *      scripts/main.py:159 (elementwise over a flat parameter range) ------------------------------------ */
+int hn_rmsprop_step(float* param, const float* grad, float* square_avg, int64_t n,
+                    float lr, float alpha, float eps, float weight_decay, void* stream);
+int hn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEATNET_HIP_H */

@@ -1,0 +1,117 @@
+"""CPU: host logic, the C-ABI library's exports, state_dict compatibility, refusal of CPU tensors."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from heatnet_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "heatnet_hip.h")).read()
+    declared = set(re.findall(r"\b(hn_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared - {"hn_strerror", "hn_version"} == set(_lib.SIGNATURES)
+    assert lib.hn_strerror(-4) == b"inconsistent shapes"
+    assert ctypes.sizeof(_lib.HnConvDesc) == 14 * 4
+
+
+def test_cpu_tensors_are_refused():
+    from heatnet_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.conv2d(torch.zeros(1, 64, 4, 4), torch.zeros(64, 64, 1, 1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.cross_entropy(torch.zeros(1, 13, 4, 4), torch.zeros(1, 4, 4, dtype=torch.long))
+
+
+def test_state_dict_layout_matches_oracle_and_reference():
+    from heatnet_amd.pspnet import PSPNet
+    from heatnet_amd import conf_segnet
+    from oracle import heatnet_ref as R
+    for late in (True, False):
+        mine = PSPNet(backend="resnet50", pretrained=False, late_fusion=late, in_channels=4)
+        ref = R.RefPSPNet(backend="resnet50", late_fusion=late, in_channels=4)
+        a, b = mine.state_dict(), ref.state_dict()
+        assert list(a) == list(b)
+        assert all(a[k].shape == b[k].shape for k in a)
+    assert len(PSPNet(backend="resnet50", pretrained=False, late_fusion=True, in_channels=4).state_dict()) == 488
+    m = conf_segnet.conv_segnet(pretrained=False, disc_arch="cyclegan", num_critics=6, arch="pspnet", late_fusion=True)
+    r = R.RefConfSegnet()
+    assert list(m.state_dict()) == list(r.state_dict())
+    assert sum(p.numel() for p in m.parameters()) == 75794006
+    # conv weights are physically OHWI
+    w = mine.feats.layer1[0].conv2.weight
+    assert w.shape == (64, 64, 3, 3) and w.is_contiguous(memory_format=torch.channels_last)
+    # checkpoint interchange keeps logical values
+    sd = {k: v.clone() for k, v in r.state_dict().items()}
+    m.load_state_dict(sd)
+    assert torch.equal(m.state_dict()["critics.0.conv1.weight"], sd["critics.0.conv1.weight"])
+    assert m.critics[0].conv1.weight.is_contiguous(memory_format=torch.channels_last)
+
+
+def test_caller_side_initialisers_hit_our_modules():
+    """scripts/main.py:init_weights keys on isinstance(nn.Conv2d); cm/utils.py:weights_init_normal on class names."""
+    from heatnet_amd.pspnet import PSPNet
+    from heatnet_amd.conf_segnet import weights_init_normal
+    net = PSPNet(backend="resnet50", pretrained=False, late_fusion=True, in_channels=4)
+    convs = [m for m in net.modules() if isinstance(m, torch.nn.Conv2d)]
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    # 23 bottlenecks x 3 + 2 stems + 5 projections + 4 pyramid + bottleneck + 3 decoder + final
+    assert len(convs) == 85 and len(bns) == 79
+    for m in net.modules():
+        name = m.__class__.__name__
+        if "Conv" in name or "BatchNorm2d" in name:
+            assert hasattr(m, "weight")
+    net.apply(weights_init_normal)
+    assert abs(float(net.feats.conv1.weight.std()) - 0.02) < 0.005
+    for m in convs:
+        torch.nn.init.xavier_normal_(m.weight, 1.0)
+
+
+def test_phase_switch_and_drop_in_module_paths():
+    import models.build_net as top
+    import models.confusion_maximization.models.build_net as cm
+    from models.confusion_maximization.models.conf_segnet import conv_segnet
+    from models.confusion_maximization.utils import calculate_ious
+    from oracle import heatnet_ref as R
+    assert set(top.models) >= {"resnet18", "resnet34", "resnet50", "resnet101", "resnet152"}
+    assert callable(top.build_network) and callable(cm.build_network)
+    m = conv_segnet(pretrained=False, disc_arch="cyclegan", num_critics=6, arch="pspnet", late_fusion=True)
+    m.setPhase("train_critic")
+    assert not any(p.requires_grad for p in m.trgb_segnet.parameters())
+    assert all(p.requires_grad for p in m.critics.parameters())
+    m.setPhase("train_seg")
+    assert all(p.requires_grad for p in m.trgb_segnet.parameters())
+    assert not any(p.requires_grad for p in m.critics.parameters())
+    with pytest.raises(NotImplementedError):
+        conv_segnet(pretrained=False, arch="custom")
+    r = np.random.RandomState(0)
+    pred, tgt = r.randint(0, 13, (2, 30, 40)), r.randint(0, 14, (2, 30, 40))
+    np.testing.assert_array_equal(calculate_ious(torch.from_numpy(pred), torch.from_numpy(tgt)),
+                                  R.calculate_ious(pred, tgt))
+
+
+def test_miou_host_arithmetic_against_golden(golden_dir):
+    from heatnet_amd import miou
+    g = np.load(os.path.join(golden_dir, "miou_cases.npz"))
+    for case in range(3):
+        pred, tgt = g["c%d_pred" % case].astype(np.int64), g["c%d_tgt" % case].astype(np.int64)
+        conf = np.bincount((tgt * 14 + pred).reshape(-1), minlength=196).reshape(14, 14)
+        np.testing.assert_array_equal(miou.ious_from_confusion(conf), g["c%d_ious" % case])
+        iou, m = miou.iou_eval_value(conf, (12, 13))
+        np.testing.assert_array_equal(iou, g["c%d_cm_iou" % case])
+        assert m == float(g["c%d_cm_miou" % case])
+
+
+def test_config_file_is_the_reference_file():
+    import json
+    conf = json.load(open(os.path.join(ROOT, "experiments", "heatnet_conf.json")))
+    assert conf["optimizer"]["learning_rate"] == 1e-05 and conf["optimizer"]["batch_size"] == 30
+    assert conf["network"]["arch"] == "resnext50" and conf["optimizer"]["clip"] == 0

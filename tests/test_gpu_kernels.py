@@ -1,0 +1,332 @@
+"""GPU: every HIP kernel (through the C ABI / autograd wrappers) against the same op in stock torch CPU fp32.
+
+Tolerances are written per test; convolution sums up to K = 9216 products in a different order than the CPU,
+so its bound scales with sqrt(K) * eps_fp32 * |x||w|.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from heatnet_amd import ops
+    return ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(a, b, atol, rtol=0.0, what=""):
+    a = a.detach().cpu().float()
+    b = b.detach().cpu().float()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    bound = atol + rtol * b.abs()
+    bad = err > bound
+    assert not bad.any(), "%s: max err %.3e (bound %.3e) at %d/%d elements" % (
+        what, err.max().item(), bound.min().item(), int(bad.sum()), bad.numel())
+
+
+CONV_CASES = [
+    # n, cin, h, w, cout, k, stride, pad, dil, bias
+    (2, 64, 20, 24, 256, 1, 1, 0, 1, False),     # 1x1, vector path
+    (1, 256, 9, 13, 64, 1, 1, 0, 1, False),      # M tail (117 pixels)
+    (2, 64, 16, 20, 64, 3, 1, 1, 1, True),       # 3x3 + bias
+    (1, 128, 12, 20, 128, 3, 1, 2, 2, False),    # dilation 2
+    (1, 64, 17, 23, 96, 3, 1, 4, 4, False),      # dilation 4, odd sizes, Cout tail (96)
+    (2, 128, 16, 24, 128, 3, 2, 1, 1, False),    # stride 2
+    (2, 256, 16, 24, 512, 1, 2, 0, 1, False),    # 1x1 stride 2 (downsample)
+    (2, 3, 32, 48, 64, 7, 2, 3, 1, False),       # RGB stem, scalar path
+    (2, 1, 32, 48, 64, 7, 2, 3, 1, False),       # IR stem
+    (2, 13, 32, 32, 64, 4, 2, 1, 1, True),       # critic conv1 on logits
+    (2, 64, 16, 16, 128, 4, 2, 1, 1, True),      # critic conv2
+    (2, 512, 4, 6, 1, 4, 2, 1, 1, True),         # critic classifier (Cout = 1)
+    (2, 64, 12, 16, 13, 1, 1, 0, 1, True),       # final 1x1 (Cout = 13)
+    (1, 2048, 6, 6, 2048, 1, 1, 0, 1, False),    # PSP stage conv on a 6x6 map
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv2d_forward_backward(dev, case):
+    ops = _ops()
+    n, cin, h, w, cout, k, stride, pad, dil, bias = case
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, k, k, seed=2, scale=1.0 / np.sqrt(cin * k * k))
+    b = rnd(cout, seed=3) if bias else None
+    xr, wr = x.clone().requires_grad_(), wt.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=pad, dilation=dil)
+    gy = rnd(*yr.shape, seed=4)
+    yr.backward(gy)
+
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    wd = wt.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    bd = b.to(dev).requires_grad_() if bias else None
+    y, stats = ops.conv2d(xd, wd, bd, stride, pad, dil, want_stats=True)
+    tol = 3e-6 * np.sqrt(cin * k * k) + 2e-6
+    close(y, yr, atol=tol * 4, what="y")
+    npix = yr.shape[0] * yr.shape[2] * yr.shape[3]
+    close(stats[:cout], yr.sum((0, 2, 3)), atol=tol * 4 * np.sqrt(npix) + 1e-4, rtol=1e-5, what="stats.sum")
+    close(stats[cout:], (yr * yr).sum((0, 2, 3)), atol=1e-4, rtol=1e-4, what="stats.sumsq")
+    y.backward(gy.to(dev))
+    ktot = cout * k * k
+    close(xd.grad, xr.grad, atol=3e-6 * np.sqrt(ktot) * 4 + 2e-6, what="dx")
+    close(wd.grad, wr.grad, atol=2e-5 * np.sqrt(npix) + 1e-5, rtol=1e-4, what="dw")
+    if bias:
+        close(bd.grad, br.grad, atol=1e-5 * np.sqrt(npix) + 1e-5, rtol=1e-5, what="db")
+
+
+def test_conv2d_fused_leaky_and_channel_slice_input(dev):
+    """LeakyReLU in the epilogue (critics) and an input that is a channel slice of a wider NHWC buffer (ld > C)."""
+    ops = _ops()
+    big = rnd(2, 96, 12, 16, seed=5)
+    wt = rnd(32, 64, 4, 4, seed=6, scale=0.03)
+    b = rnd(32, seed=7)
+    xr = big[:, 16:80].clone().requires_grad_()
+    wr, br = wt.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.leaky_relu(F.conv2d(xr, wr, br, stride=2, padding=1), 0.2)
+    gy = rnd(*yr.shape, seed=8)
+    yr.backward(gy)
+    bigd = big.to(dev).contiguous(memory_format=torch.channels_last)
+    xd = bigd[:, 16:80].detach().requires_grad_()
+    assert ops.nhwc_ld(xd) == 96
+    wd = wt.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    bd = b.to(dev).requires_grad_()
+    y = ops.conv2d(xd, wd, bd, 2, 1, 1, act=ops.ACT_LEAKY, slope=0.2)
+    close(y, yr, atol=2e-4, what="y")
+    y.backward(gy.to(dev))
+    close(xd.grad, xr.grad, atol=2e-4, what="dx")
+    close(wd.grad, wr.grad, atol=5e-4, rtol=1e-4, what="dw")
+    close(bd.grad, br.grad, atol=5e-4, rtol=1e-4, what="db")
+
+
+@pytest.mark.parametrize("act", ["none", "relu", "prelu"])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("residual", [False, True])
+def test_bn_act(dev, act, training, residual):
+    ops = _ops()
+    if residual and act == "prelu":
+        pytest.skip("the reference never adds a residual before PReLU")
+    n, c, h, w = 3, 64, 10, 14
+    y = rnd(n, c, h, w, seed=1, scale=2.0) + 0.5
+    gamma, beta = rnd(c, seed=2).abs() + 0.5, rnd(c, seed=3) * 0.1
+    rm, rv = rnd(c, seed=4) * 0.1, rnd(c, seed=5).abs() + 0.5
+    res = rnd(n, c, h, w, seed=6) if residual else None
+    slope = torch.tensor([0.25])
+
+    yr, gr, br = y.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    rr = res.clone().requires_grad_() if residual else None
+    sr = slope.clone().requires_grad_()
+    rm_r, rv_r = rm.clone(), rv.clone()
+    u = F.batch_norm(yr, rm_r, rv_r, gr, br, training=training, momentum=0.1, eps=1e-5)
+    if residual:
+        u = u + rr
+    zr = {"none": u, "relu": F.relu(u), "prelu": F.prelu(u, sr)}[act]
+    gz = rnd(n, c, h, w, seed=7)
+    zr.backward(gz)
+
+    cl = torch.channels_last
+    yd = y.to(dev).contiguous(memory_format=cl).requires_grad_()
+    gd, bd = gamma.to(dev).requires_grad_(), beta.to(dev).requires_grad_()
+    rd = res.to(dev).contiguous(memory_format=cl).requires_grad_() if residual else None
+    sd = slope.to(dev).requires_grad_()
+    rm_d, rv_d = rm.to(dev), rv.to(dev)
+    code = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "prelu": ops.ACT_PRELU}[act]
+    z = ops.bn_act(yd, None, gd, bd, rm_d, rv_d, residual=rd, prelu_weight=sd if act == "prelu" else None,
+                   training=training, act=code)
+    close(z, zr, atol=2e-5, rtol=1e-5, what="z")
+    close(rm_d, rm_r, atol=1e-6, rtol=1e-5, what="running_mean")
+    close(rv_d, rv_r, atol=1e-5, rtol=1e-5, what="running_var")
+    z.backward(gz.to(dev))
+    close(yd.grad, yr.grad, atol=3e-5, rtol=1e-4, what="dy")
+    close(gd.grad, gr.grad, atol=2e-3, rtol=1e-4, what="dgamma")
+    close(bd.grad, br.grad, atol=2e-3, rtol=1e-4, what="dbeta")
+    if residual:
+        close(rd.grad, rr.grad, atol=1e-6, what="dres")
+    if act == "prelu":
+        close(sd.grad, sr.grad, atol=2e-3, rtol=1e-4, what="dslope")
+
+
+def test_bn_stats_from_conv_epilogue_match_standalone(dev):
+    """conv_bn_act (statistics from the conv epilogue) == conv then BatchNorm on CPU, incl. narrow C with ld tails."""
+    from heatnet_amd.layers import HnBatchNorm2d, HnConv2d, conv_bn_act
+    ops = _ops()
+    conv = HnConv2d(64, 128, 3, padding=1, bias=False)
+    bn = HnBatchNorm2d(128)
+    ref_conv = torch.nn.Conv2d(64, 128, 3, padding=1, bias=False)
+    ref_bn = torch.nn.BatchNorm2d(128)
+    ref_conv.load_state_dict(conv.state_dict())
+    bn.weight.data = rnd(128, seed=1).abs() + 0.5
+    ref_bn.load_state_dict(bn.state_dict())
+    x = rnd(2, 64, 12, 20, seed=2)
+    zr = F.relu(ref_bn(ref_conv(x)))
+    conv, bn = conv.to(dev), bn.to(dev)
+    z = conv_bn_act(x.to(dev), conv, bn, ops.ACT_RELU)
+    close(z, zr, atol=5e-5, rtol=1e-4, what="z")
+    sd = bn.state_dict()
+    close(sd["running_var"], ref_bn.running_var, atol=1e-5, rtol=1e-4, what="running_var")
+    assert int(sd["num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 20, 28), (1, 64, 21, 27), (2, 3, 9, 11)])
+def test_maxpool(dev, shape):
+    ops = _ops()
+    x = rnd(*shape, seed=1)
+    xr = x.clone().requires_grad_()
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    g = rnd(*yr.shape, seed=2)
+    yr.backward(g)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    y = ops.maxpool3x3s2(xd)
+    close(y, yr, atol=0, what="y")
+    y.backward(g.to(dev))
+    close(xd.grad, xr.grad, atol=1e-6, what="dx")
+
+
+@pytest.mark.parametrize("size", [1, 2, 3, 6])
+@pytest.mark.parametrize("hw", [(40, 88), (8, 12), (5, 7)])
+def test_adaptive_avgpool(dev, size, hw):
+    ops = _ops()
+    x = rnd(2, 64, *hw, seed=1)
+    xr = x.clone().requires_grad_()
+    yr = F.adaptive_avg_pool2d(xr, (size, size))
+    g = rnd(*yr.shape, seed=2)
+    yr.backward(g)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    y = ops.adaptive_avg_pool(xd, size)
+    close(y, yr, atol=2e-6, rtol=1e-5, what="y")
+    y.backward(g.to(dev))
+    close(xd.grad, xr.grad, atol=1e-6, rtol=1e-5, what="dx")
+
+
+BILINEAR_CASES = [((2, 64, 10, 14), (20, 28)), ((1, 64, 1, 1), (40, 88)), ((2, 64, 2, 2), (40, 88)),
+                  ((2, 64, 3, 3), (40, 88)), ((2, 64, 6, 6), (40, 88)), ((2, 64, 6, 6), (8, 12)),
+                  ((2, 1, 2, 5), (64, 160)), ((2, 1, 1, 2), (32, 64)), ((1, 13, 7, 9), (14, 18))]
+
+
+@pytest.mark.parametrize("case", BILINEAR_CASES, ids=[str(c) for c in BILINEAR_CASES])
+def test_bilinear(dev, case):
+    ops = _ops()
+    shape, size = case
+    x = rnd(*shape, seed=1)
+    xr = x.clone().requires_grad_()
+    yr = F.interpolate(xr, size=size, mode="bilinear", align_corners=False)
+    g = rnd(*yr.shape, seed=2)
+    yr.backward(g)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    y = ops.bilinear(xd, size)
+    close(y, yr, atol=2e-6, rtol=1e-5, what="y")
+    y.backward(g.to(dev))
+    scale = (size[0] * size[1]) / (shape[2] * shape[3])
+    close(xd.grad, xr.grad, atol=2e-6 * max(1.0, scale), rtol=1e-4, what="dx")
+
+
+def test_upsample_scale_factor_32_matches_nn_upsample(dev):
+    ops = _ops()
+    x = rnd(2, 1, 10, 22, seed=3)
+    yr = torch.nn.Upsample(scale_factor=32, mode="bilinear")(x)
+    y = ops.bilinear(x.to(dev), (320, 704))
+    close(y, yr, atol=2e-6, what="x32")
+
+
+@pytest.mark.parametrize("ignore", [-100, 13])
+def test_cross_entropy(dev, ignore):
+    ops = _ops()
+    n, c, h, w = 2, 13, 24, 40
+    logits = rnd(n, c, h, w, seed=1, scale=3.0)
+    g = torch.Generator().manual_seed(2)
+    labels = torch.randint(0, 14 if ignore == 13 else 13, (n, h, w), generator=g)
+    lr = logits.clone().requires_grad_()
+    loss_r = F.cross_entropy(lr, labels, ignore_index=ignore)
+    (loss_r * 1.7).backward()
+    ld = logits.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    loss = ops.cross_entropy(ld, labels.to(dev), ignore)
+    assert abs(loss.item() - loss_r.item()) < 2e-6 * max(1.0, abs(loss_r.item())) * 4
+    (loss * 1.7).backward()
+    close(ld.grad, lr.grad, atol=1e-8, rtol=2e-5, what="dlogits")
+
+
+@pytest.mark.parametrize("kind", ["MSE", "BCE"])
+@pytest.mark.parametrize("target", [0.0, 1.0])
+def test_adv_loss(dev, kind, target):
+    ops = _ops()
+    x = rnd(2, 1, 64, 96, seed=1, scale=2.0)
+    xr = x.clone().requires_grad_()
+    crit = torch.nn.BCEWithLogitsLoss() if kind == "BCE" else torch.nn.MSELoss()
+    lr = crit(xr, torch.full_like(xr, target))
+    (lr * 0.3).backward()
+    xd = x.to(dev).requires_grad_()
+    l = ops.adv_loss(xd, target, kind)
+    assert abs(l.item() - lr.item()) < 1e-5 * max(1.0, abs(lr.item()))
+    (l * 0.3).backward()
+    close(xd.grad, xr.grad, atol=1e-9, rtol=2e-5, what="dx")
+
+
+def test_concat_dropout_mask_and_add(dev):
+    ops = _ops()
+    a, b = rnd(2, 64, 6, 10, seed=1), rnd(2, 32, 6, 10, seed=2)
+    ar, br = a.clone().requires_grad_(), b.clone().requires_grad_()
+    mask = (torch.rand(2, 96, generator=torch.Generator().manual_seed(3)) > 0.3).float() / 0.7
+    yr = torch.cat([ar, br], 1) * mask[:, :, None, None]
+    g = rnd(*yr.shape, seed=4)
+    yr.backward(g)
+    cl = torch.channels_last
+    ad = a.to(dev).contiguous(memory_format=cl).requires_grad_()
+    bd = b.to(dev).contiguous(memory_format=cl).requires_grad_()
+    y = ops.dropout2d(ops.concat([ad, bd]), 0.3, True, mask=mask.to(dev))
+    close(y, yr, atol=1e-7, what="y")
+    y.backward(g.to(dev))
+    close(ad.grad, ar.grad, atol=1e-7, what="da")
+    close(bd.grad, br.grad, atol=1e-7, what="db")
+
+
+def test_argmax_confusion_bit_exact(dev):
+    from heatnet_amd import miou
+    from oracle import heatnet_ref as R
+    logits = rnd(2, 13, 40, 56, seed=1)
+    labels = torch.randint(0, 14, (2, 40, 56), generator=torch.Generator().manual_seed(2))
+    ops = _ops()
+    pred, conf = ops.argmax_confusion(logits.to(dev), labels.to(dev), 14)
+    ref_pred = logits.argmax(1)
+    assert torch.equal(pred.cpu().long(), ref_pred)
+    ref_conf = np.bincount((ref_pred + 14 * labels).view(-1).numpy(), minlength=196).reshape(14, 14)
+    np.testing.assert_array_equal(conf.cpu().numpy(), ref_conf)
+    np.testing.assert_array_equal(miou.ious_from_confusion(conf.cpu().numpy()),
+                                  R.calculate_ious(ref_pred.numpy(), labels.numpy()))
+    iou, m = miou.iou_eval_value(conf.cpu().numpy(), (12, 13))
+    riou, rm = R.confusion_matrix_iou(ref_pred.numpy(), labels.numpy(), 14, (12, 13))
+    np.testing.assert_array_equal(iou, riou)
+    assert m == rm
+
+
+def test_optimizer_steps(dev):
+    ops = _ops()
+    p, g = rnd(10007, seed=1), rnd(10007, seed=2)
+    pr = p.clone().requires_grad_()
+    pr.grad = g.clone()
+    opt = torch.optim.RMSprop([pr], lr=1e-4)
+    pd, sq = p.to(dev), torch.zeros(10007, device=dev)
+    for _ in range(3):
+        opt.step()
+        ops.rmsprop_step_(pd, g.to(dev), sq, 1e-4)
+    close(pd, pr, atol=1e-7, rtol=1e-6, what="rmsprop")
+    pr2 = p.clone().requires_grad_()
+    pr2.grad = g.clone()
+    opt2 = torch.optim.Adam([pr2], lr=1e-3)
+    pd2, m, v = p.to(dev), torch.zeros(10007, device=dev), torch.zeros(10007, device=dev)
+    for step in range(1, 4):
+        opt2.step()
+        ops.adam_step_(pd2, g.to(dev), m, v, step, 1e-3)
+    close(pd2, pr2, atol=1e-6, rtol=1e-5, what="adam")

@@ -1,0 +1,168 @@
+"""GPU: the HIP-backed networks against the CPU oracle and the golden fixtures made from the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _seeded import seeded_inputs, seeded_state, set_dropout, tensor_digest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    return torch.device("cuda:0")
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def _build(late, state_seed, dev):
+    from heatnet_amd.pspnet import PSPNet
+    net = PSPNet(backend="resnet50", pretrained=False, late_fusion=late, in_channels=4)
+    net.load_state_dict(seeded_state(net, seed=state_seed))
+    set_dropout(net, 0.0)
+    return net.to(dev)
+
+
+@pytest.mark.parametrize("tag,late", [("late", True), ("early", False)])
+def test_segnet_forward_matches_reference_fixture(dev, golden_dir, tag, late):
+    """Train-mode and eval-mode logits + the five feature maps vs. fixtures produced by the reference (tol 1e-3)."""
+    g = _load(golden_dir, "segnet_%s_2x64x96" % tag)
+    net = _build(late, 1, dev)
+    rgb, ir, _ = seeded_inputs(2, 64, 96, seed=3)
+    net.train()
+    logits, feats, none = net(rgb.to(dev), ir.to(dev))
+    assert none is None and len(feats) == 6
+    err = np.abs(logits.detach().cpu().numpy() - g["train_logits"]).max()
+    assert err < 1e-3, err
+    for i, t in enumerate(feats[1:]):
+        assert tuple(g["train_feat%d_shape" % i]) == tuple(t.shape)
+        _, s = tensor_digest(t.contiguous(), 97)
+        np.testing.assert_allclose(s, g["train_feat%d_sample" % i], rtol=0, atol=1e-3)
+    sd = net.state_dict()
+    for k in ("feats.bn1.running_mean", "feats.bn1.running_var", "feats.layer4.2.bn3.running_mean",
+              "feats.layer4.2.bn3.running_var", "up_3.conv.1.running_var"):
+        np.testing.assert_allclose(sd[k].cpu().numpy(), g["after_" + k], rtol=1e-4, atol=1e-5)
+    assert int(sd["feats.bn1.num_batches_tracked"]) == int(g["after_nbt"])
+    net.load_state_dict(seeded_state(net, seed=1))
+    net.eval()
+    with torch.no_grad():
+        logits, feats, _ = net(rgb.to(dev), ir.to(dev))
+    err = np.abs(logits.cpu().numpy() - g["eval_logits"]).max()
+    assert err < 1e-3, err
+
+
+def test_segnet_backward_matches_oracle(dev):
+    """Every parameter gradient of forward + CE + backward vs. the CPU oracle on identical weights/inputs."""
+    from heatnet_amd import train_step
+    from oracle import heatnet_ref as R
+    rgb, ir, lab = seeded_inputs(2, 64, 96, seed=3)
+    ref = R.RefPSPNet(backend="resnet50", late_fusion=True, in_channels=4)
+    ref.load_state_dict(seeded_state(ref, seed=1))
+    set_dropout(ref, 0.0)
+    ref.train()
+    rl, _, _ = ref(rgb, ir)
+    rloss = torch.nn.functional.cross_entropy(rl, lab)
+    rloss.backward()
+    net = _build(True, 1, dev)
+    net.train()
+    logits, _, _ = net(rgb.to(dev), ir.to(dev))
+    loss = train_step.segmentation_loss(logits, lab.to(dev))
+    loss.backward()
+    assert abs(loss.item() - rloss.item()) < 1e-4
+    refg = dict(ref.named_parameters())
+    worst = ("", 0.0)
+    for k, p in net.named_parameters():
+        assert p.grad is not None, k
+        a, b = p.grad.detach().cpu().double(), refg[k].grad.double()
+        rel = float((a - b).norm() / (b.norm() + 1e-12))
+        if rel > worst[1]:
+            worst = (k, rel)
+    assert worst[1] < 2e-3, worst
+
+
+def test_fullres_minibatch_logits_and_miou(dev, golden_dir):
+    """BASELINE criterion: logits within 1e-3 and |d mIoU| < 1e-3 on the fixed 2x320x704 mini-batch."""
+    from heatnet_amd import miou, train_step
+    from oracle import heatnet_ref as R
+    g = _load(golden_dir, "segnet_late_2x320x704")
+    net = _build(True, 2, dev)
+    net.train()
+    rgb, ir, lab = seeded_inputs(2, 320, 704, seed=5)
+    with torch.no_grad():
+        logits, feats, _ = net(rgb.to(dev), ir.to(dev))
+    err = np.abs(logits[:, :, ::8, ::8].cpu().numpy() - g["logits_s8"]).max()
+    assert err < 1e-3, err
+    ce = train_step.segmentation_loss(logits, lab.to(dev)).item()
+    assert abs(ce - float(g["ce"])) < 1e-4
+    conf = miou.confusion_matrix(logits, lab.to(dev), 14)
+    mine = np.nanmean(miou.ious_from_confusion(conf))
+    ref = np.nanmean(R.calculate_ious(g["argmax"].astype(np.int64), lab.numpy()))
+    assert abs(mine - ref) < 1e-3, (mine, ref)
+    pred, _ = __import__("heatnet_amd.ops", fromlist=["x"]).argmax_confusion(logits, None, 14)
+    assert (pred.cpu().numpy() != g["argmax"]).mean() < 1e-3
+
+
+def test_rgb18_config1(dev, golden_dir):
+    """BASELINE config 1 on the GPU path: top-level PSPNet/ResNet-18 forward + CE(ignore_index=13) + backward."""
+    from heatnet_amd.pspnet import PSPNet
+    from heatnet_amd import train_step
+    g = _load(golden_dir, "rgb18_1x320x704")
+    net = PSPNet(n_classes=18, psp_size=512, deep_features_size=256, backend="resnet18", pretrained=False, rgb_only=True)
+    assert sum(p.numel() for p in net.parameters()) == int(g["n_params"])
+    net.load_state_dict(seeded_state(net, seed=4))
+    set_dropout(net, 0.0)
+    net = net.to(dev).train()
+    rgb, _, lab = seeded_inputs(1, 320, 704, seed=9, n_classes=14)
+    logits = net(rgb.to(dev))
+    loss = train_step.segmentation_loss(logits, lab.to(dev), ignore_index=13)
+    loss.backward()
+    err = np.abs(logits[:, :, ::8, ::8].detach().cpu().numpy() - g["logits_s8"]).max()
+    assert err < 1e-3, err
+    assert abs(loss.item() - float(g["ce"])) < 1e-4
+    np.testing.assert_allclose(net.final[0].weight.grad.cpu().numpy(), g["grad_final_w"], rtol=2e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("adv", ["MSE", "BCE"])
+def test_confusion_maximisation_steps(dev, golden_dir, adv):
+    """conv_segnet forward, one train_critic and one train_seg iteration (RMSprop) vs. the reference fixture."""
+    from heatnet_amd import conf_segnet, train_step
+    g = _load(golden_dir, "confstep_%s_2x256x256" % adv.lower())
+    model = conf_segnet.conv_segnet(pretrained=False, disc_arch="cyclegan", num_critics=6, arch="pspnet",
+                                    late_fusion=True)
+    state = seeded_state(model, seed=7)
+    model.load_state_dict(state)
+    set_dropout(model, 0.0)
+    model = model.to(dev).train()
+    opt = torch.optim.RMSprop(model.parameters(), lr=1e-4)
+    rgb_d, ir_d, lab = [t.to(dev) for t in seeded_inputs(2, 256, 256, seed=11)]
+    rgb_n, ir_n, _ = [t.to(dev) for t in seeded_inputs(2, 256, 256, seed=12)]
+    for step, state_name in enumerate(("train_critic", "train_seg")):
+        model.setPhase(state_name)
+        if step == 0:
+            with torch.no_grad():
+                o = model([rgb_d, ir_d], [rgb_n, ir_n])
+            assert np.abs(o["pred_label_a"][:, :, ::4, ::4].cpu().numpy() - g["fwd_logits_a_s4"]).max() < 1e-3
+            for i in range(6):
+                a = o["critics_a"][i][:, :, ::8, ::8].cpu().numpy()
+                b = o["critics_b"][i][:, :, ::8, ::8].cpu().numpy()
+                np.testing.assert_allclose(a, g["fwd_critic_a%d" % i], atol=1e-3, rtol=1e-3)
+                np.testing.assert_allclose(b, g["fwd_critic_b%d" % i], atol=1e-3, rtol=1e-3)
+            model.load_state_dict(state)
+        losses = train_step.train_step(model, opt, [rgb_d, ir_d], [rgb_n, ir_n], lab, state_name, adv=adv)
+        total = float(g["s%d_total" % step])
+        assert abs(losses["total"].item() - total) < 1e-3 * max(1.0, abs(total)), (losses["total"].item(), total)
+        if state_name == "train_seg":
+            assert abs(losses["seg"].item() - float(g["s1_seg"])) < 1e-3
+            assert abs(losses["conf"].item() - float(g["s1_conf"])) < 1e-3 * max(1.0, abs(float(g["s1_conf"])))
+        names = [str(n) for n in g["s%d_grad_names" % step]]
+        norms = dict(zip(names, g["s%d_grad_norms" % step]))
+        got = {k: float(p.grad.double().norm()) for k, p in model.named_parameters() if p.grad is not None}
+        assert sorted(got) == sorted(names)
+        worst = max(abs(got[k] - norms[k]) / (norms[k] + 1e-9) for k in names)
+        assert worst < 5e-3, worst
