@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/s of the HeatNet hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload seg|confmax_seg|confmax_critic]
+
+A step = one pass of the hot path over one synthetic batch resident in HBM:
+  seg (default, BASELINE.json configs[1]): dual-stream RGB+thermal PSPNet (ResNet-50, late fusion), bs=8/GPU,
+      320x704, forward + per-pixel CE + backward + RMSprop update.
+  confmax_seg / confmax_critic (configs[2]): one train_seg / train_critic iteration of the confusion-maximisation
+      trainer (day + night passes, six critics); an "image" is then one day+night pair.
+N>1 is launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: one process per GPU,
+full replica each, gradients all-reduced by RCCL in flat buckets overlapped with backward (weak scaling).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernels -- the fp32-MFMA implicit-GEMM convolutions --
+as algorithmic conv FLOPs (2*M*N*K of every conv forward / data-gradient / weight-gradient launch) over the
+HIP-event time of exactly those launches, measured in an instrumented pass after the timed region.
+`cpu_baseline` times the CPU oracle (oracle/heatnet_ref.py, a port) on this host, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+H, W, BS = 320, 704, 8
+
+
+def synthetic_batch(rank, dev, n=BS, h=H, w=W):
+    g = torch.Generator().manual_seed(1234 + rank)
+    mk = lambda c: torch.randn(n, c, h, w, generator=g).clamp_(-1, 1)
+    batch = {"rgb_day": mk(3), "ir_day": torch.rand(n, 1, h, w, generator=g) * 2 - 1,
+             "rgb_night": mk(3), "ir_night": torch.rand(n, 1, h, w, generator=g) * 2 - 1,
+             "label_day": torch.randint(0, 13, (n, h, w), generator=g)}
+    return {k: v.to(dev) for k, v in batch.items()}
+
+
+def build(workload, dev):
+    from heatnet_amd import conf_segnet
+    from heatnet_amd.conf_segnet import weights_init_normal
+    from heatnet_amd.pspnet import PSPNet
+    torch.manual_seed(0)
+    if workload == "seg":
+        model = PSPNet(backend="resnet50", pretrained=False, late_fusion=True, in_channels=4)
+        model.apply(weights_init_normal)
+    else:
+        model = conf_segnet.conv_segnet(pretrained=False, disc_arch="cyclegan", num_critics=6, arch="pspnet",
+                                        late_fusion=True)
+        model.setPhase("train_seg" if workload == "confmax_seg" else "train_critic")
+    return model.to(dev).train()
+
+
+def make_step(workload, model, opt, batch, buckets):
+    from heatnet_amd import train_step
+    if workload == "seg":
+        return lambda: train_step.segmentation_step(model, opt, batch["rgb_day"], batch["ir_day"], batch["label_day"],
+                                                    grad_sync=buckets)
+    state = "train_seg" if workload == "confmax_seg" else "train_critic"
+    return lambda: train_step.train_step(model, opt, [batch["rgb_day"], batch["ir_day"]],
+                                         [batch["rgb_night"], batch["ir_night"]], batch["label_day"], state,
+                                         adv="MSE", grad_sync=buckets)
+
+
+def measure_conv_roofline(step_fn, steps):
+    """Instrumented pass: HIP events (torch's current stream = the launch stream) around every conv-kernel launch."""
+    from heatnet_amd import ops
+    records = []
+    ops.set_conv_profiler(records)
+    try:
+        for _ in range(steps):
+            step_fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_profiler(None)
+    per_kind = {}
+    flops = ms = 0.0
+    for kind, fl, e0, e1 in records:
+        t = e0.elapsed_time(e1)
+        k = per_kind.setdefault(kind, [0, 0.0, 0.0])
+        k[0] += 1
+        k[1] += fl
+        k[2] += t
+        flops += fl
+        ms += t
+    launches = len(records)
+    detail = {k: {"launches_per_step": v[0] // steps, "tflop_per_step": v[1] / steps / 1e12,
+                  "ms_per_step": v[2] / steps, "avg_launch_us": 1e3 * v[2] / v[0], "tflops": v[1] / v[2] / 1e9}
+              for k, v in per_kind.items()}
+    achieved = flops / ms / 1e9 if ms > 0 else 0.0
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "conv_igemm_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32)",
+            "launches_per_step": launches // steps, "conv_tflop_per_step": round(flops / steps / 1e12, 3),
+            "conv_ms_per_step": round(ms / steps, 3), "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
+            "by_kind": detail}
+
+
+def cpu_baseline(workload):
+    """The oracle on this host's cores: bs=1, 320x704, 1 warm-up + 2 timed steps (about 15-30 s of CPU work)."""
+    from oracle import heatnet_ref as R
+    cores = torch.get_num_threads()
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(99)
+    rgb, ir = torch.randn(1, 3, H, W, generator=g).clamp_(-1, 1), torch.rand(1, 1, H, W, generator=g) * 2 - 1
+    lab = torch.randint(0, 13, (1, H, W), generator=g)
+    if workload == "seg":
+        model = R.RefPSPNet(backend="resnet50", late_fusion=True, in_channels=4).train()
+        opt = torch.optim.RMSprop(model.parameters(), lr=1e-4)
+
+        def step():
+            opt.zero_grad()
+            loss = torch.nn.functional.cross_entropy(model(rgb, ir)[0], lab)
+            loss.backward()
+            opt.step()
+    else:
+        model = R.RefConfSegnet().train()
+        state = "train_seg" if workload == "confmax_seg" else "train_critic"
+        model.setPhase(state)
+        opt = torch.optim.RMSprop(model.parameters(), lr=1e-4)
+        rgb2, ir2 = torch.randn(1, 3, H, W, generator=g).clamp_(-1, 1), torch.rand(1, 1, H, W, generator=g) * 2 - 1
+        step = lambda: R.train_step(model, opt, [rgb, ir], [rgb2, ir2], lab, state)
+    step()
+    t0 = time.time()
+    n = 2
+    for _ in range(n):
+        step()
+    dt = (time.time() - t0) / n
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "oracle/heatnet_ref.py, %s step at bs=1 320x704 fp32, 1 warm-up + %d timed steps, %.1f s/step"
+                      % (workload, n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="seg", choices=["seg", "confmax_seg", "confmax_critic"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from heatnet_amd import ddp
+    model = build(args.workload, dev)
+    buckets = None
+    if world > 1:
+        ddp.broadcast_module_state(model)
+        buckets = ddp.GradBuckets([p for p in model.parameters() if p.requires_grad])
+    opt = torch.optim.RMSprop([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+    batch = synthetic_batch(rank, dev)
+    step = make_step(args.workload, model, opt, batch, buckets)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        roof = measure_conv_roofline(step, max(1, min(3, args.steps)))
+    if world > 1:
+        dist.barrier()
+    base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base = cpu_baseline(args.workload)
+
+    if rank == 0:
+        names = {"seg": "configs[1]: HeatNet RGB+thermal dual-stream PSPNet (ResNet-50, late fusion), forward + CE + "
+                        "backward + RMSprop",
+                 "confmax_seg": "configs[2]: confusion-maximisation train_seg iteration (day+night passes, 6 critics)",
+                 "confmax_critic": "configs[2]: confusion-maximisation train_critic iteration (day+night passes, 6 critics)"}
+        out = {"metric": "training images/s at 320x704 RGB+IR, bs=8/GPU", "value": round(world * BS * args.steps / elapsed, 3),
+               "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": names[args.workload], "global_batch": world * BS, "height": H, "width": W,
+                          "parallelism": "dp%d" % world, "optimizer": "RMSprop lr=1e-4", "weights": "random init"},
+               "roofline": roof, "cpu_baseline": base}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

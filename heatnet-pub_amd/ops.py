@@ -94,6 +94,34 @@ def _desc(n, h, w, cin, ldx, ho, wo, cout, ldy, kh, kw, stride, pad, dil):
     return HnConvDesc(n, h, w, cin, ldx, ho, wo, cout, ldy, kh, kw, stride, pad, dil)
 
 
+_conv_prof = None  # bench.py: list receiving (kind, algorithmic flops, start event, end event) per conv launch
+
+
+def set_conv_profiler(records):
+    global _conv_prof
+    _conv_prof = records
+
+
+class _ConvTimer:
+    """HIP events on the launch stream (torch's current stream) around one conv-kernel launch."""
+
+    def __init__(self, kind, d):
+        self.on = _conv_prof is not None
+        if self.on:
+            self.kind = kind
+            self.flops = 2.0 * d.N * d.Hout * d.Wout * d.Cout * d.KH * d.KW * d.Cin
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            _conv_prof.append((self.kind, self.flops, self.e0, self.e1))
+
+
 # ------------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------------
@@ -114,8 +142,9 @@ class _Conv2d(torch.autograd.Function):
         y = new_nhwc(n, cout, ho, wo, x.device)
         stats = torch.zeros(2 * cout, device=x.device, dtype=torch.float32) if want_stats else None
         d = _desc(n, h, wd, cin, ldx, ho, wo, cout, cout, kh, kw, stride, pad, dil)
-        check(lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(stats), ctypes.byref(d), act, slope,
-                                _stream()), "hn_conv2d_fwd")
+        with _ConvTimer("fwd", d):
+            check(lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(stats), ctypes.byref(d), act, slope,
+                                    _stream()), "hn_conv2d_fwd")
         ctx.geom = (stride, pad, dil, act, slope)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
@@ -148,10 +177,12 @@ class _Conv2d(torch.autograd.Function):
             check(lib.hn_weight_flip_transpose(_ptr(w), _ptr(wt), cout, kh, kw, cin, s), "hn_weight_flip_transpose")
             dx = new_nhwc(n, cin, h, wd, x.device)
             dd = _desc(n, h, wd, cin, cin, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
-            check(lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(dx), ctypes.byref(dd), s), "hn_conv2d_dgrad")
+            with _ConvTimer("dgrad", dd):
+                check(lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(dx), ctypes.byref(dd), s), "hn_conv2d_dgrad")
         if ctx.needs_input_grad[1]:
             dw = torch.empty((cout, kh, kw, cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
-            check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), 0, s), "hn_conv2d_wgrad")
+            with _ConvTimer("wgrad", d):
+                check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), 0, s), "hn_conv2d_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(cout, device=x.device, dtype=torch.float32)
             check(lib.hn_channel_sum(_ptr(dy), lddy, npix, cout, _ptr(db), s), "hn_channel_sum")

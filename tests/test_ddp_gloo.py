@@ -1,0 +1,115 @@
+"""CPU, world_size 2 over gloo: the gradient-bucket all-reduce that bench.py / the trainer use over RCCL.
+
+The collective layer is independent of the kernels, so it is exercised here with a small stock-torch model:
+bucket views, arrival-counted launches during backward, averaging, unused parameters, phase-specific buckets.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.body = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 4, 1), nn.Flatten(),
+                                  nn.Linear(4 * 6 * 6, 5))
+        self.body[0].weight.data = self.body[0].weight.data.contiguous(memory_format=torch.channels_last)
+        self.unused = nn.Linear(3, 3)  # never touched by forward: its bucket must still be reduced (zeros)
+
+    def forward(self, x):
+        return self.body(x)
+
+
+def _model():
+    torch.manual_seed(0)
+    return _Net()
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from heatnet_amd import ddp
+    m = _model()
+    if rank == 1:  # perturb, then check the broadcast restores rank 0's values
+        for p in m.parameters():
+            p.data.add_(1.0)
+    ddp.broadcast_module_state(m)
+    ref = _model()
+    same = all(torch.equal(a, b) for a, b in zip(m.parameters(), ref.parameters()))
+
+    buckets = ddp.GradBuckets(list(m.parameters()), bucket_bytes=256)  # several small buckets
+    assert len(buckets.buckets) >= 2
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(100 + rank)
+    errs = []
+    for it in range(2):
+        x = torch.randn(4, 3, 6, 6, generator=g)
+        y = torch.randn(4, 5, generator=g)
+        # expected: mean over ranks of the local gradients
+        ref.load_state_dict(m.state_dict())
+        ref.zero_grad()
+        ((ref(x) - y) ** 2).mean().backward()
+        expected = []
+        for p in ref.parameters():
+            gl = p.grad.clone() if p.grad is not None else torch.zeros_like(p)
+            dist.all_reduce(gl)
+            expected.append(gl / world)
+        opt.zero_grad(set_to_none=False)
+        buckets.begin_step()
+        ((m(x) - y) ** 2).mean().backward()
+        buckets.finish_step()
+        for p, e in zip(m.parameters(), expected):
+            errs.append(float((p.grad - e).abs().max()))
+        assert m.body[0].weight.grad.is_contiguous(memory_format=torch.channels_last)
+        opt.step()
+    # parameters stay identical across ranks after the synchronised steps
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    other = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    ret[rank] = (same, max(errs), float((other[0] - other[1]).abs().max()))
+    dist.destroy_process_group()
+
+
+def test_grad_buckets_two_ranks():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for rank in range(world):
+        same, err, drift = ret[rank]
+        assert same
+        assert err < 1e-6, err
+        assert drift == 0.0
+
+
+def test_grad_buckets_single_process_is_a_no_op():
+    sys.path.insert(0, ROOT)
+    from heatnet_amd import ddp
+    m = _model()
+    b = ddp.GradBuckets(list(m.parameters()))
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    opt.zero_grad(set_to_none=False)
+    b.begin_step()
+    m(torch.randn(2, 3, 6, 6)).sum().backward()
+    b.finish_step()
+    assert all(p.grad is not None for p in m.parameters())
+    with pytest.raises(RuntimeError, match="left its bucket"):
+        opt.zero_grad(set_to_none=True)
+        b.begin_step()
