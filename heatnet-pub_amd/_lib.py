@@ -32,7 +32,7 @@ SIGNATURES = {
     "hn_bn_finalize": [P, c_i64, P, P, P, P, c_float, c_float, P, P, P, P, c_int, P],
     "hn_bn_eval_params": [P, P, P, P, c_float, P, P, P, P, c_int, P],
     "hn_bn_act_fwd": [P, c_int, P, P, P, c_int, P, c_int, c_i64, c_int, c_int, P, c_float, P],
-    "hn_bn_act_bwd_reduce": [P, c_int, P, c_int, P, c_int, P, P, P, P, c_i64, c_int, c_int, P, c_float, P, P],
+    "hn_bn_act_bwd_reduce": [P, c_int, P, c_int, P, c_int, P, P, P, P, c_i64, c_int, c_int, P, c_float, P, P, P],
     "hn_bn_act_bwd_apply": [P, c_int, P, c_int, P, c_int, P, P, P, P, P, P, c_i64, c_int, P, c_int, P, c_int,
                             c_i64, c_int, c_int, P, c_float, P],
     "hn_act_bwd": [P, c_int, P, c_int, P, c_int, c_i64, c_int, c_int, c_float, P],
@@ -66,6 +66,10 @@ def load():
         raise RuntimeError(
             "heatnet_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C heatnet-pub_amd/csrc`). There is no CPU/PyTorch fallback for the hot path." % LIB_PATH)
+    # PyTorch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Import torch FIRST so that this library
+    # binds to the HIP runtime torch's streams and allocations belong to; loaded the other way round the process ends
+    # up with the system runtime under torch and kernel launches on torch's streams fail.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -27,7 +27,7 @@ struct ConvArgs {
     const float* w;
     const float* bias;
     float* y;
-    float* stats;
+    double* stats;
     int H, W, C, ldx;        // input tensor
     int Ho, Wo, K, ldy;      // output tensor (K = output channels)
     int KH, KW, stride, pad, dil, in_dil;
@@ -220,11 +220,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
             }
         }
         if (p.stats != nullptr) {
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
+            // <= 64 rows per lane were summed in fp32; everything across tiles is accumulated in double
+            // (global_atomic_add_f64), like the double accumulators of the CPU reference's BatchNorm.
+            double d1 = (double)s1, d2 = (double)s2;
+            d1 += __shfl_xor(d1, 32);
+            d2 += __shfl_xor(d2, 32);
             if (lh == 0 && cok) {
-                atomicAdd(p.stats + col, s1);
-                atomicAdd(p.stats + p.K + col, s2);
+                unsafeAtomicAdd(p.stats + col, d1);
+                unsafeAtomicAdd(p.stats + p.K + col, d2);
             }
         }
     }
@@ -244,7 +247,7 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     ConvArgs p = a;
     p.ntm = (a.M + BM - 1) / BM;
     p.ntn = (a.K + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, VEC>), dim3(p.ntm * p.ntn), dim3(256), lds, stream, p);
+    HN_LAUNCH((conv_igemm_kernel<TM, TN, VEC>), dim3(p.ntm * p.ntn), dim3(256), lds, stream, p);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_kernel(const float*
 
 }  // namespace
 
-extern "C" int hn_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, float* stats,
+extern "C" int hn_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, double* stats,
                              const HnConvDesc* d, int act, float slope, void* stream) {
     if (x == nullptr || w == nullptr || y == nullptr) return HN_EINVAL;
     if (act < HN_ACT_NONE || act > HN_ACT_LEAKY) return HN_EINVAL;
@@ -337,7 +340,7 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, cons
 extern "C" int hn_weight_flip_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream) {
     if (w == nullptr || wt == nullptr || Cout <= 0 || KH <= 0 || KW <= 0 || Cin <= 0) return HN_EINVAL;
     const dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, KH * KW);
-    hipLaunchKernelGGL(weight_flip_transpose_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, wt, Cout,
+    HN_LAUNCH(weight_flip_transpose_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, wt, Cout,
                        KH * KW, Cin);
     HN_CHECK_LAUNCH();
     return HN_OK;

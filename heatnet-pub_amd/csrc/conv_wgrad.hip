@@ -217,7 +217,7 @@ int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     if (a.atomic) {
         if (hipMemsetAsync(a.dw, 0, (size_t)a.K * a.Kdim * sizeof(float), stream) != hipSuccess) return HN_ELAUNCH;
     }
-    hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, VEC>), dim3(tiles * split_k), dim3(256), lds, stream, a);
+    HN_LAUNCH((conv_wgrad_kernel<TM, TN, VEC>), dim3(tiles * split_k), dim3(256), lds, stream, a);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

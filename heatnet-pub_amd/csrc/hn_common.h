@@ -8,6 +8,10 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// hipGetLastError() is per-thread state shared with every other HIP user of the process (PyTorch leaves benign
+// codes such as hipErrorNotReady behind), so it is cleared right before each launch and read right after it.
+#define HN_LAUNCH(...) \
+    do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 #define HN_CHECK_LAUNCH() \
     do { if (hipGetLastError() != hipSuccess) return HN_ELAUNCH; } while (0)
 

@@ -167,7 +167,7 @@ extern "C" int hn_ce_fwd(const float* logits, int ld, const int64_t* labels, int
     if (!logits || !labels || !out || npix <= 0 || C <= 0 || C > MAXC || ld < C) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(out, 0, 2 * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, ignore_index, out);
+    HN_LAUNCH(ce_fwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, ignore_index, out);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -177,7 +177,7 @@ extern "C" int hn_ce_bwd(const float* logits, int ld, const int64_t* labels, int
     if (!logits || !labels || !out || !gout || !dlogits || npix <= 0 || C <= 0 || C > MAXC || ld < C || lddl < C)
         return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, ignore_index, out,
+    HN_LAUNCH(ce_bwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, ignore_index, out,
                        gout, dlogits, lddl);
     HN_CHECK_LAUNCH();
     return HN_OK;
@@ -189,7 +189,7 @@ extern "C" int hn_adv_loss_fwd(const float* x, int64_t n, float target, int kind
     if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
     int grid = flat_grid(n);
     if (grid > 512) grid = 512;
-    hipLaunchKernelGGL(adv_fwd_kernel, dim3(grid), dim3(256), 0, s, x, n, target, kind, (float)(1.0 / (double)n), out);
+    HN_LAUNCH(adv_fwd_kernel, dim3(grid), dim3(256), 0, s, x, n, target, kind, (float)(1.0 / (double)n), out);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -198,7 +198,7 @@ extern "C" int hn_adv_loss_bwd(const float* x, int64_t n, float target, int kind
                                void* stream) {
     if (!x || !gout || !dx || n <= 0 || (kind != HN_LOSS_MSE && kind != HN_LOSS_BCE)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(adv_bwd_kernel, dim3(flat_grid(n)), dim3(256), 0, s, x, n, target, kind, (float)(1.0 / (double)n),
+    HN_LAUNCH(adv_bwd_kernel, dim3(flat_grid(n)), dim3(256), 0, s, x, n, target, kind, (float)(1.0 / (double)n),
                        gout, dx);
     HN_CHECK_LAUNCH();
     return HN_OK;
@@ -211,7 +211,7 @@ extern "C" int hn_argmax_confusion(const float* logits, int ld, const int64_t* l
     hipStream_t s = static_cast<hipStream_t>(stream);
     int grid = flat_grid(npix);
     if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(argmax_conf_kernel, dim3(grid), dim3(256), (size_t)K * K * sizeof(unsigned int), s, logits, ld, labels,
+    HN_LAUNCH(argmax_conf_kernel, dim3(grid), dim3(256), (size_t)K * K * sizeof(unsigned int), s, logits, ld, labels,
                        npix, C, K, reinterpret_cast<unsigned long long*>(conf), pred_out);
     HN_CHECK_LAUNCH();
     return HN_OK;
@@ -221,7 +221,7 @@ extern "C" int hn_rmsprop_step(float* param, const float* grad, float* square_av
                                float eps, float weight_decay, void* stream) {
     if (!param || !grad || !square_avg || n <= 0) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(rmsprop_kernel, dim3(flat_grid(n)), dim3(256), 0, s, param, grad, square_avg, n, lr, alpha, eps,
+    HN_LAUNCH(rmsprop_kernel, dim3(flat_grid(n)), dim3(256), 0, s, param, grad, square_avg, n, lr, alpha, eps,
                        weight_decay);
     HN_CHECK_LAUNCH();
     return HN_OK;
@@ -232,7 +232,7 @@ extern "C" int hn_adam_step(float* param, const float* grad, float* exp_avg, flo
     if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n,
+    HN_LAUNCH(adam_kernel, dim3(flat_grid(n)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n,
                        (float)((double)lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)));
     HN_CHECK_LAUNCH();
     return HN_OK;

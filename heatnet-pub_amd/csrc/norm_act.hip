@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     }
 }
 
-// sums[0:C] += sum du ; sums[C:2C] += sum du*xhat ; sums[2C] += dslope
+// sums[0:C] += sum du ; sums[C:2C] += sum du*xhat ; sums[2C] += dslope   (double accumulation throughout)
 template <int V>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ dz, int lddz,
                                                                const float* __restrict__ z, int ldz,
@@ -108,14 +108,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                int64_t npix, int C, int act, const float* slope_p, float leaky,
-                                                               float* __restrict__ sums) {
-    __shared__ float red[2 * 256 * 4 + 256];
+                                                               double* __restrict__ sums) {
+    __shared__ double red[2 * 256 * 4 + 256];
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     const bool live = c < C;
-    float sc[V], sh[V], mu[V], is[V], s1[V], s2[V];
-    float dslope = 0.f;
+    float sc[V], sh[V], mu[V], is[V];
+    double s1[V], s2[V];
+    double dslope = 0.0;
 #pragma unroll
-    for (int i = 0; i < V; ++i) { sc[i] = sh[i] = mu[i] = is[i] = s1[i] = s2[i] = 0.f; }
+    for (int i = 0; i < V; ++i) { sc[i] = sh[i] = mu[i] = is[i] = 0.f; s1[i] = s2[i] = 0.0; }
     if (live) {
         ldv<V>(scale + c, sc);
         ldv<V>(shift + c, sh);
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
         for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix;
              pix += (int64_t)gridDim.y * blockDim.y) {
             float g[V], zz[V], yy[V], du[V];
+            float ds = 0.f;
             ldv<V>(dz + pix * lddz + c, g);
             ldv<V>(y + pix * ldy + c, yy);
             if (act == HN_ACT_RELU) ldv<V>(z + pix * ldz + c, zz);
@@ -134,19 +136,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
 #pragma unroll
                 for (int i = 0; i < V; ++i) zz[i] = 0.f;
             }
-            act_grad<V>(g, zz, yy, sc, sh, act, slope, du, dslope);
+            act_grad<V>(g, zz, yy, sc, sh, act, slope, du, ds);
+            dslope += (double)ds;
 #pragma unroll
             for (int i = 0; i < V; ++i) {
-                s1[i] += du[i];
-                s2[i] += du[i] * (yy[i] - mu[i]) * is[i];
+                s1[i] += (double)du[i];
+                s2[i] += (double)(du[i] * ((yy[i] - mu[i]) * is[i]));
             }
         }
     }
     // reduce over threadIdx.y
     const int bx = blockDim.x, by = blockDim.y, tx = threadIdx.x, ty = threadIdx.y;
-    float* r1 = red;
-    float* r2 = red + 256 * 4;
-    float* r3 = red + 2 * 256 * 4;
+    double* r1 = red;
+    double* r2 = red + 256 * 4;
+    double* r3 = red + 2 * 256 * 4;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         r1[(ty * bx + tx) * V + i] = s1[i];
@@ -157,22 +160,27 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
     if (ty == 0 && live) {
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            float a = 0.f, b = 0.f;
+            double a = 0.0, b = 0.0;
             for (int k = 0; k < by; ++k) {
                 a += r1[(k * bx + tx) * V + i];
                 b += r2[(k * bx + tx) * V + i];
             }
-            atomicAdd(sums + c + i, a);
-            atomicAdd(sums + C + c + i, b);
+            unsafeAtomicAdd(sums + c + i, a);
+            unsafeAtomicAdd(sums + C + c + i, b);
         }
     }
     if (act == HN_ACT_PRELU) {
         if (ty == 0 && tx == 0) {
-            float a = 0.f;
+            double a = 0.0;
             for (int k = 0; k < bx * by; ++k) a += r3[k];
-            atomicAdd(sums + 2 * C, a);
+            unsafeAtomicAdd(sums + 2 * C, a);
         }
     }
+}
+
+__global__ void f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
 }
 
 template <int V>
@@ -181,8 +189,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
                                                               const float* __restrict__ y, int ldy,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, const float* __restrict__ sums,
-                                                              float inv_count, int training, float* __restrict__ dy, int lddy,
+                                                              const float* __restrict__ shift, const double* __restrict__ sums,
+                                                              double inv_count, int training, float* __restrict__ dy, int lddy,
                                                               float* __restrict__ dres, int lddr, int64_t npix, int C, int act,
                                                               const float* slope_p, float leaky) {
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
@@ -193,14 +201,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
     ldv<V>(mean + c, mu);
     ldv<V>(invstd + c, is);
     ldv<V>(gamma + c, ga);
-    if (training) {
-        ldv<V>(sums + c, m1);
-        ldv<V>(sums + C + c, m2);
-    }
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        m1[i] = training ? m1[i] * inv_count : 0.f;
-        m2[i] = training ? m2[i] * inv_count : 0.f;
+        m1[i] = training ? (float)(sums[c + i] * inv_count) : 0.f;
+        m2[i] = training ? (float)(sums[C + c + i] * inv_count) : 0.f;
         ga[i] *= is[i];
     }
     const float slope = act == HN_ACT_PRELU ? *slope_p : leaky;
@@ -222,14 +226,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
     }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, float inv_count, float unbias,
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double inv_count, double unbias,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                    float* running_var, float momentum, float eps, float* __restrict__ mean,
                                    float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double m = (double)stats[c] * inv_count;
-    double var = (double)stats[C + c] * inv_count - m * m;
+    const double m = stats[c] * inv_count;
+    double var = stats[C + c] * inv_count - m * m;
     if (var < 0.0) var = 0.0;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     const float mf = (float)m;
@@ -256,22 +260,23 @@ __global__ void bn_eval_params_kernel(const float* __restrict__ gamma, const flo
     shift[c] = beta[c] - rm[c] * sc;
 }
 
+// out[c] += block partial (summed in double inside the block, one float atomic per block and channel)
 template <int V>
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, int ld, int64_t npix, int C,
                                                          float* __restrict__ out) {
-    __shared__ float red[256 * 4];
+    __shared__ double red[256 * 4];
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     const bool live = c < C;
-    float s[V];
+    double s[V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) s[i] = 0.f;
+    for (int i = 0; i < V; ++i) s[i] = 0.0;
     if (live) {
         for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix;
              pix += (int64_t)gridDim.y * blockDim.y) {
             float v[V];
             ldv<V>(x + pix * ld + c, v);
 #pragma unroll
-            for (int i = 0; i < V; ++i) s[i] += v[i];
+            for (int i = 0; i < V; ++i) s[i] += (double)v[i];
         }
     }
     const int bx = blockDim.x, by = blockDim.y, tx = threadIdx.x, ty = threadIdx.y;
@@ -281,30 +286,30 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     if (ty == 0 && live) {
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            float a = 0.f;
+            double a = 0.0;
             for (int k = 0; k < by; ++k) a += red[(k * bx + tx) * V + i];
-            atomicAdd(out + c + i, a);
+            atomicAdd(out + c + i, (float)a);
         }
     }
 }
 
-// stats[0:C] += sum x ; stats[C:2C] += sum x*x  (batch statistics when the producer was not our conv)
+// stats[0:C] += sum x ; stats[C:2C] += sum x*x in double (batch statistics when the producer was not our conv)
 template <int V>
 __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, int ld, int64_t npix, int C,
-                                                           float* __restrict__ out) {
-    __shared__ float red[2 * 256 * 4];
+                                                           double* __restrict__ out) {
+    __shared__ double red[2 * 256 * 4];
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     const bool live = c < C;
-    float s[V], q[V];
+    double s[V], q[V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) s[i] = q[i] = 0.f;
+    for (int i = 0; i < V; ++i) s[i] = q[i] = 0.0;
     if (live) {
         for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix;
              pix += (int64_t)gridDim.y * blockDim.y) {
             float v[V];
             ldv<V>(x + pix * ld + c, v);
 #pragma unroll
-            for (int i = 0; i < V; ++i) { s[i] += v[i]; q[i] += v[i] * v[i]; }
+            for (int i = 0; i < V; ++i) { s[i] += (double)v[i]; q[i] += (double)v[i] * (double)v[i]; }
         }
     }
     const int bx = blockDim.x, by = blockDim.y, tx = threadIdx.x, ty = threadIdx.y;
@@ -317,13 +322,13 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
     if (ty == 0 && live) {
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            float a = 0.f, b = 0.f;
+            double a = 0.0, b = 0.0;
             for (int k = 0; k < by; ++k) {
                 a += red[(k * bx + tx) * V + i];
                 b += red[256 * 4 + (k * bx + tx) * V + i];
             }
-            atomicAdd(out + c + i, a);
-            atomicAdd(out + C + c + i, b);
+            unsafeAtomicAdd(out + c + i, a);
+            unsafeAtomicAdd(out + C + c + i, b);
         }
     }
 }
@@ -381,17 +386,17 @@ bool bad_rows(int64_t npix, int C, std::initializer_list<int> lds) {
 
 #define HN_LAUNCH_V(plan, kern, ...)                                                                     \
     do {                                                                                                 \
-        if ((plan).V == 4) hipLaunchKernelGGL((kern<4>), (plan).grid, (plan).block, 0, s, __VA_ARGS__);  \
-        else hipLaunchKernelGGL((kern<1>), (plan).grid, (plan).block, 0, s, __VA_ARGS__);                \
+        if ((plan).V == 4) HN_LAUNCH((kern<4>), (plan).grid, (plan).block, 0, s, __VA_ARGS__);  \
+        else HN_LAUNCH((kern<1>), (plan).grid, (plan).block, 0, s, __VA_ARGS__);                \
     } while (0)
 
-extern "C" int hn_bn_finalize(const float* stats, int64_t count, const float* gamma, const float* beta,
+extern "C" int hn_bn_finalize(const double* stats, int64_t count, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* mean,
                               float* invstd, float* scale, float* shift, int C, void* stream) {
     if (!stats || !gamma || !beta || !mean || !invstd || !scale || !shift || C <= 0 || count <= 0) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, (float)(1.0 / (double)count),
+    const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+    HN_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, 1.0 / (double)count,
                        unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C);
     HN_CHECK_LAUNCH();
     return HN_OK;
@@ -403,7 +408,7 @@ extern "C" int hn_bn_eval_params(const float* gamma, const float* beta, const fl
     if (!gamma || !beta || !running_mean || !running_var || !mean || !invstd || !scale || !shift || C <= 0)
         return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(bn_eval_params_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gamma, beta, running_mean,
+    HN_LAUNCH(bn_eval_params_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gamma, beta, running_mean,
                        running_var, eps, mean, invstd, scale, shift, C);
     HN_CHECK_LAUNCH();
     return HN_OK;
@@ -423,24 +428,26 @@ extern "C" int hn_bn_act_fwd(const float* y, int ldy, const float* scale, const 
 
 extern "C" int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                                     const float* mean, const float* invstd, const float* scale, const float* shift,
-                                    int64_t npix, int C, int act, const float* slope, float leaky_slope, float* sums,
-                                    void* stream) {
-    if (!dz || !y || !mean || !invstd || !scale || !shift || !sums || act < 0 || act > 3) return HN_EINVAL;
+                                    int64_t npix, int C, int act, const float* slope, float leaky_slope, double* sums,
+                                    float* dparams, void* stream) {
+    if (!dz || !y || !mean || !invstd || !scale || !shift || !sums || !dparams || act < 0 || act > 3) return HN_EINVAL;
     if ((act == HN_ACT_RELU && !z) || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
     if (bad_rows(npix, C, {lddz, ldy}) || (act == HN_ACT_RELU && ldz < C)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(sums, 0, (size_t)(2 * C + 1) * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
+    if (hipMemsetAsync(sums, 0, (size_t)(2 * C + 1) * sizeof(double), s) != hipSuccess) return HN_ELAUNCH;
     const RowLaunch pl = plan_rows(npix, C, {dz, y, act == HN_ACT_RELU ? z : nullptr, mean, invstd, scale, shift},
                                    {lddz, ldy, act == HN_ACT_RELU ? ldz : 4}, 1024);
     HN_LAUNCH_V(pl, bn_act_bwd_reduce_kernel, dz, lddz, z, ldz, y, ldy, mean, invstd, scale, shift, npix, C, act, slope,
                 leaky_slope, sums);
+    HN_CHECK_LAUNCH();
+    HN_LAUNCH(f64_to_f32_kernel, dim3((2 * C + 1 + 255) / 256), dim3(256), 0, s, sums, dparams, 2 * C + 1);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
 
 extern "C" int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                                    const float* mean, const float* invstd, const float* gamma, const float* scale,
-                                   const float* shift, const float* sums, int64_t count, int training, float* dy,
+                                   const float* shift, const double* sums, int64_t count, int training, float* dy,
                                    int lddy, float* dres, int lddr, int64_t npix, int C, int act, const float* slope,
                                    float leaky_slope, void* stream) {
     if (!dz || !y || !mean || !invstd || !gamma || !scale || !shift || !dy || act < 0 || act > 3) return HN_EINVAL;
@@ -451,7 +458,7 @@ extern "C" int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, in
     const RowLaunch pl =
         plan_rows(npix, C, {dz, y, dy, dres, act == HN_ACT_RELU ? z : nullptr, mean, invstd, gamma, scale, shift, sums},
                   {lddz, ldy, lddy, dres ? lddr : 4, act == HN_ACT_RELU ? ldz : 4});
-    const float inv_count = training ? (float)(1.0 / (double)count) : 0.f;
+    const double inv_count = training ? 1.0 / (double)count : 0.0;
     HN_LAUNCH_V(pl, bn_act_bwd_apply_kernel, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, sums, inv_count,
                 training, dy, lddy, dres, lddr, npix, C, act, slope, leaky_slope);
     HN_CHECK_LAUNCH();
@@ -468,10 +475,10 @@ extern "C" int hn_channel_sum(const float* x, int ld, int64_t npix, int C, float
     return HN_OK;
 }
 
-extern "C" int hn_channel_stats(const float* x, int ld, int64_t npix, int C, float* stats, void* stream) {
+extern "C" int hn_channel_stats(const float* x, int ld, int64_t npix, int C, double* stats, void* stream) {
     if (!x || !stats || bad_rows(npix, C, {ld})) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(stats, 0, (size_t)2 * C * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
+    if (hipMemsetAsync(stats, 0, (size_t)2 * C * sizeof(double), s) != hipSuccess) return HN_ELAUNCH;
     const RowLaunch pl = plan_rows(npix, C, {x}, {ld}, 1024);
     HN_LAUNCH_V(pl, channel_stats_kernel, x, ld, npix, C, stats);
     HN_CHECK_LAUNCH();
@@ -483,8 +490,8 @@ extern "C" int hn_act_bwd(const float* dy, int lddy, const float* out, int ldo, 
     if (!dy || !out || !dx || act < 0 || act > 3 || bad_rows(npix, C, {lddy, ldo, lddx})) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const RowLaunch pl = plan_rows(npix, C, {dy, out, dx}, {lddy, ldo, lddx});
-    if (pl.V == 4) hipLaunchKernelGGL((rowwise_kernel<4, 0>), pl.grid, pl.block, 0, s, dy, lddy, out, ldo, dx, lddx, npix, C, act, leaky_slope);
-    else hipLaunchKernelGGL((rowwise_kernel<1, 0>), pl.grid, pl.block, 0, s, dy, lddy, out, ldo, dx, lddx, npix, C, act, leaky_slope);
+    if (pl.V == 4) HN_LAUNCH((rowwise_kernel<4, 0>), pl.grid, pl.block, 0, s, dy, lddy, out, ldo, dx, lddx, npix, C, act, leaky_slope);
+    else HN_LAUNCH((rowwise_kernel<1, 0>), pl.grid, pl.block, 0, s, dy, lddy, out, ldo, dx, lddx, npix, C, act, leaky_slope);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -494,8 +501,8 @@ extern "C" int hn_add(const float* a, int lda, const float* b, int ldb, float* y
     if (!a || !b || !y || bad_rows(npix, C, {lda, ldb, ldy})) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const RowLaunch pl = plan_rows(npix, C, {a, b, y}, {lda, ldb, ldy});
-    if (pl.V == 4) hipLaunchKernelGGL((rowwise_kernel<4, 1>), pl.grid, pl.block, 0, s, a, lda, b, ldb, y, ldy, npix, C, 0, 0.f);
-    else hipLaunchKernelGGL((rowwise_kernel<1, 1>), pl.grid, pl.block, 0, s, a, lda, b, ldb, y, ldy, npix, C, 0, 0.f);
+    if (pl.V == 4) HN_LAUNCH((rowwise_kernel<4, 1>), pl.grid, pl.block, 0, s, a, lda, b, ldb, y, ldy, npix, C, 0, 0.f);
+    else HN_LAUNCH((rowwise_kernel<1, 1>), pl.grid, pl.block, 0, s, a, lda, b, ldb, y, ldy, npix, C, 0, 0.f);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -504,8 +511,8 @@ extern "C" int hn_copy(const float* x, int ldx, float* y, int ldy, int64_t npix,
     if (!x || !y || bad_rows(npix, C, {ldx, ldy})) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const RowLaunch pl = plan_rows(npix, C, {x, y}, {ldx, ldy});
-    if (pl.V == 4) hipLaunchKernelGGL((rowwise_kernel<4, 2>), pl.grid, pl.block, 0, s, x, ldx, nullptr, 0, y, ldy, npix, C, 0, 0.f);
-    else hipLaunchKernelGGL((rowwise_kernel<1, 2>), pl.grid, pl.block, 0, s, x, ldx, nullptr, 0, y, ldy, npix, C, 0, 0.f);
+    if (pl.V == 4) HN_LAUNCH((rowwise_kernel<4, 2>), pl.grid, pl.block, 0, s, x, ldx, nullptr, 0, y, ldy, npix, C, 0, 0.f);
+    else HN_LAUNCH((rowwise_kernel<1, 2>), pl.grid, pl.block, 0, s, x, ldx, nullptr, 0, y, ldy, npix, C, 0, 0.f);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

@@ -274,8 +274,8 @@ bool bad_geom(int N, int H, int W, int C, int Ho, int Wo, int lda, int ldb) {
 
 #define HN_LAUNCH_V(plan, kern, ...)                                                                     \
     do {                                                                                                 \
-        if ((plan).V == 4) hipLaunchKernelGGL((kern<4>), (plan).grid, (plan).block, 0, s, __VA_ARGS__);  \
-        else hipLaunchKernelGGL((kern<1>), (plan).grid, (plan).block, 0, s, __VA_ARGS__);                \
+        if ((plan).V == 4) HN_LAUNCH((kern<4>), (plan).grid, (plan).block, 0, s, __VA_ARGS__);  \
+        else HN_LAUNCH((kern<1>), (plan).grid, (plan).block, 0, s, __VA_ARGS__);                \
     } while (0)
 
 extern "C" int hn_maxpool3x3s2_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx, int N, int H, int W, int C,

@@ -140,7 +140,7 @@ class _Conv2d(torch.autograd.Function):
             raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (cin, cin_w))
         ho, wo = conv_out_size(h, kh, stride, pad, dil), conv_out_size(wd, kw, stride, pad, dil)
         y = new_nhwc(n, cout, ho, wo, x.device)
-        stats = torch.zeros(2 * cout, device=x.device, dtype=torch.float32) if want_stats else None
+        stats = torch.zeros(2 * cout, device=x.device, dtype=torch.float64) if want_stats else None
         d = _desc(n, h, wd, cin, ldx, ho, wo, cout, cout, kh, kw, stride, pad, dil)
         with _ConvTimer("fwd", d):
             check(lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(stats), ctypes.byref(d), act, slope,
@@ -214,7 +214,7 @@ class _BnAct(torch.autograd.Function):
         mean, invstd, scale, shift = par[0:c], par[c:2 * c], par[2 * c:3 * c], par[3 * c:4 * c]
         if training:
             if stats is None:
-                stats = torch.empty(2 * c, device=dev, dtype=torch.float32)
+                stats = torch.empty(2 * c, device=dev, dtype=torch.float64)
                 check(lib.hn_channel_stats(_ptr(y), ldy, npix, c, _ptr(stats), s), "hn_channel_stats")
             check(lib.hn_bn_finalize(_ptr(stats), npix, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                      momentum, eps, _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift), c, s),
@@ -246,9 +246,10 @@ class _BnAct(torch.autograd.Function):
         s = _stream()
         mean, invstd, scale, shift = par[0:c], par[c:2 * c], par[2 * c:3 * c], par[3 * c:4 * c]
         ldz = c
-        sums = torch.empty(2 * c + 1, device=y.device, dtype=torch.float32)
+        sums = torch.empty(2 * c + 1, device=y.device, dtype=torch.float64)   # double workspace
+        dpar = torch.empty(2 * c + 1, device=y.device, dtype=torch.float32)   # dbeta | dgamma | dslope
         check(lib.hn_bn_act_bwd_reduce(_ptr(dz), lddz, _ptr(z), ldz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(scale),
-                                       _ptr(shift), npix, c, act, _ptr(prelu_w), leaky, _ptr(sums), s),
+                                       _ptr(shift), npix, c, act, _ptr(prelu_w), leaky, _ptr(sums), _ptr(dpar), s),
               "hn_bn_act_bwd_reduce")
         dy = new_nhwc(n, c, h, w, y.device) if ctx.needs_input_grad[0] else None
         dres = new_nhwc(n, c, h, w, y.device) if (has_res and ctx.needs_input_grad[6]) else None
@@ -259,9 +260,9 @@ class _BnAct(torch.autograd.Function):
                                           _ptr(gamma), _ptr(scale), _ptr(shift), _ptr(sums), npix, int(training),
                                           _ptr(dy), c, _ptr(dres), c, npix, c, act, _ptr(prelu_w), leaky, s),
                   "hn_bn_act_bwd_apply")
-        dgamma = sums[c:2 * c] if ctx.needs_input_grad[2] else None
-        dbeta = sums[0:c] if ctx.needs_input_grad[3] else None
-        dprelu = sums[2 * c:2 * c + 1] if (prelu_w is not None and ctx.needs_input_grad[7]) else None
+        dgamma = dpar[c:2 * c] if ctx.needs_input_grad[2] else None
+        dbeta = dpar[0:c] if ctx.needs_input_grad[3] else None
+        dprelu = dpar[2 * c:2 * c + 1] if (prelu_w is not None and ctx.needs_input_grad[7]) else None
         return dy, None, dgamma, dbeta, None, None, dres, dprelu, None, None, None, None, None
 
 

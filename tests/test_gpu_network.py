@@ -76,11 +76,14 @@ def test_segnet_backward_matches_oracle(dev):
     loss.backward()
     assert abs(loss.item() - rloss.item()) < 1e-4
     refg = dict(ref.named_parameters())
+    # A conv bias in front of a BatchNorm has an exactly-zero true gradient (fp noise on both sides), so errors are
+    # measured against max(|g_ref|, 1e-4 * largest gradient norm in the net) rather than |g_ref| alone.
+    floor = 1e-4 * max(float(p.grad.double().norm()) for p in ref.parameters())
     worst = ("", 0.0)
     for k, p in net.named_parameters():
         assert p.grad is not None, k
         a, b = p.grad.detach().cpu().double(), refg[k].grad.double()
-        rel = float((a - b).norm() / (b.norm() + 1e-12))
+        rel = float((a - b).norm() / max(float(b.norm()), floor))
         if rel > worst[1]:
             worst = (k, rel)
     assert worst[1] < 2e-3, worst
@@ -155,14 +158,19 @@ def test_confusion_maximisation_steps(dev, golden_dir, adv):
                 np.testing.assert_allclose(b, g["fwd_critic_b%d" % i], atol=1e-3, rtol=1e-3)
             model.load_state_dict(state)
         losses = train_step.train_step(model, opt, [rgb_d, ir_d], [rgb_n, ir_n], lab, state_name, adv=adv)
+        # Step 0 runs on identical weights: tight bounds.  Step 1 follows an RMSprop update whose first step is
+        # lr/sqrt(1-alpha) * sign(g) = 1e-3 * sign(g) per element: critic weights whose gradient is at fp-noise level
+        # may move the other way than on the CPU (|w| ~ 5e-3), which shifts critic outputs by a few 1e-3 relative.
+        tol = 1e-3 if step == 0 else 1e-2
         total = float(g["s%d_total" % step])
-        assert abs(losses["total"].item() - total) < 1e-3 * max(1.0, abs(total)), (losses["total"].item(), total)
+        assert abs(losses["total"].item() - total) < tol * max(1.0, abs(total)), (losses["total"].item(), total)
         if state_name == "train_seg":
             assert abs(losses["seg"].item() - float(g["s1_seg"])) < 1e-3
-            assert abs(losses["conf"].item() - float(g["s1_conf"])) < 1e-3 * max(1.0, abs(float(g["s1_conf"])))
+            assert abs(losses["conf"].item() - float(g["s1_conf"])) < tol * max(1.0, abs(float(g["s1_conf"])))
         names = [str(n) for n in g["s%d_grad_names" % step]]
         norms = dict(zip(names, g["s%d_grad_norms" % step]))
         got = {k: float(p.grad.double().norm()) for k, p in model.named_parameters() if p.grad is not None}
         assert sorted(got) == sorted(names)
-        worst = max(abs(got[k] - norms[k]) / (norms[k] + 1e-9) for k in names)
-        assert worst < 5e-3, worst
+        floor = 1e-4 * max(norms.values())  # conv biases in front of a BatchNorm have a zero true gradient
+        worst = max((abs(got[k] - norms[k]) / max(norms[k], floor), k) for k in names)
+        assert worst[0] < (5e-3 if step == 0 else 5e-2), worst
