@@ -81,8 +81,13 @@ def measure_conv_roofline(step_fn, steps):
         ops.set_conv_profiler(None)
     per_kind = {}
     flops = ms = 0.0
-    for kind, fl, e0, e1 in records:
+    table = {}
+    for kind, fl, e0, e1, shape in records:
         t = e0.elapsed_time(e1)
+        row = table.setdefault((kind,) + shape, [0, 0.0, 0.0])
+        row[0] += 1
+        row[1] += fl
+        row[2] += t
         k = per_kind.setdefault(kind, [0, 0.0, 0.0])
         k[0] += 1
         k[1] += fl
@@ -90,6 +95,12 @@ def measure_conv_roofline(step_fn, steps):
         flops += fl
         ms += t
     launches = len(records)
+    dump = os.environ.get("HN_CONV_TABLE")
+    if dump:  # per-shape table for kernel tuning: kind, geometry, launches/step, ms/step, TFLOP/s
+        with open(dump, "w") as f:
+            f.write("kind N Hin Win Cin Hout Wout Cout K stride dil launches ms_per_step tflops\n")
+            for key, (cnt, fl, t) in sorted(table.items(), key=lambda kv: -kv[1][2]):
+                f.write(" ".join(str(v) for v in key) + " %d %.3f %.1f\n" % (cnt // steps, t / steps, fl / t / 1e9))
     detail = {k: {"launches_per_step": v[0] // steps, "tflop_per_step": v[1] / steps / 1e12,
                   "ms_per_step": v[2] / steps, "avg_launch_us": 1e3 * v[2] / v[0], "tflops": v[1] / v[2] / 1e9}
               for k, v in per_kind.items()}

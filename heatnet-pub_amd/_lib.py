@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libheatnet_hip.so")
+# HEATNET_HIP_LIB selects another build of the same library (kernel experiments); it is never a fallback
+LIB_PATH = os.environ.get("HEATNET_HIP_LIB") or os.path.join(_HERE, "lib", "libheatnet_hip.so")
 
 c_int, c_i64, c_float, c_void_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 P = c_void_p  # every device pointer crosses the ABI as a plain address

@@ -15,12 +15,26 @@
 //
 // The same kernel computes the data gradient: dX = conv(dY "dilated" by the forward stride, flipped and
 // transposed weights) -- `in_dil` below.
+#include <type_traits>
+
 #include "hn_common.h"
+
+#ifdef HN_EXP_PIN
+#define HN_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define HN_PIN() ((void)0)
+#endif
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDK = 36;
+#ifndef HN_BK
+#define HN_BK 32
+#endif
+constexpr int BK = HN_BK;      // reduction indices per K step
+constexpr int LDK = BK + 4;    // LDS row stride in floats: 16-B aligned rows, conflict-free ds_read_b128
+constexpr int PR = BK / 4;     // 16-B pieces per staged row
+constexpr int VROWS = 256 / PR;  // rows staged by one pass of the 256 threads (vector path)
+constexpr int SROWS = 256 / BK;  // same, scalar path
 
 struct ConvArgs {
     const float* x;
@@ -34,10 +48,24 @@ struct ConvArgs {
     int M, Kdim, ntm, ntn;
     int act;
     float slope;
+    long long x_bytes;  // extent of the gathered tensor from p.x, for the buffer descriptors
 };
 
-template <int TM, int TN, bool VEC>
+// Loader variants.  BUF fetches through buffer descriptors: one SGPR resource per tile, 32-bit byte offsets, and
+// out-of-range taps / rows are zero-filled by the hardware range check instead of by selects.
+enum : int { MODE_SCALAR = 0, MODE_SCALAR_STRIDED = 1, MODE_VEC = 2, MODE_VEC_STRIDED = 3, MODE_VEC_BUF = 4 };
+
+__device__ __forceinline__ f32x4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
+}
+
+// STRIDED = the gathered tensor is "dilated" by in_dil > 1 (data gradient of a strided convolution): taps must
+// land on multiples of in_dil.  Kept out of the common instantiation because it costs integer divisions per tap.
+template <int TM, int TN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
+    constexpr bool VEC = MODE >= MODE_VEC;
+    constexpr bool STRIDED = MODE == MODE_SCALAR_STRIDED || MODE == MODE_VEC_STRIDED;
+    constexpr bool BUF = MODE == MODE_VEC_BUF;
     constexpr int BM = 64 * TM, BN = 64 * TN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                        // [2][BM][LDK]
@@ -68,74 +96,146 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     __syncthreads();
 
     // ---- operand staging -------------------------------------------------------------------------------
-    constexpr int RA = VEC ? BM / 32 : BM / 8;
-    constexpr int RB = VEC ? BN / 32 : BN / 8;
+    constexpr int RA = VEC ? BM / VROWS : BM / SROWS;
+    constexpr int RB = VEC ? BN / VROWS : BN / SROWS;
     f32x4 va[VEC ? RA : 1], vb[VEC ? RB : 1];
     float sa[VEC ? 1 : RA], sb[VEC ? 1 : RB];
     int ahb[VEC ? RA : 1], awb[VEC ? RA : 1], anb[VEC ? RA : 1];
-    const int c4 = tid & 7, vrow = tid >> 3;    // VEC: 8 lanes x 16 B cover one 128-B row of the K step
-    const int sk = tid & 31, srow = tid >> 5;   // scalar: 32 lanes cover one row of the K step
+    long long aoff[VEC ? RA : 1];  // element offset of the row's (h base, w base) pixel, may be negative
+    long long boff[VEC ? RB : 1];
+    const int c4 = tid % PR, vrow = tid / PR;   // VEC: PR lanes x 16 B cover one row of the K step
+    const int sk = tid % BK, srow = tid / BK;   // scalar: BK lanes cover one row of the K step
     if constexpr (VEC) {
 #pragma unroll
         for (int q = 0; q < RA; ++q) {
-            const int r = vrow + 32 * q;
+            const int r = vrow + VROWS * q;
             ahb[q] = rowinfo[r * 4 + 0];
             awb[q] = rowinfo[r * 4 + 1];
             anb[q] = rowinfo[r * 4 + 2];
+            aoff[q] = ((long long)anb[q] + (long long)ahb[q] * p.W + awb[q]) * p.ldx + c4 * 4;
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int co = n0 + vrow + VROWS * q;
+            boff[q] = co < p.K ? (long long)co * p.Kdim + c4 * 4 : -1;
         }
     }
+    // BUF: resources rebased to the tile (first image touched / first weight row) so that offsets fit 32 bits
+    int aoff32[BUF ? RA : 1];
+    unsigned boff32[BUF ? RB : 1];
+    __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
+    unsigned a_records = 0;
+    if constexpr (BUF) {
+        const int nb0 = __builtin_amdgcn_readfirstlane(rowinfo[2]);
+        const long long a_base = (long long)nb0 * p.ldx * 4;
+        const long long a_left = p.x_bytes - a_base;
+        a_records = a_left > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)a_left;
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + (long long)nb0 * p.ldx, 0, a_records, 0x00020000);
+        const int rows_b = min(BN, p.K - n0);
+        rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w) + (long long)n0 * p.Kdim, 0,
+                                                   (unsigned)((long long)rows_b * p.Kdim * 4), 0x00020000);
+#pragma unroll
+        for (int q = 0; q < RA; ++q)
+            aoff32[q] = (((anb[q] - nb0) + ahb[q] * p.W + awb[q]) * p.ldx + c4 * 4) * 4;
+#pragma unroll
+        for (int q = 0; q < RB; ++q) boff32[q] = (unsigned)(((vrow + VROWS * q) * p.Kdim + c4 * 4) * 4);
+    }
 
-    auto tap_ok = [&](int& h, int& w) -> bool {
-        bool ok = true;
-        if (p.in_dil > 1) {
-            ok = (h >= 0) & (w >= 0) & (h % p.in_dil == 0) & (w % p.in_dil == 0);
-            h /= p.in_dil;
-            w /= p.in_dil;
-        }
-        return ok & ((unsigned)h < (unsigned)p.H) & ((unsigned)w < (unsigned)p.W);
-    };
+    // K-step position of the NEXT chunk to fetch, advanced incrementally (VEC: a step never straddles a tap
+    // because C % 32 == 0).
+    int st_kh = 0, st_kw = 0, st_c0 = 0, st_k0 = 0;
 
-    auto load_global = [&](int kc) {
-        const int k0 = kc * BK;
+    // Predicated loads are branch-free (the address falls back to the tensor base, the value is zeroed by a
+    // select) so that a whole K step stays one basic block the scheduler can interleave with the MFMAs.
+    auto load_a = [&]() {
         if constexpr (VEC) {
-            const int tap = k0 / p.C, c0 = k0 - tap * p.C;
-            const int kh = tap / p.KW, kw = tap - kh * p.KW;
-            const int dh = kh * p.dil, dw = kw * p.dil;
+            const int dh = st_kh * p.dil, dw = st_kw * p.dil;
+            if constexpr (BUF) {
+                const int doff = ((dh * p.W + dw) * p.ldx + st_c0) * 4;
 #pragma unroll
-            for (int q = 0; q < RA; ++q) {
-                int h = ahb[q] + dh, w = awb[q] + dw;
-                const bool ok = tap_ok(h, w);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(anb[q] + h * p.W + w) * p.ldx + c0 + c4 * 4);
-                va[q] = v;
-            }
+                for (int q = 0; q < RA; ++q) {
+                    const bool ok = ((unsigned)(ahb[q] + dh) < (unsigned)p.H) & ((unsigned)(awb[q] + dw) < (unsigned)p.W);
+                    va[q] = buffer_load16(rsrc_a, ok ? (unsigned)(aoff32[q] + doff) : a_records, 0);
+                }
+            } else if constexpr (!STRIDED) {
+                const long long doff = ((long long)dh * p.W + dw) * p.ldx + st_c0;
 #pragma unroll
-            for (int q = 0; q < RB; ++q) {
-                const int co = n0 + vrow + 32 * q;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (co < p.K) v = *reinterpret_cast<const f32x4*>(p.w + (size_t)co * p.Kdim + k0 + c4 * 4);
-                vb[q] = v;
+                for (int q = 0; q < RA; ++q) {
+                    const bool ok = ((unsigned)(ahb[q] + dh) < (unsigned)p.H) & ((unsigned)(awb[q] + dw) < (unsigned)p.W);
+                    const float* src = ok ? p.x + (aoff[q] + doff) : p.x;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    va[q] = ok ? v : z;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < RA; ++q) {
+                    int h = ahb[q] + dh, w = awb[q] + dw;
+                    bool ok = (h >= 0) & (w >= 0) & (h % p.in_dil == 0) & (w % p.in_dil == 0);
+                    h /= p.in_dil;
+                    w /= p.in_dil;
+                    ok = ok & (h < p.H) & (w < p.W);
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(anb[q] + h * p.W + w) * p.ldx + st_c0 + c4 * 4);
+                    va[q] = v;
+                }
             }
         } else {
-            const int kg = k0 + sk;
+            const int kg = st_k0 + sk;
             const bool kvalid = kg < p.Kdim;
             const int tap = kg / p.C, ci = kg - tap * p.C;
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
             const int dh = kh * p.dil, dw = kw * p.dil;
 #pragma unroll
             for (int q = 0; q < RA; ++q) {
-                const int r = srow + 8 * q;
+                const int r = srow + SROWS * q;
                 int h = rowinfo[r * 4 + 0] + dh, w = rowinfo[r * 4 + 1] + dw;
                 const int nb = rowinfo[r * 4 + 2];
-                const bool ok = tap_ok(h, w) & kvalid;
+                bool ok = kvalid;
+                if constexpr (STRIDED) {
+                    ok = ok & (h >= 0) & (w >= 0) & (h % p.in_dil == 0) & (w % p.in_dil == 0);
+                    h /= p.in_dil;
+                    w /= p.in_dil;
+                }
+                ok = ok & ((unsigned)h < (unsigned)p.H) & ((unsigned)w < (unsigned)p.W);
                 sa[q] = ok ? p.x[(size_t)(nb + h * p.W + w) * p.ldx + ci] : 0.f;
             }
+        }
+    };
+    auto load_b = [&]() {  // also advances the fetch position
+        if constexpr (BUF) {
+            // rows past Cout are beyond the resource's extent: zero-filled by the range check
+#pragma unroll
+            for (int q = 0; q < RB; ++q) vb[q] = buffer_load16(rsrc_b, boff32[q], (unsigned)(st_k0 * 4));
+            st_c0 += BK;
+            if (st_c0 >= p.C) {
+                st_c0 = 0;
+                if (++st_kw == p.KW) { st_kw = 0; ++st_kh; }
+            }
+        } else if constexpr (VEC) {
 #pragma unroll
             for (int q = 0; q < RB; ++q) {
-                const int co = n0 + srow + 8 * q;
+                const bool ok = boff[q] >= 0;
+                const float* src = ok ? p.w + (boff[q] + st_k0) : p.w;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                vb[q] = ok ? v : z;
+            }
+            st_c0 += BK;
+            if (st_c0 >= p.C) {
+                st_c0 = 0;
+                if (++st_kw == p.KW) { st_kw = 0; ++st_kh; }
+            }
+        } else {
+            const int kg = st_k0 + sk;
+            const bool kvalid = kg < p.Kdim;
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                const int co = n0 + srow + SROWS * q;
                 sb[q] = (kvalid && co < p.K) ? p.w[(size_t)co * p.Kdim + kg] : 0.f;
             }
         }
+        st_k0 += BK;
     };
 
     auto store_lds = [&](int buf) {
@@ -143,14 +243,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         float* b = Bs + buf * BN * LDK;
         if constexpr (VEC) {
 #pragma unroll
-            for (int q = 0; q < RA; ++q) *reinterpret_cast<f32x4*>(a + (vrow + 32 * q) * LDK + c4 * 4) = va[q];
+            for (int q = 0; q < RA; ++q) *reinterpret_cast<f32x4*>(a + (vrow + VROWS * q) * LDK + c4 * 4) = va[q];
 #pragma unroll
-            for (int q = 0; q < RB; ++q) *reinterpret_cast<f32x4*>(b + (vrow + 32 * q) * LDK + c4 * 4) = vb[q];
+            for (int q = 0; q < RB; ++q) *reinterpret_cast<f32x4*>(b + (vrow + VROWS * q) * LDK + c4 * 4) = vb[q];
         } else {
 #pragma unroll
-            for (int q = 0; q < RA; ++q) a[(srow + 8 * q) * LDK + sk] = sa[q];
+            for (int q = 0; q < RA; ++q) a[(srow + SROWS * q) * LDK + sk] = sa[q];
 #pragma unroll
-            for (int q = 0; q < RB; ++q) b[(srow + 8 * q) * LDK + sk] = sb[q];
+            for (int q = 0; q < RB; ++q) b[(srow + SROWS * q) * LDK + sk] = sb[q];
         }
     };
 
@@ -166,80 +266,138 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     const int lr = lane & 31, lh = lane >> 5;
     const int nchunks = (p.Kdim + BK - 1) / BK;
 
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
+    // Fragments are double-buffered in registers: the ds_read_b128s of group g+1 are issued before the 16 MFMAs of
+    // group g, so LDS latency is exposed once per K step (after the barrier) instead of once per group.
+    struct Frag {
+        f32x4 a[TM], b[TN];
+    };
+    auto read_frag = [&](int buf, int kk, Frag& f) {
+        const float* a = As + buf * BM * LDK + (wm * TM * 32 + lr) * LDK + lh * 4 + kk * 8;
+        const float* b = Bs + buf * BN * LDK + (wn * TN * 32 + lr) * LDK + lh * 4 + kk * 8;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK);
+    };
+    auto mfma16 = [&](const Frag& f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
+    };
 
-    for (int kc = 0; kc < nchunks; ++kc) {
-        const int buf = kc & 1;
-        const bool more = kc + 1 < nchunks;
-        if (more) load_global(kc + 1);
-
-        const float* a = As + buf * BM * LDK + (wm * TM * 32 + lr) * LDK + lh * 4;
-        const float* b = Bs + buf * BN * LDK + (wn * TN * 32 + lr) * LDK + lh * 4;
+    // Software pipeline, two LDS buffers: while step kc multiplies buffer kc&1, the staging registers (chunk kc+1,
+    // fetched during step kc-1) are written to the other buffer first, then the fetch of chunk kc+2 is issued in
+    // two halves between the MFMA groups -- every global load has a full K step to land before it is needed.
+    auto k_step = [&](int buf, auto write_tag, auto fetch_tag) {
+        constexpr int G = BK / 8;  // MFMA groups per step
+        Frag f[2];
+        read_frag(buf, 0, f[0]);
+#ifndef HN_EXP_NOWRITE
+        if constexpr (decltype(write_tag)::value) store_lds(buf ^ 1);
+#endif
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + kk * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK + kk * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        for (int g = 0; g < G; ++g) {
+            if (g + 1 < G) read_frag(buf, g + 1, f[(g + 1) & 1]);
+#ifndef HN_EXP_NOLOAD
+            if constexpr (decltype(fetch_tag)::value) {
+                if (g == (G >= 4 ? 1 : 0)) load_a();
+                if (g == (G >= 4 ? 2 : G - 1)) load_b();
+            }
+#endif
+            mfma16(f[g & 1]);
         }
-
-        if (more) store_lds(buf ^ 1);
+#ifndef HN_EXP_NOBARRIER
         __syncthreads();
+#endif
+    };
+
+    load_a();
+    load_b();
+    store_lds(0);
+    if (nchunks > 1) {
+        load_a();
+        load_b();
     }
+    __syncthreads();
+    int kc = 0;
+    for (; kc + 2 < nchunks; ++kc) k_step(kc & 1, std::true_type{}, std::true_type{});
+    if (kc + 1 < nchunks) {
+        k_step(kc & 1, std::true_type{}, std::false_type{});
+        ++kc;
+    }
+    k_step(kc & 1, std::false_type{}, std::false_type{});
 
     // ---- epilogue: bias, batch-statistics partials, activation, store -------------------------------------
     // Accumulator map (32x32 MFMA): column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // The bias is loaded unconditionally (clamped index) and folded in BEFORE any store is issued, and full tiles
+    // take a branch-free path: a conditional load inside the store loop makes hipcc wait vmcnt(0) -- i.e. for the
+    // previous store -- in front of every store.
+    const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.K);
+    float bias_v[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 32 + lr;
-        const bool cok = col < p.K;
-        const float bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
+        const int col = min(n0 + (wn * TN + j) * 32 + lr, p.K - 1);
+        bias_v[j] = p.bias != nullptr ? p.bias[col] : 0.f;
+    }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                const float v = acc[i][j][r] + bv;
-                if (row < p.M && cok) {
-                    s1 += v;
-                    s2 += v * v;
-                    p.y[(size_t)row * p.ldy + col] = hn_apply_act(v, p.act, p.slope);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += bias_v[j];
+
+    // branch-free activation: out = v > 0 ? v : v * neg_slope  (none: 1, relu: 0, leaky/prelu: slope)
+    const float neg_slope = p.act == HN_ACT_NONE ? 1.f : (p.act == HN_ACT_RELU ? 0.f : p.slope);
+    auto finish = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + lr;
+            const bool cok = FULL || col < p.K;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
+                float* dst = p.y + (size_t)rbase * p.ldy + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    const float v = acc[i][j][r];
+                    if (FULL || (rbase + ro < p.M && cok)) {
+                        s1 += v;
+                        s2 += v * v;
+                        dst[(size_t)ro * p.ldy] = v > 0.f ? v : v * neg_slope;
+                    }
+                }
+            }
+            if (p.stats != nullptr) {
+                // <= 64 rows per lane were summed in fp32; everything across tiles is accumulated in double
+                // (global_atomic_add_f64), like the double accumulators of the CPU reference's BatchNorm.
+                double d1 = (double)s1, d2 = (double)s2;
+                d1 += __shfl_xor(d1, 32);
+                d2 += __shfl_xor(d2, 32);
+                if (lh == 0 && cok) {
+                    unsafeAtomicAdd(p.stats + col, d1);
+                    unsafeAtomicAdd(p.stats + p.K + col, d2);
                 }
             }
         }
-        if (p.stats != nullptr) {
-            // <= 64 rows per lane were summed in fp32; everything across tiles is accumulated in double
-            // (global_atomic_add_f64), like the double accumulators of the CPU reference's BatchNorm.
-            double d1 = (double)s1, d2 = (double)s2;
-            d1 += __shfl_xor(d1, 32);
-            d2 += __shfl_xor(d2, 32);
-            if (lh == 0 && cok) {
-                unsafeAtomicAdd(p.stats + col, d1);
-                unsafeAtomicAdd(p.stats + p.K + col, d2);
-            }
-        }
-    }
+    };
+    if (full) finish(std::true_type{});
+    else finish(std::false_type{});
 }
 
-template <int TM, int TN, bool VEC>
+template <int TM, int TN, int MODE>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int lds = (2 * (BM + BN) * LDK + BM * 4) * (int)sizeof(float);
     static bool configured = false;  // raising the dynamic-LDS cap is idempotent; the flag only saves calls
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<TM, TN, VEC>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<TM, TN, MODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return HN_ELAUNCH;
         configured = true;
@@ -247,9 +405,15 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     ConvArgs p = a;
     p.ntm = (a.M + BM - 1) / BM;
     p.ntn = (a.K + BN - 1) / BN;
-    HN_LAUNCH((conv_igemm_kernel<TM, TN, VEC>), dim3(p.ntm * p.ntn), dim3(256), lds, stream, p);
+    HN_LAUNCH((conv_igemm_kernel<TM, TN, MODE>), dim3(p.ntm * p.ntn), dim3(256), lds, stream, p);
     HN_CHECK_LAUNCH();
     return HN_OK;
+}
+
+template <int MODE>
+int dispatch_tile(const ConvArgs& a, bool tall, bool wide, hipStream_t stream) {
+    if (tall) return wide ? launch_conv<2, 2, MODE>(a, stream) : launch_conv<2, 1, MODE>(a, stream);
+    return wide ? launch_conv<1, 2, MODE>(a, stream) : launch_conv<1, 1, MODE>(a, stream);
 }
 
 int dispatch_conv(const ConvArgs& a, hipStream_t stream) {
@@ -257,12 +421,15 @@ int dispatch_conv(const ConvArgs& a, hipStream_t stream) {
     const bool wide = a.K > 64;
     const long blocks128 = (long)((a.M + 127) / 128) * ((a.K + (wide ? 127 : 63)) / (wide ? 128 : 64));
     const bool tall = blocks128 >= 256;  // enough 128-row tiles to cover the chip; else halve the tile
-    if (vec) {
-        if (tall) return wide ? launch_conv<2, 2, true>(a, stream) : launch_conv<2, 1, true>(a, stream);
-        return wide ? launch_conv<1, 2, true>(a, stream) : launch_conv<1, 1, true>(a, stream);
-    }
-    if (tall) return wide ? launch_conv<2, 2, false>(a, stream) : launch_conv<2, 1, false>(a, stream);
-    return wide ? launch_conv<1, 2, false>(a, stream) : launch_conv<1, 1, false>(a, stream);
+    const bool strided = a.in_dil > 1;
+    // buffer path: offsets are 32-bit relative to the first image a tile touches (a tile may reach into the next
+    // image) and to the tile's first weight row
+    const long long image_bytes = (long long)a.H * a.W * a.ldx * 4;
+    const bool buf_ok = 3 * image_bytes < (1ll << 31) && 128ll * a.Kdim * 4 < (1ll << 31) &&
+                        (long long)a.H * a.W >= 128;
+    if (vec && !strided && buf_ok) return dispatch_tile<MODE_VEC_BUF>(a, tall, wide, stream);
+    if (vec) return strided ? dispatch_tile<MODE_VEC_STRIDED>(a, tall, wide, stream) : dispatch_tile<MODE_VEC>(a, tall, wide, stream);
+    return strided ? dispatch_tile<MODE_SCALAR_STRIDED>(a, tall, wide, stream) : dispatch_tile<MODE_SCALAR>(a, tall, wide, stream);
 }
 
 int check_desc(const HnConvDesc* d) {
@@ -314,6 +481,7 @@ extern "C" int hn_conv2d_fwd(const float* x, const float* w, const float* bias, 
     a.Kdim = d->KH * d->KW * d->Cin;
     a.ntm = a.ntn = 0;
     a.act = act; a.slope = slope;
+    a.x_bytes = (((long long)d->N * d->Hin * d->Win - 1) * d->ldx + d->Cin) * 4;
     return dispatch_conv(a, static_cast<hipStream_t>(stream));
 }
 
@@ -332,8 +500,7 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, cons
     a.Kdim = d->KH * d->KW * d->Cout;
     a.ntm = a.ntn = 0;
     a.act = HN_ACT_NONE; a.slope = 0.f;
-    // the gather compares against the DILATED extent of dY
-    a.H = d->Hout; a.W = d->Wout;
+    a.x_bytes = (((long long)d->N * d->Hout * d->Wout - 1) * d->ldy + d->Cout) * 4;
     return dispatch_conv(a, static_cast<hipStream_t>(stream));
 }
 

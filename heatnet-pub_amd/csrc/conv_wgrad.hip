@@ -2,16 +2,31 @@
 //
 // GEMM view: dW[co][(kh,kw,ci)] = sum over output pixels p of dY[p][co] * X[tap-shifted p][ci]
 //   m = output channel, n = (tap, ci), reduction over pixels (28 k ... 1.8 M of them), so the output is
-//   small and the reduction is split over blockIdx.z; partial tiles meet in dW through
+//   small and the reduction is split over the grid; partial tiles meet in dW through
 //   global_atomic_add_f32 (dW zeroed first), or are stored directly when there is a single split.
 // Both operands are pixel-major in memory (NHWC), i.e. the reduction index is the slow one: tiles are
 // staged as [32 pixels][BM or BN channels] and a lane's MFMA operand is one ds_read_b32 -- lanes 0..31
 // read 32 consecutive channels of pixel row 2*kk, lanes 32..63 of row 2*kk+1 (conflict-free).
+//
+// Loader variants: WG_VEC_BUF (16-B buffer loads through per-launch SGPR resources, out-of-range taps and
+// pixel tails zero-filled by the hardware range check, pixel coordinates advanced incrementally -- no integer
+// division in the loop), WG_VEC (same with plain global loads, for tensors beyond 4 GiB), WG_SCALAR (any
+// channel count / alignment: 7x7x3 stem, 13- and 1-channel heads).
+#include <type_traits>
+
 #include "hn_common.h"
+
+#ifdef HN_EXP_PIN
+#define HN_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define HN_PIN() ((void)0)
+#endif
 
 namespace {
 
 constexpr int BKP = 32;  // pixels per reduction step
+
+enum : int { WG_SCALAR = 0, WG_VEC = 1, WG_VEC_BUF = 2 };
 
 struct WgradArgs {
     const float* x;
@@ -25,10 +40,17 @@ struct WgradArgs {
     int ntm, ntn; // tiles over Cout and over (tap, ci)
     int chunks_per_split;
     int atomic;
+    long long x_bytes, dy_bytes;
 };
 
-template <int TM, int TN, bool VEC>
+__device__ __forceinline__ f32x4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
+}
+
+template <int TM, int TN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
+    constexpr bool VEC = MODE != WG_SCALAR;
+    constexpr bool BUF = MODE == WG_VEC_BUF;
     constexpr int BM = 64 * TM, BN = 64 * TN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                   // [2][BKP][BM]  dY tile
@@ -50,6 +72,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     constexpr int CA = BM / 4, CB = BN / 4;               // 16-B pieces per pixel row
     constexpr int RA = VEC ? (BKP * CA) / 256 : (BKP * BM) / 256;
     constexpr int RB = VEC ? (BKP * CB) / 256 : (BKP * BN) / 256;
+    constexpr int ROWS_A = 256 / CA, ROWS_B = 256 / CB;   // VEC: pixel rows covered by one pass of the 256 threads
     f32x4 va[VEC ? RA : 1], vb[VEC ? RB : 1];
     float sa[VEC ? 1 : RA], sb[VEC ? 1 : RB];
 
@@ -60,13 +83,50 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     }
     const int vkh = tap / p.KW, vkw = tap - vkh * p.KW;
 
+    // ---- VEC state: this thread's piece column and the coordinates of its RB gathered pixels ---------------
+    const int a_c4 = tid % CA, a_r0 = tid / CA;
+    const int b_c4 = tid % CB, b_r0 = tid / CB;
+    const bool a_col_ok = co0 + a_c4 * 4 < p.K;
+    int hq[VEC ? RB : 1], wq[VEC ? RB : 1];   // input row / column hit by this tile's tap for pixel (ho, wo)
+    int wo_[VEC ? RB : 1], ho_[VEC ? RB : 1];
+    long long xoff[VEC ? RB : 1];             // element offset of that input pixel (+ channel piece)
+    unsigned a_voff[BUF ? RA : 1];
+    __amdgpu_buffer_rsrc_t rsrc_x, rsrc_dy;
+    unsigned x_records = 0;
+    if constexpr (VEC) {
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int pix = c_begin * BKP + b_r0 + ROWS_B * q;
+            const int n = pix / hw, rem = pix - n * hw;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            ho_[q] = ho;
+            wo_[q] = wo;
+            hq[q] = ho * p.stride - p.pad + vkh * p.dil;
+            wq[q] = wo * p.stride - p.pad + vkw * p.dil;
+            xoff[q] = ((long long)(n * p.H + hq[q]) * p.W + wq[q]) * p.ldx + ci0 + b_c4 * 4;
+        }
+    }
+    if constexpr (BUF) {
+        x_records = (unsigned)p.x_bytes;
+        rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, x_records, 0x00020000);
+        rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (unsigned)p.dy_bytes, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < RA; ++q)
+            a_voff[q] = a_col_ok ? (unsigned)(((a_r0 + ROWS_A * q) * p.ldy + co0 + a_c4 * 4) * 4) : (unsigned)p.dy_bytes;
+    }
+    // uniform increments of xoff when a pixel advances by one step (32 pixels) and wraps rows / images
+    const long long step_w = (long long)p.stride * p.ldx;
+    const long long step_h = (long long)p.stride * p.W * p.ldx;
+    const long long wrap_w = step_h - (long long)p.Wo * step_w;                        // wo -= Wo, ho += 1
+    const long long wrap_h = (long long)p.H * p.W * p.ldx - (long long)p.Ho * step_h;  // ho -= Ho, n += 1
+
     // scalar path: this thread's fixed column of each tile
-    const int a_col = tid % BM, a_row0 = tid / BM;      // rows a_row0 + (256/BM)*q
-    const int b_col = tid % BN, b_row0 = tid / BN;
+    const int sa_col = tid % BM, sa_row0 = tid / BM;      // rows sa_row0 + (256/BM)*q
+    const int sb_col = tid % BN, sb_row0 = tid / BN;
     int s_kh = 0, s_kw = 0, s_ci = 0;
     bool s_nvalid = false;
     if constexpr (!VEC) {
-        const int n = n0 + b_col;
+        const int n = n0 + sb_col;
         s_nvalid = n < p.Kdim;
         const int t = n / p.C;
         s_ci = n - t * p.C;
@@ -84,40 +144,79 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
         return true;
     };
 
-    auto load_global = [&](int chunk) {
-        const int p0 = chunk * BKP;
-        if constexpr (VEC) {
+    int fetch_chunk = c_begin;  // next chunk to fetch
+
+    auto load_a = [&]() {
+        const int p0 = fetch_chunk * BKP;
+        if constexpr (BUF) {
+            // rows past M lie beyond the resource extent and come back as zeros.  The chunk advance is folded into
+            // voffset (not soffset) so that the range check sees the full offset.
+            const unsigned adv = (unsigned)((long long)p0 * p.ldy * 4);
 #pragma unroll
             for (int q = 0; q < RA; ++q) {
-                const int piece = tid + 256 * q;
-                const int row = piece / CA, c4 = piece - row * CA;
-                const int pix = p0 + row, co = co0 + c4 * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (pix < p.M && co < p.K) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)pix * p.ldy + co);
-                va[q] = v;
+                const unsigned off = a_voff[q] + adv;
+                va[q] = buffer_load16(rsrc_dy, off < a_voff[q] ? 0xFFFFFFFFu : off, 0);
             }
+        } else if constexpr (VEC) {
 #pragma unroll
-            for (int q = 0; q < RB; ++q) {
-                const int piece = tid + 256 * q;
-                const int row = piece / CB, c4 = piece - row * CB;
-                size_t off = 0;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (gather_pixel(p0 + row, vkh, vkw, off)) v = *reinterpret_cast<const f32x4*>(p.x + off + ci0 + c4 * 4);
-                vb[q] = v;
+            for (int q = 0; q < RA; ++q) {
+                const int pix = p0 + a_r0 + ROWS_A * q;
+                const bool ok = (pix < p.M) & a_col_ok;
+                const float* src = ok ? p.dy + ((size_t)pix * p.ldy + co0 + a_c4 * 4) : p.dy;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                va[q] = ok ? v : z;
             }
         } else {
 #pragma unroll
             for (int q = 0; q < RA; ++q) {
-                const int pix = p0 + a_row0 + (256 / BM) * q, co = co0 + a_col;
+                const int pix = p0 + sa_row0 + (256 / BM) * q, co = co0 + sa_col;
                 sa[q] = (pix < p.M && co < p.K) ? p.dy[(size_t)pix * p.ldy + co] : 0.f;
             }
+        }
+    };
+
+    auto load_b = [&]() {  // also advances the fetch position
+        const int p0 = fetch_chunk * BKP;
+        if constexpr (VEC) {
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                const int pix = p0 + b_r0 + ROWS_B * q;
+                const bool ok = (pix < p.M) & ((unsigned)hq[q] < (unsigned)p.H) & ((unsigned)wq[q] < (unsigned)p.W);
+                if constexpr (BUF) {
+                    vb[q] = buffer_load16(rsrc_x, ok ? (unsigned)(xoff[q] * 4) : x_records, 0);
+                } else {
+                    const float* src = ok ? p.x + xoff[q] : p.x;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    vb[q] = ok ? v : z;
+                }
+                // advance this pixel by one reduction step
+                wo_[q] += BKP;
+                wq[q] += BKP * p.stride;
+                xoff[q] += BKP * step_w;
+                while (wo_[q] >= p.Wo) {
+                    wo_[q] -= p.Wo;
+                    wq[q] -= p.Wo * p.stride;
+                    ho_[q] += 1;
+                    hq[q] += p.stride;
+                    xoff[q] += wrap_w;
+                    if (ho_[q] >= p.Ho) {
+                        ho_[q] -= p.Ho;
+                        hq[q] -= p.Ho * p.stride;
+                        xoff[q] += wrap_h;
+                    }
+                }
+            }
+        } else {
 #pragma unroll
             for (int q = 0; q < RB; ++q) {
                 size_t off = 0;
-                const bool ok = s_nvalid && gather_pixel(p0 + b_row0 + (256 / BN) * q, s_kh, s_kw, off);
+                const bool ok = s_nvalid && gather_pixel(p0 + sb_row0 + (256 / BN) * q, s_kh, s_kw, off);
                 sb[q] = ok ? p.x[off + s_ci] : 0.f;
             }
         }
+        ++fetch_chunk;
     };
 
     auto store_lds = [&](int buf) {
@@ -130,9 +229,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
             for (int q = 0; q < RB; ++q) *reinterpret_cast<f32x4*>(b + (tid + 256 * q) * 4) = vb[q];
         } else {
 #pragma unroll
-            for (int q = 0; q < RA; ++q) a[(a_row0 + (256 / BM) * q) * BM + a_col] = sa[q];
+            for (int q = 0; q < RA; ++q) a[(sa_row0 + (256 / BM) * q) * BM + sa_col] = sa[q];
 #pragma unroll
-            for (int q = 0; q < RB; ++q) b[(b_row0 + (256 / BN) * q) * BN + b_col] = sb[q];
+            for (int q = 0; q < RB; ++q) b[(sb_row0 + (256 / BN) * q) * BN + sb_col] = sb[q];
         }
     };
 
@@ -146,59 +245,119 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
 
     const int lr = lane & 31, lh = lane >> 5;
 
-    if (c_begin < c_end) {
-        load_global(c_begin);
-        store_lds(0);
-        __syncthreads();
-        for (int c = c_begin; c < c_end; ++c) {
-            const int buf = (c - c_begin) & 1;
-            const bool more = c + 1 < c_end;
-            if (more) load_global(c + 1);
-            const float* a = As + buf * BKP * BM + lh * BM + wm * TM * 32 + lr;
-            const float* b = Bs + buf * BKP * BN + lh * BN + wn * TN * 32 + lr;
+    // One group = 8 pixels of the reduction = 4 MFMA k-pairs; its 4*(TM+TN) ds_read_b32 fragments are
+    // double-buffered in registers and fetched one group ahead of the MFMAs that consume them.
+    struct Frag {
+        float a[4][TM], b[4][TN];
+    };
+    auto read_frag = [&](int buf, int g, Frag& f) {
+        const float* a = As + buf * BKP * BM + (g * 8 + lh) * BM + wm * TM * 32 + lr;
+        const float* b = Bs + buf * BKP * BN + (g * 8 + lh) * BN + wn * TN * 32 + lr;
 #pragma unroll
-            for (int kk = 0; kk < BKP / 2; ++kk) {
-                float fa[TM], fb[TN];
+        for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = a[kk * 2 * BM + i * 32];
+            for (int i = 0; i < TM; ++i) f.a[kk][i] = a[kk * 2 * BM + i * 32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = b[kk * 2 * BN + j * 32];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            }
-            if (more) store_lds(buf ^ 1);
-            __syncthreads();
+            for (int j = 0; j < TN; ++j) f.b[kk][j] = b[kk * 2 * BN + j * 32];
         }
+    };
+    auto mfma16 = [&](const Frag& f) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[kk][i], f.b[kk][j], acc[i][j], 0, 0, 0);
+    };
+
+    // same software pipeline as the forward kernel: staging registers -> other LDS buffer at the top of a step,
+    // the fetch of the chunk after next issued between the MFMA groups
+    auto k_step = [&](int buf, auto write_tag, auto fetch_tag) {
+        Frag f0, f1;
+        read_frag(buf, 0, f0);
+        if constexpr (decltype(write_tag)::value) store_lds(buf ^ 1);
+        read_frag(buf, 1, f1);
+        HN_PIN();
+        mfma16(f0);
+        HN_PIN();
+        read_frag(buf, 2, f0);
+        if constexpr (decltype(fetch_tag)::value) load_a();
+        HN_PIN();
+        mfma16(f1);
+        HN_PIN();
+        read_frag(buf, 3, f1);
+        if constexpr (decltype(fetch_tag)::value) load_b();
+        HN_PIN();
+        mfma16(f0);
+        HN_PIN();
+        mfma16(f1);
+        __syncthreads();
+    };
+
+    const int nch = c_end - c_begin;
+    if (nch > 0) {
+        load_a();
+        load_b();
+        store_lds(0);
+        if (nch > 1) {
+            load_a();
+            load_b();
+        }
+        __syncthreads();
+        int kc = 0;
+        for (; kc + 2 < nch; ++kc) k_step(kc & 1, std::true_type{}, std::true_type{});
+        if (kc + 1 < nch) {
+            k_step(kc & 1, std::true_type{}, std::false_type{});
+            ++kc;
+        }
+        k_step(kc & 1, std::false_type{}, std::false_type{});
     }
 
-    // D row = output channel, D column = (tap, ci): column on the lane -> 128-B runs of dW per store.
+    // D row = output channel, D column = (tap, ci): column on the lane -> 128-B runs of dW per store / atomic.
+    const bool full = (co0 + BM <= p.K) && (n0 + BN <= p.Kdim);
+    auto finish = [&](auto full_tag, auto atomic_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        constexpr bool ATOMIC = decltype(atomic_tag)::value;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + lr;
-        if (n >= p.Kdim) continue;
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + lr;
+            const bool nok = FULL || n < p.Kdim;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int rbase = co0 + (wm * TM + i) * 32 + 4 * lh;
+            for (int i = 0; i < TM; ++i) {
+                const int rbase = co0 + (wm * TM + i) * 32 + 4 * lh;
+                float* dst = p.dw + (size_t)rbase * p.Kdim + n;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = rbase + (r & 3) + 8 * (r >> 2);
-                if (co < p.K) {
-                    float* dst = p.dw + (size_t)co * p.Kdim + n;
-                    if (p.atomic) atomicAdd(dst, acc[i][j][r]);
-                    else *dst = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    if (FULL || (nok && rbase + ro < p.K)) {
+                        if constexpr (ATOMIC) atomicAdd(dst + (size_t)ro * p.Kdim, acc[i][j][r]);
+                        else dst[(size_t)ro * p.Kdim] = acc[i][j][r];
+                    }
                 }
             }
         }
+    };
+    if (p.atomic) {
+        if (full) finish(std::true_type{}, std::true_type{});
+        else finish(std::false_type{}, std::true_type{});
+    } else {
+        if (full) finish(std::true_type{}, std::false_type{});
+        else finish(std::false_type{}, std::false_type{});
     }
 }
 
-template <int TM, int TN, bool VEC>
+template <int TM, int TN, int MODE>
 int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int lds = 2 * BKP * (BM + BN) * (int)sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<TM, TN, MODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return HN_ELAUNCH;
+        configured = true;
+    }
     a.ntm = (a.K + BM - 1) / BM;
     a.ntn = (a.Kdim + BN - 1) / BN;
     const int tiles = a.ntm * a.ntn;
@@ -217,9 +376,15 @@ int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     if (a.atomic) {
         if (hipMemsetAsync(a.dw, 0, (size_t)a.K * a.Kdim * sizeof(float), stream) != hipSuccess) return HN_ELAUNCH;
     }
-    HN_LAUNCH((conv_wgrad_kernel<TM, TN, VEC>), dim3(tiles * split_k), dim3(256), lds, stream, a);
+    HN_LAUNCH((conv_wgrad_kernel<TM, TN, MODE>), dim3(tiles * split_k), dim3(256), lds, stream, a);
     HN_CHECK_LAUNCH();
     return HN_OK;
+}
+
+template <int MODE>
+int dispatch_wgrad(const WgradArgs& a, bool wide_m, bool wide_n, int split_k, hipStream_t s) {
+    if (wide_m) return wide_n ? launch_wgrad<2, 2, MODE>(a, split_k, s) : launch_wgrad<2, 1, MODE>(a, split_k, s);
+    return wide_n ? launch_wgrad<1, 2, MODE>(a, split_k, s) : launch_wgrad<1, 1, MODE>(a, split_k, s);
 }
 
 }  // namespace
@@ -238,15 +403,16 @@ extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const
     a.M = d->N * d->Hout * d->Wout;
     a.Kdim = d->KH * d->KW * d->Cin;
     a.ntm = a.ntn = a.chunks_per_split = a.atomic = 0;
+    a.x_bytes = (((long long)d->N * d->Hin * d->Win - 1) * d->ldx + d->Cin) * 4;
+    a.dy_bytes = (((long long)a.M - 1) * d->ldy + d->Cout) * 4;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool aligned = (d->ldx % 4 == 0) && (d->ldy % 4 == 0) && hn_aligned16(x) && hn_aligned16(dy);
     const bool wide_m = d->Cout > 64;
     if (aligned && d->Cout % 4 == 0 && d->Cin % 64 == 0) {
         const bool wide_n = d->Cin % 128 == 0;
-        if (wide_m) return wide_n ? launch_wgrad<2, 2, true>(a, split_k, s) : launch_wgrad<2, 1, true>(a, split_k, s);
-        return wide_n ? launch_wgrad<1, 2, true>(a, split_k, s) : launch_wgrad<1, 1, true>(a, split_k, s);
+        const bool buf_ok = a.x_bytes < 0xFFFF0000ll && a.dy_bytes + 64ll * d->ldy * 4 < 0xFFFF0000ll;
+        return buf_ok ? dispatch_wgrad<WG_VEC_BUF>(a, wide_m, wide_n, split_k, s)
+                      : dispatch_wgrad<WG_VEC>(a, wide_m, wide_n, split_k, s);
     }
-    const bool wide_n = a.Kdim > 64;
-    if (wide_m) return wide_n ? launch_wgrad<2, 2, false>(a, split_k, s) : launch_wgrad<2, 1, false>(a, split_k, s);
-    return wide_n ? launch_wgrad<1, 2, false>(a, split_k, s) : launch_wgrad<1, 1, false>(a, split_k, s);
+    return dispatch_wgrad<WG_SCALAR>(a, wide_m, a.Kdim > 64, split_k, s);
 }
