@@ -381,8 +381,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
                 d1 += __shfl_xor(d1, 32);
                 d2 += __shfl_xor(d2, 32);
                 if (lh == 0 && cok) {
-                    unsafeAtomicAdd(p.stats + col, d1);
-                    unsafeAtomicAdd(p.stats + p.K + col, d2);
+                    double* rep = p.stats + (size_t)(tile_m % HN_STAT_REPLICAS) * 2 * p.K;  // spread same-address atomics
+                    unsafeAtomicAdd(rep + col, d1);
+                    unsafeAtomicAdd(rep + p.K + col, d2);
                 }
             }
         }

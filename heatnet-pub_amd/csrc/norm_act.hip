@@ -59,11 +59,13 @@ RowLaunch plan_rows(int64_t npix, int C, std::initializer_list<const void*> ptrs
 template <int V>
 __device__ __forceinline__ void act_grad(const float (&dz)[V], const float (&z)[V], const float (&y)[V],
                                          const float (&sc)[V], const float (&sh)[V], int act, float slope,
-                                         float (&du)[V], float& dslope) {
+                                         bool zmask, float (&du)[V], float& dslope) {
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         if (act == HN_ACT_RELU) {
-            du[i] = z[i] > 0.f ? dz[i] : 0.f;
+            // mask from the saved output, or (no residual, z not kept) from u recomputed exactly as the forward did
+            const float m = zmask ? z[i] : y[i] * sc[i] + sh[i];
+            du[i] = m > 0.f ? dz[i] : 0.f;
         } else if (act == HN_ACT_PRELU || act == HN_ACT_LEAKY) {
             const float u = y[i] * sc[i] + sh[i];
             du[i] = u > 0.f ? dz[i] : dz[i] * slope;
@@ -124,19 +126,21 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
         ldv<V>(invstd + c, is);
     }
     const float slope = act == HN_ACT_PRELU ? *slope_p : leaky;
+    const bool zmask = act == HN_ACT_RELU && z != nullptr;
     if (live) {
+#pragma unroll 2
         for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix;
              pix += (int64_t)gridDim.y * blockDim.y) {
             float g[V], zz[V], yy[V], du[V];
             float ds = 0.f;
             ldv<V>(dz + pix * lddz + c, g);
             ldv<V>(y + pix * ldy + c, yy);
-            if (act == HN_ACT_RELU) ldv<V>(z + pix * ldz + c, zz);
+            if (zmask) ldv<V>(z + pix * ldz + c, zz);
             else {
 #pragma unroll
                 for (int i = 0; i < V; ++i) zz[i] = 0.f;
             }
-            act_grad<V>(g, zz, yy, sc, sh, act, slope, du, ds);
+            act_grad<V>(g, zz, yy, sc, sh, act, slope, zmask, du, ds);
             dslope += (double)ds;
 #pragma unroll
             for (int i = 0; i < V; ++i) {
@@ -157,6 +161,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
     }
     r3[ty * bx + tx] = dslope;
     __syncthreads();
+    double* rep = sums + (size_t)(blockIdx.y % HN_STAT_REPLICAS) * (2 * C + 1);
     if (ty == 0 && live) {
 #pragma unroll
         for (int i = 0; i < V; ++i) {
@@ -165,22 +170,32 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
                 a += r1[(k * bx + tx) * V + i];
                 b += r2[(k * bx + tx) * V + i];
             }
-            unsafeAtomicAdd(sums + c + i, a);
-            unsafeAtomicAdd(sums + C + c + i, b);
+            unsafeAtomicAdd(rep + c + i, a);
+            unsafeAtomicAdd(rep + C + c + i, b);
         }
     }
     if (act == HN_ACT_PRELU) {
         if (ty == 0 && tx == 0) {
             double a = 0.0;
             for (int k = 0; k < bx * by; ++k) a += r3[k];
-            unsafeAtomicAdd(sums + 2 * C, a);
+            unsafeAtomicAdd(rep + 2 * C, a);
         }
     }
 }
 
-__global__ void f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int n) {
+// out[i] = (float) sum over replicas of in[r][i], and the double workspace is zeroed again so that the next
+// reduction can accumulate into it
+__global__ void f64_to_f32_reset_kernel(double* __restrict__ in, float* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (float)in[i];
+    if (i < n) {
+        double a = 0.0;
+#pragma unroll
+        for (int r = 0; r < HN_STAT_REPLICAS; ++r) {
+            a += in[(size_t)r * n + i];
+            in[(size_t)r * n + i] = 0.0;
+        }
+        out[i] = (float)a;
+    }
 }
 
 template <int V>
@@ -189,8 +204,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
                                                               const float* __restrict__ y, int ldy,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, const double* __restrict__ sums,
-                                                              double inv_count, int training, float* __restrict__ dy, int lddy,
+                                                              const float* __restrict__ shift, const float* __restrict__ dparams,
+                                                              float inv_count, int training, float* __restrict__ dy, int lddy,
                                                               float* __restrict__ dres, int lddr, int64_t npix, int C, int act,
                                                               const float* slope_p, float leaky) {
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
@@ -203,22 +218,24 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
     ldv<V>(gamma + c, ga);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        m1[i] = training ? (float)(sums[c + i] * inv_count) : 0.f;
-        m2[i] = training ? (float)(sums[C + c + i] * inv_count) : 0.f;
+        m1[i] = training ? dparams[c + i] * inv_count : 0.f;
+        m2[i] = training ? dparams[C + c + i] * inv_count : 0.f;
         ga[i] *= is[i];
     }
     const float slope = act == HN_ACT_PRELU ? *slope_p : leaky;
+    const bool zmask = act == HN_ACT_RELU && z != nullptr;
     float unused = 0.f;
+#pragma unroll 2
     for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
         float g[V], zz[V], yy[V], du[V], o[V];
         ldv<V>(dz + pix * lddz + c, g);
         ldv<V>(y + pix * ldy + c, yy);
-        if (act == HN_ACT_RELU) ldv<V>(z + pix * ldz + c, zz);
+        if (zmask) ldv<V>(z + pix * ldz + c, zz);
         else {
 #pragma unroll
             for (int i = 0; i < V; ++i) zz[i] = 0.f;
         }
-        act_grad<V>(g, zz, yy, sc, sh, act, slope, du, unused);
+        act_grad<V>(g, zz, yy, sc, sh, act, slope, zmask, du, unused);
 #pragma unroll
         for (int i = 0; i < V; ++i) o[i] = ga[i] * (du[i] - m1[i] - (yy[i] - mu[i]) * is[i] * m2[i]);
         stv<V>(dy + pix * lddy + c, o);
@@ -226,14 +243,23 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
     }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, double inv_count, double unbias,
+__global__ void bn_finalize_kernel(double* __restrict__ stats, double inv_count, double unbias,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                    float* running_var, float momentum, float eps, float* __restrict__ mean,
                                    float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double m = stats[c] * inv_count;
-    double var = stats[C + c] * inv_count - m * m;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < HN_STAT_REPLICAS; ++r) {
+        s1 += stats[(size_t)r * 2 * C + c];
+        s2 += stats[(size_t)r * 2 * C + C + c];
+        // consumed: leave the accumulators zeroed for the next convolution epilogue that adds into them
+        stats[(size_t)r * 2 * C + c] = 0.0;
+        stats[(size_t)r * 2 * C + C + c] = 0.0;
+    }
+    const double m = s1 * inv_count;
+    double var = s2 * inv_count - m * m;
     if (var < 0.0) var = 0.0;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     const float mf = (float)m;
@@ -327,8 +353,9 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
                 a += red[(k * bx + tx) * V + i];
                 b += red[256 * 4 + (k * bx + tx) * V + i];
             }
-            unsafeAtomicAdd(out + c + i, a);
-            unsafeAtomicAdd(out + C + c + i, b);
+            double* rep = out + (size_t)(blockIdx.y % HN_STAT_REPLICAS) * 2 * C;
+            unsafeAtomicAdd(rep + c + i, a);
+            unsafeAtomicAdd(rep + C + c + i, b);
         }
     }
 }
@@ -390,7 +417,7 @@ bool bad_rows(int64_t npix, int C, std::initializer_list<int> lds) {
         else HN_LAUNCH((kern<1>), (plan).grid, (plan).block, 0, s, __VA_ARGS__);                \
     } while (0)
 
-extern "C" int hn_bn_finalize(const double* stats, int64_t count, const float* gamma, const float* beta,
+extern "C" int hn_bn_finalize(double* stats, int64_t count, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* mean,
                               float* invstd, float* scale, float* shift, int C, void* stream) {
     if (!stats || !gamma || !beta || !mean || !invstd || !scale || !shift || C <= 0 || count <= 0) return HN_EINVAL;
@@ -431,35 +458,35 @@ extern "C" int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, i
                                     int64_t npix, int C, int act, const float* slope, float leaky_slope, double* sums,
                                     float* dparams, void* stream) {
     if (!dz || !y || !mean || !invstd || !scale || !shift || !sums || !dparams || act < 0 || act > 3) return HN_EINVAL;
-    if ((act == HN_ACT_RELU && !z) || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
-    if (bad_rows(npix, C, {lddz, ldy}) || (act == HN_ACT_RELU && ldz < C)) return HN_EINVAL;
+    if (act == HN_ACT_PRELU && !slope) return HN_EINVAL;
+    if (bad_rows(npix, C, {lddz, ldy}) || (z && ldz < C)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(sums, 0, (size_t)(2 * C + 1) * sizeof(double), s) != hipSuccess) return HN_ELAUNCH;
-    const RowLaunch pl = plan_rows(npix, C, {dz, y, act == HN_ACT_RELU ? z : nullptr, mean, invstd, scale, shift},
-                                   {lddz, ldy, act == HN_ACT_RELU ? ldz : 4}, 1024);
+    const bool zmask = act == HN_ACT_RELU && z != nullptr;
+    const RowLaunch pl = plan_rows(npix, C, {dz, y, zmask ? z : nullptr, mean, invstd, scale, shift},
+                                   {lddz, ldy, zmask ? ldz : 4}, 2048);
     HN_LAUNCH_V(pl, bn_act_bwd_reduce_kernel, dz, lddz, z, ldz, y, ldy, mean, invstd, scale, shift, npix, C, act, slope,
                 leaky_slope, sums);
     HN_CHECK_LAUNCH();
-    HN_LAUNCH(f64_to_f32_kernel, dim3((2 * C + 1 + 255) / 256), dim3(256), 0, s, sums, dparams, 2 * C + 1);
+    HN_LAUNCH(f64_to_f32_reset_kernel, dim3((2 * C + 1 + 255) / 256), dim3(256), 0, s, sums, dparams, 2 * C + 1);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
 
 extern "C" int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                                    const float* mean, const float* invstd, const float* gamma, const float* scale,
-                                   const float* shift, const double* sums, int64_t count, int training, float* dy,
+                                   const float* shift, const float* dparams, int64_t count, int training, float* dy,
                                    int lddy, float* dres, int lddr, int64_t npix, int C, int act, const float* slope,
                                    float leaky_slope, void* stream) {
     if (!dz || !y || !mean || !invstd || !gamma || !scale || !shift || !dy || act < 0 || act > 3) return HN_EINVAL;
-    if ((training && (!sums || count <= 0)) || (act == HN_ACT_RELU && !z) || (act == HN_ACT_PRELU && !slope))
-        return HN_EINVAL;
-    if (bad_rows(npix, C, {lddz, ldy, lddy}) || (dres && lddr < C) || (act == HN_ACT_RELU && ldz < C)) return HN_EINVAL;
+    if ((training && (!dparams || count <= 0)) || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
+    if (bad_rows(npix, C, {lddz, ldy, lddy}) || (dres && lddr < C) || (z && ldz < C)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool zmask = act == HN_ACT_RELU && z != nullptr;
     const RowLaunch pl =
-        plan_rows(npix, C, {dz, y, dy, dres, act == HN_ACT_RELU ? z : nullptr, mean, invstd, gamma, scale, shift, sums},
-                  {lddz, ldy, lddy, dres ? lddr : 4, act == HN_ACT_RELU ? ldz : 4});
-    const double inv_count = training ? 1.0 / (double)count : 0.0;
-    HN_LAUNCH_V(pl, bn_act_bwd_apply_kernel, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, sums, inv_count,
+        plan_rows(npix, C, {dz, y, dy, dres, zmask ? z : nullptr, mean, invstd, gamma, scale, shift},
+                  {lddz, ldy, lddy, dres ? lddr : 4, zmask ? ldz : 4});
+    const float inv_count = training ? (float)(1.0 / (double)count) : 0.f;
+    HN_LAUNCH_V(pl, bn_act_bwd_apply_kernel, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, dparams, inv_count,
                 training, dy, lddy, dres, lddr, npix, C, act, slope, leaky_slope);
     HN_CHECK_LAUNCH();
     return HN_OK;
@@ -478,8 +505,7 @@ extern "C" int hn_channel_sum(const float* x, int ld, int64_t npix, int C, float
 extern "C" int hn_channel_stats(const float* x, int ld, int64_t npix, int C, double* stats, void* stream) {
     if (!x || !stats || bad_rows(npix, C, {ld})) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(stats, 0, (size_t)2 * C * sizeof(double), s) != hipSuccess) return HN_ELAUNCH;
-    const RowLaunch pl = plan_rows(npix, C, {x}, {ld}, 1024);
+    const RowLaunch pl = plan_rows(npix, C, {x}, {ld}, 2048);
     HN_LAUNCH_V(pl, channel_stats_kernel, x, ld, npix, C, stats);
     HN_CHECK_LAUNCH();
     return HN_OK;

@@ -60,14 +60,23 @@ class HnBatchNorm2d(nn.BatchNorm2d):
             self._pending_batches += 1  # host-side counter: no 1-element kernel per layer per step
         momentum = 0.1 if self.momentum is None else self.momentum
         return ops.bn_act(x, stats, self.weight, self.bias, self.running_mean, self.running_var, residual,
-                          prelu_weight, training, momentum, self.eps, act)
+                          prelu_weight, training, momentum, self.eps, act, ws=self.workspace(x.device))
+
+    _ws = None
+
+    def workspace(self, device):
+        """Per-layer double accumulators for batch statistics (forward) and the backward reductions."""
+        if self._ws is None or self._ws.device != device:
+            self._ws = ops.BnWorkspace(self.num_features, device)
+        return self._ws
 
 
 def conv_bn_act(x, conv, bn, act=ops.ACT_NONE, residual=None, prelu_weight=None):
     """conv -> BatchNorm (batch statistics from the conv epilogue) -> (+residual) -> activation."""
     s, p, d = conv.geometry()
     if bn.training:
-        y, stats = ops.conv2d(x, conv.weight, conv.bias, s, p, d, want_stats=True)
+        stats = bn.workspace(x.device).stats  # the conv epilogue adds into it, hn_bn_finalize re-zeroes it
+        y = ops.conv2d(x, conv.weight, conv.bias, s, p, d, want_stats=stats)
     else:
         y, stats = ops.conv2d(x, conv.weight, conv.bias, s, p, d), None
     return bn(y, residual=residual, act=act, stats=stats, prelu_weight=prelu_weight)

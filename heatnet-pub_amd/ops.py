@@ -14,6 +14,7 @@ from . import _lib
 from ._lib import HnConvDesc, check
 
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY = 0, 1, 2, 3
+STAT_REPLICAS = 16  # HN_STAT_REPLICAS in include/heatnet_hip.h
 LOSS_MSE, LOSS_BCE = 0, 1
 
 
@@ -141,7 +142,12 @@ class _Conv2d(torch.autograd.Function):
             raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (cin, cin_w))
         ho, wo = conv_out_size(h, kh, stride, pad, dil), conv_out_size(wd, kw, stride, pad, dil)
         y = new_nhwc(n, cout, ho, wo, x.device)
-        stats = torch.zeros(2 * cout, device=x.device, dtype=torch.float64) if want_stats else None
+        if want_stats is True:
+            stats = torch.zeros(STAT_REPLICAS * 2 * cout, device=x.device, dtype=torch.float64)
+        elif torch.is_tensor(want_stats):
+            stats = want_stats  # persistent per-layer accumulator: zero on entry, re-zeroed by hn_bn_finalize
+        else:
+            stats = None
         d = _desc(n, h, wd, cin, ldx, ho, wo, cout, cout, kh, kw, stride, pad, dil)
         with _ConvTimer("fwd", d):
             check(lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(stats), ctypes.byref(d), act, slope,
@@ -149,10 +155,10 @@ class _Conv2d(torch.autograd.Function):
         ctx.geom = (stride, pad, dil, act, slope)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
-        if want_stats:
+        if want_stats is True:
             ctx.mark_non_differentiable(stats)
             return y, stats
-        return y
+        return y  # a caller-owned accumulator is not returned (it is an input)
 
     @staticmethod
     def backward(ctx, dy, *unused):
@@ -191,7 +197,8 @@ class _Conv2d(torch.autograd.Function):
 
 
 def conv2d(x, w, b=None, stride=1, pad=0, dil=1, act=ACT_NONE, slope=0.0, want_stats=False):
-    return _Conv2d.apply(x, w, b, int(stride), int(pad), int(dil), int(act), float(slope), bool(want_stats))
+    """`want_stats`: False, True (fresh accumulator) or a zeroed float64 [STAT_REPLICAS*2*Cout] accumulator."""
+    return _Conv2d.apply(x, w, b, int(stride), int(pad), int(dil), int(act), float(slope), want_stats)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -204,7 +211,7 @@ class _BnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, stats, gamma, beta, running_mean, running_var, residual, prelu_w, training, momentum, eps,
-                act, leaky):
+                act, leaky, ws):
         lib = _lib.load()
         y, ldy = as_nhwc(y)
         n, c, h, w = y.shape
@@ -215,7 +222,8 @@ class _BnAct(torch.autograd.Function):
         mean, invstd, scale, shift = par[0:c], par[c:2 * c], par[2 * c:3 * c], par[3 * c:4 * c]
         if training:
             if stats is None:
-                stats = torch.empty(2 * c, device=dev, dtype=torch.float64)
+                stats = ws.stats if ws is not None else torch.zeros(STAT_REPLICAS * 2 * c, device=dev,
+                                                                    dtype=torch.float64)
                 check(lib.hn_channel_stats(_ptr(y), ldy, npix, c, _ptr(stats), s), "hn_channel_stats")
             check(lib.hn_bn_finalize(_ptr(stats), npix, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                      momentum, eps, _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift), c, s),
@@ -232,7 +240,9 @@ class _BnAct(torch.autograd.Function):
         check(lib.hn_bn_act_fwd(_ptr(y), ldy, _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(z), c, npix, c, act,
                                 _ptr(prelu_w), leaky, s), "hn_bn_act_fwd")
         ctx.cfg = (training, act, leaky, residual is not None)
-        ctx.save_for_backward(y, z if act == ACT_RELU else None, par, gamma, prelu_w)
+        ctx.ws = ws
+        # the ReLU mask is recomputed from y in backward unless a residual entered u (then z is kept)
+        ctx.save_for_backward(y, z if (act == ACT_RELU and residual is not None) else None, par, gamma, prelu_w)
         return z
 
     @staticmethod
@@ -247,7 +257,9 @@ class _BnAct(torch.autograd.Function):
         s = _stream()
         mean, invstd, scale, shift = par[0:c], par[c:2 * c], par[2 * c:3 * c], par[3 * c:4 * c]
         ldz = c
-        sums = torch.empty(2 * c + 1, device=y.device, dtype=torch.float64)   # double workspace
+        ws = ctx.ws
+        sums = ws.bwd if ws is not None else torch.zeros(STAT_REPLICAS * (2 * c + 1), device=y.device,
+                                                         dtype=torch.float64)
         dpar = torch.empty(2 * c + 1, device=y.device, dtype=torch.float32)   # dbeta | dgamma | dslope
         check(lib.hn_bn_act_bwd_reduce(_ptr(dz), lddz, _ptr(z), ldz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(scale),
                                        _ptr(shift), npix, c, act, _ptr(prelu_w), leaky, _ptr(sums), _ptr(dpar), s),
@@ -258,19 +270,28 @@ class _BnAct(torch.autograd.Function):
             if dy is None:
                 dy = new_nhwc(n, c, h, w, y.device)
             check(lib.hn_bn_act_bwd_apply(_ptr(dz), lddz, _ptr(z), ldz, _ptr(y), ldy, _ptr(mean), _ptr(invstd),
-                                          _ptr(gamma), _ptr(scale), _ptr(shift), _ptr(sums), npix, int(training),
+                                          _ptr(gamma), _ptr(scale), _ptr(shift), _ptr(dpar), npix, int(training),
                                           _ptr(dy), c, _ptr(dres), c, npix, c, act, _ptr(prelu_w), leaky, s),
                   "hn_bn_act_bwd_apply")
         dgamma = dpar[c:2 * c] if ctx.needs_input_grad[2] else None
         dbeta = dpar[0:c] if ctx.needs_input_grad[3] else None
         dprelu = dpar[2 * c:2 * c + 1] if (prelu_w is not None and ctx.needs_input_grad[7]) else None
-        return dy, None, dgamma, dbeta, None, None, dres, dprelu, None, None, None, None, None
+        return dy, None, dgamma, dbeta, None, None, dres, dprelu, None, None, None, None, None, None
+
+
+class BnWorkspace:
+    """Persistent per-layer double accumulators (zero between uses: the kernels that read them re-zero them)."""
+
+    def __init__(self, c, device):
+        self.device = device
+        buf = torch.zeros(STAT_REPLICAS * (4 * c + 1), device=device, dtype=torch.float64)
+        self.stats, self.bwd = buf[:STAT_REPLICAS * 2 * c], buf[STAT_REPLICAS * 2 * c:]
 
 
 def bn_act(y, stats, gamma, beta, running_mean, running_var, residual=None, prelu_weight=None, training=True,
-           momentum=0.1, eps=1e-5, act=ACT_NONE, leaky=0.0):
+           momentum=0.1, eps=1e-5, act=ACT_NONE, leaky=0.0, ws=None):
     return _BnAct.apply(y, stats, gamma, beta, running_mean, running_var, residual, prelu_weight, bool(training),
-                        float(momentum), float(eps), int(act), float(leaky))
+                        float(momentum), float(eps), int(act), float(leaky), ws)
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -41,6 +41,11 @@ extern "C" {
 #define HN_ACT_PRELU 2   /* one shared slope read from device memory (nn.PReLU())  */
 #define HN_ACT_LEAKY 3   /* constant slope (nn.LeakyReLU(0.2))                     */
 
+/* Per-channel double accumulators (batch statistics, BatchNorm backward sums) are kept in HN_STAT_REPLICAS
+ * interleaved copies so that concurrent workgroups do not serialise on one address; the kernels that consume an
+ * accumulator add the replicas up (and zero them again). */
+#define HN_STAT_REPLICAS 16
+
 #define HN_LOSS_MSE 0
 #define HN_LOSS_BCE 1
 
@@ -56,8 +61,8 @@ int hn_version(void);
 /* ---- convolution: nn.Conv2d in cm/models/extractors.py:71-77,111-146, cm/models/pspnet.py:13,18,32,57,
  *      cm/discriminator_model.py:40-44.  Implicit GEMM on v_mfma_f32_32x32x2_f32. ------------------------- */
 
-/* y = act(conv(x, w) + bias).  `bias` may be NULL.  If `stats` is non-NULL it must hold 2*Cout DOUBLES,
- * zeroed by the caller; the kernel adds per-channel sum and sum of squares of the PRE-activation output
+/* y = act(conv(x, w) + bias).  `bias` may be NULL.  If `stats` is non-NULL it must hold
+ * HN_STAT_REPLICAS*2*Cout DOUBLES, zero on entry; the kernel adds per-channel sum and sum of squares of the PRE-activation output
  * (the batch statistics nn.BatchNorm2d needs, cm/models/extractors.py:72,75,77).  Statistics are accumulated
  * in double (global_atomic_add_f64), as the reference's CPU BatchNorm does. */
 int hn_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, double* stats,
@@ -77,17 +82,18 @@ int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc
 /* out[c] = sum over npix pixels of x[p*ld + c]  (bias gradient).  `out` is overwritten. */
 int hn_channel_sum(const float* x, int ld, int64_t npix, int C, float* out, void* stream);
 
-/* stats = {sum[C], sumsq[C]} (doubles) over npix pixels (overwritten): batch statistics of a tensor that did
+/* stats[HN_STAT_REPLICAS][{sum[C], sumsq[C]}] (doubles, zero on entry) += over npix pixels: batch statistics of a tensor that did
  * not come out of hn_conv2d_fwd. */
 int hn_channel_stats(const float* x, int ld, int64_t npix, int C, double* stats, void* stream);
 
 /* ---- batch norm + activation (+ residual): nn.BatchNorm2d / ReLU / PReLU / `out += residual`,
  *      cm/models/extractors.py:84-100, cm/models/pspnet.py:31-35 ------------------------------------------ */
 
-/* From stats = {sum[C], sumsq[C]} over `count` values per channel: mean, invstd = 1/sqrt(var_biased+eps),
+/* From stats[HN_STAT_REPLICAS][{sum[C], sumsq[C]}] (doubles) over `count` values per channel: mean, invstd = 1/sqrt(var_biased+eps),
  * scale = gamma*invstd, shift = beta - mean*scale; running stats updated in place when non-NULL
- * (momentum 0.1 style, unbiased variance), exactly as nn.BatchNorm2d in training mode. */
-int hn_bn_finalize(const double* stats, int64_t count, const float* gamma, const float* beta,
+ * (momentum 0.1 style, unbiased variance), exactly as nn.BatchNorm2d in training mode.  `stats` is ZEROED after it
+ * has been read, so one persistent accumulator per layer needs no per-step fill. */
+int hn_bn_finalize(double* stats, int64_t count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps,
                    float* mean, float* invstd, float* scale, float* shift, int C, void* stream);
 
@@ -102,20 +108,22 @@ int hn_bn_act_fwd(const float* y, int ldy, const float* scale, const float* shif
                   const float* residual, int ldr, float* z, int ldz, int64_t npix, int C,
                   int act, const float* slope, float leaky_slope, void* stream);
 
-/* First backward pass.  du = dz * act'(u), u = y*scale+shift(+residual).  Writes the double workspace
- * sums = {sum du [C], sum du*xhat [C], dslope [1]} (overwritten; xhat = (y-mean)*invstd) and its fp32 copy
- * dparams = {dbeta [C], dgamma [C], dslope [1]}.
- * For HN_ACT_RELU the mask is taken from z > 0; for PRELU/LEAKY u is recomputed from y (residual must be NULL). */
+/* First backward pass.  du = dz * act'(u), u = y*scale+shift(+residual).  Accumulates into the double workspace
+ * sums[HN_STAT_REPLICAS][2C+1] (must be all zero on entry; it is zero again on return) and writes
+ * dparams = {dbeta [C], dgamma [C], dslope [1]} = {sum du, sum du*xhat, ...} in fp32 (xhat = (y-mean)*invstd).
+ * HN_ACT_RELU takes its mask from z > 0, or -- when z is NULL (allowed only if the forward had no residual) -- from
+ * u recomputed from y; PRELU/LEAKY always recompute u from y (residual must have been NULL). */
 int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                          const float* mean, const float* invstd, const float* scale, const float* shift,
                          int64_t npix, int C, int act, const float* slope, float leaky_slope,
                          double* sums, float* dparams, void* stream);
 
-/* Second backward pass: dy = gamma*invstd*(du - sum_du/count - xhat*sum_duxhat/count) when `training`,
- * dy = gamma*invstd*du otherwise; dres = du when dres != NULL (gradient of the residual input). */
+/* Second backward pass: dy = gamma*invstd*(du - dbeta/count - xhat*dgamma/count) when `training`,
+ * dy = gamma*invstd*du otherwise; dres = du when dres != NULL (gradient of the residual input).
+ * `dparams` is the fp32 output of hn_bn_act_bwd_reduce; `z` as there. */
 int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                         const float* mean, const float* invstd, const float* gamma, const float* scale,
-                        const float* shift, const double* sums, int64_t count, int training,
+                        const float* shift, const float* dparams, int64_t count, int training,
                         float* dy, int lddy, float* dres, int lddr, int64_t npix, int C,
                         int act, const float* slope, float leaky_slope, void* stream);
 

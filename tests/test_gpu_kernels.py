@@ -78,8 +78,9 @@ def test_conv2d_forward_backward(dev, case):
     tol = 3e-6 * np.sqrt(cin * k * k) + 2e-6
     close(y, yr, atol=tol * 4, what="y")
     npix = yr.shape[0] * yr.shape[2] * yr.shape[3]
-    close(stats[:cout], yr.sum((0, 2, 3)), atol=tol * 4 * np.sqrt(npix) + 1e-4, rtol=1e-5, what="stats.sum")
-    close(stats[cout:], (yr * yr).sum((0, 2, 3)), atol=1e-4, rtol=1e-4, what="stats.sumsq")
+    stats = stats.view(ops.STAT_REPLICAS, 2, cout).sum(0)  # replicas of {sum, sumsq}
+    close(stats[0], yr.sum((0, 2, 3)), atol=tol * 4 * np.sqrt(npix) + 1e-4, rtol=1e-5, what="stats.sum")
+    close(stats[1], (yr * yr).sum((0, 2, 3)), atol=1e-4, rtol=1e-4, what="stats.sumsq")
     y.backward(gy.to(dev))
     ktot = cout * k * k
     close(xd.grad, xr.grad, atol=3e-6 * np.sqrt(ktot) * 4 + 2e-6, what="dx")

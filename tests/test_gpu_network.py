@@ -98,7 +98,7 @@ def test_segnet_backward_matches_oracle(dev):
         hip_err.append(float((p.grad.detach().cpu().double() - t).norm() / t.norm()))
         cpu_err.append(float((grads["f32"][k] - t).norm() / t.norm()))
     hip_err, cpu_err = np.array(hip_err), np.array(cpu_err)
-    assert len(hip_err) > 250
+    assert len(hip_err) > 200
     assert np.median(hip_err) < 2 * np.median(cpu_err) + 1e-5, (np.median(hip_err), np.median(cpu_err))
     assert hip_err.max() < 3 * cpu_err.max() + 1e-5, (hip_err.max(), cpu_err.max())
 
