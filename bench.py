@@ -31,6 +31,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 H, W, BS = 320, 704, 8
+# conv FLOPs of one step in the REFERENCE's op graph (per image/pair x 8)
+REFERENCE_CONV_TFLOP = {"seg": 8 * 1.0738, "confmax_seg": 8 * 2.2532, "confmax_critic": 8 * 0.8484}
 
 
 def synthetic_batch(rank, dev, n=BS, h=H, w=W):
@@ -68,7 +70,7 @@ def make_step(workload, model, opt, batch, buckets):
                                          adv="MSE", grad_sync=buckets)
 
 
-def measure_conv_roofline(step_fn, steps):
+def measure_conv_roofline(step_fn, steps, workload):
     """Instrumented pass: HIP events (torch's current stream = the launch stream) around every conv-kernel launch."""
     from heatnet_amd import ops
     records = []
@@ -105,10 +107,17 @@ def measure_conv_roofline(step_fn, steps):
                   "ms_per_step": v[2] / steps, "avg_launch_us": 1e3 * v[2] / v[0], "tflops": v[1] / v[2] / 1e9}
               for k, v in per_kind.items()}
     achieved = flops / ms / 1e9 if ms > 0 else 0.0
+    ref_tflop = REFERENCE_CONV_TFLOP.get(workload)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
             "kernel": "conv_igemm_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32)",
-            "launches_per_step": launches // steps, "conv_tflop_per_step": round(flops / steps / 1e12, 3),
+            "launches_per_step": launches // steps,
+            # executed = 2*M*N*K of the launches actually made (the pyramid bottleneck is applied per level at the
+            # pooled resolution); reference = the same step in the reference's op graph
+            # (1073.8 GFLOP/image).  `achieved`/`frac` use the EXECUTED count.
+            "conv_tflop_per_step": round(flops / steps / 1e12, 3),
+            "reference_op_tflop_per_step": ref_tflop,
+            "achieved_vs_reference_op_count": round(ref_tflop * 1e3 / (ms / steps), 2) if ref_tflop else None,
             "conv_ms_per_step": round(ms / steps, 3), "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
             "by_kind": detail}
 
@@ -202,7 +211,7 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        roof = measure_conv_roofline(step, max(1, min(3, args.steps)))
+        roof = measure_conv_roofline(step, max(1, min(3, args.steps)), args.workload)
     if world > 1:
         dist.barrier()
     base = None

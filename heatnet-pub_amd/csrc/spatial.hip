@@ -152,6 +152,47 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restric
     }
 }
 
+// Large bins (pyramid pooling: up to the whole 40x88 map per output pixel): one block per output pixel and channel
+// slab, threadIdx.y strides over the bin's pixels, LDS reduction across threadIdx.y.
+template <int V>
+__global__ __launch_bounds__(256) void avgpool_fwd_bin_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                             int N, int H, int W, int C, int Ho, int Wo) {
+    __shared__ float red[256 * 4];
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const bool live = c < C;
+    const int pix = blockIdx.y;
+    const int j = pix % Wo, t = pix / Wo, i = t % Ho, n = t / Ho;
+    const int h0 = bin_start(i, H, Ho), h1 = bin_end(i, H, Ho), w0 = bin_start(j, W, Wo), w1 = bin_end(j, W, Wo);
+    const int bw = w1 - w0, cnt = (h1 - h0) * bw;
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    if (live) {
+        for (int k = threadIdx.y; k < cnt; k += blockDim.y) {
+            const int h = h0 + k / bw, w = w0 + k % bw;
+            float v[V];
+            ldv<V>(x + ((int64_t)(n * H + h) * W + w) * ldx + c, v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += v[e];
+        }
+    }
+    const int bx = blockDim.x, by = blockDim.y, tx = threadIdx.x, ty = threadIdx.y;
+#pragma unroll
+    for (int e = 0; e < V; ++e) red[(ty * bx + tx) * V + e] = acc[e];
+    __syncthreads();
+    if (ty == 0 && live) {
+        const float inv = 1.f / (float)cnt;
+        float o[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float a = 0.f;
+            for (int k = 0; k < by; ++k) a += red[(k * bx + tx) * V + e];
+            o[e] = a * inv;
+        }
+        stv<V>(y + (int64_t)pix * ldy + c, o);
+    }
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
                                                          int N, int H, int W, int C, int Ho, int Wo) {
@@ -266,6 +307,113 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     }
 }
 
+// Strong upsampling (pyramid priors 1x1..6x6 -> 40x88, critic maps x32): every input pixel gathers from hundreds of
+// outputs, so one block owns one input pixel (and channel slab) and threadIdx.y strides over the candidate window.
+template <int V>
+__global__ __launch_bounds__(256) void bilinear_bwd_pix_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx,
+                                                              int lddx, int N, int H, int W, int C, int Ho, int Wo, float sh,
+                                                              float sw) {
+    __shared__ float red[256 * 4];
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const bool live = c < C;
+    const int pix = blockIdx.y;
+    const int w = pix % W, t = pix / W, h = t % H, n = t / H;
+    int ho_lo = (int)floorf(((float)h - 0.5f) / sh - 0.5f) - 1, ho_hi = (int)ceilf(((float)h + 1.5f) / sh - 0.5f) + 1;
+    int wo_lo = (int)floorf(((float)w - 0.5f) / sw - 0.5f) - 1, wo_hi = (int)ceilf(((float)w + 1.5f) / sw - 0.5f) + 1;
+    ho_lo = max(ho_lo, 0); ho_hi = min(ho_hi, Ho - 1);
+    wo_lo = max(wo_lo, 0); wo_hi = min(wo_hi, Wo - 1);
+    if (h == 0) ho_lo = 0;
+    if (w == 0) wo_lo = 0;
+    const int bw = wo_hi - wo_lo + 1, cnt = (ho_hi - ho_lo + 1) * bw;
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+    if (live) {
+        for (int k = threadIdx.y; k < cnt; k += blockDim.y) {
+            const int ho = ho_lo + k / bw, wo = wo_lo + k % bw;
+            const float kw = bilinear_weight(ho, h, sh, H) * bilinear_weight(wo, w, sw, W);
+            if (kw == 0.f) continue;
+            float g[V];
+            ldv<V>(dy + ((int64_t)(n * Ho + ho) * Wo + wo) * lddy + c, g);
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i] += kw * g[i];
+        }
+    }
+    const int bx = blockDim.x, by = blockDim.y, tx = threadIdx.x, ty = threadIdx.y;
+#pragma unroll
+    for (int i = 0; i < V; ++i) red[(ty * bx + tx) * V + i] = acc[i];
+    __syncthreads();
+    if (ty == 0 && live) {
+        float o[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float a = 0.f;
+            for (int k = 0; k < by; ++k) a += red[(k * bx + tx) * V + i];
+            o[i] = a;
+        }
+        stv<V>(dx + (int64_t)pix * lddx + c, o);
+    }
+}
+
+// one block per pixel of the small tensor: bx walks channel pieces (<= 16 so that >= 16 threads share the window)
+RowLaunch plan_pixel_blocks(int64_t npix, int C, std::initializer_list<const void*> ptrs, std::initializer_list<int> lds) {
+    bool v4 = (C % 4) == 0;
+    for (const void* p : ptrs) v4 = v4 && (p == nullptr || hn_aligned16(p));
+    for (int ld : lds) v4 = v4 && (ld % 4 == 0);
+    RowLaunch r;
+    r.V = v4 ? 4 : 1;
+    const int pieces = C / r.V;
+    int bx = 1;
+    while (bx < pieces && bx < 16) bx <<= 1;
+    r.grid = dim3((pieces + bx - 1) / bx, (unsigned)npix);
+    r.block = dim3(bx, 256 / bx);
+    return r;
+}
+
+// out = act(main + sum_i bilinear_up(prior_i)): the merge step of the pyramid-pooling head once its 1x1 bottleneck
+// has been applied per pyramid level at the pooled resolution (a 1x1 convolution commutes with bilinear resampling).
+struct PyramidArgs {
+    const float* p[8];
+    int h[8], w[8], ld[8];
+    int count;
+};
+
+template <int V>
+__global__ __launch_bounds__(256) void pyramid_merge_kernel(const float* __restrict__ mainp, int ldm, PyramidArgs a,
+                                                           float* __restrict__ out, int ldo, int N, int H, int W, int C,
+                                                           int relu) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (c >= C) return;
+    const int64_t npix = (int64_t)N * H * W;
+    HN_PIX_LOOP(npix) {
+        const int wo = (int)(pix % W);
+        const int64_t t = pix / W;
+        const int ho = (int)(t % H), n = (int)(t / H);
+        float acc[V];
+        ldv<V>(mainp + pix * ldm + c, acc);
+        for (int k = 0; k < a.count; ++k) {
+            const int ph = a.h[k], pw = a.w[k], pl = a.ld[k];
+            int h0, h1, w0, w1;
+            float lh0, lh1, lw0, lw1;
+            bilinear_src(ho, (float)ph / (float)H, ph, h0, h1, lh0, lh1);
+            bilinear_src(wo, (float)pw / (float)W, pw, w0, w1, lw0, lw1);
+            const float* base = a.p[k] + (int64_t)n * ph * pw * pl + c;
+            float q0[V], q1[V], q2[V], q3[V];
+            ldv<V>(base + ((int64_t)h0 * pw + w0) * pl, q0);
+            ldv<V>(base + ((int64_t)h0 * pw + w1) * pl, q1);
+            ldv<V>(base + ((int64_t)h1 * pw + w0) * pl, q2);
+            ldv<V>(base + ((int64_t)h1 * pw + w1) * pl, q3);
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i] += lh0 * (lw0 * q0[i] + lw1 * q1[i]) + lh1 * (lw0 * q2[i] + lw1 * q3[i]);
+        }
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i] = acc[i] > 0.f ? acc[i] : 0.f;
+        }
+        stv<V>(out + pix * ldo + c, acc);
+    }
+}
+
 bool bad_geom(int N, int H, int W, int C, int Ho, int Wo, int lda, int ldb) {
     return N <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || lda < C || ldb < C;
 }
@@ -304,7 +452,14 @@ extern "C" int hn_adaptive_avgpool_fwd(const float* x, int ldx, float* y, int ld
                                        int Wo, void* stream) {
     if (!x || !y || bad_geom(N, H, W, C, Ho, Wo, ldx, ldy)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const RowLaunch pl = plan_rows((int64_t)N * Ho * Wo, C, {x, y}, {ldx, ldy});
+    const int64_t opix = (int64_t)N * Ho * Wo;
+    if ((int64_t)H * W >= 64 * (int64_t)Ho * Wo && opix <= 65535) {  // bins of >= 64 pixels: block per bin
+        const RowLaunch pb = plan_pixel_blocks(opix, C, {x, y}, {ldx, ldy});
+        HN_LAUNCH_V(pb, avgpool_fwd_bin_kernel, x, ldx, y, ldy, N, H, W, C, Ho, Wo);
+        HN_CHECK_LAUNCH();
+        return HN_OK;
+    }
+    const RowLaunch pl = plan_rows(opix, C, {x, y}, {ldx, ldy});
     HN_LAUNCH_V(pl, avgpool_fwd_kernel, x, ldx, y, ldy, N, H, W, C, Ho, Wo);
     HN_CHECK_LAUNCH();
     return HN_OK;
@@ -335,9 +490,40 @@ extern "C" int hn_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, i
                                int Wout, void* stream) {
     if (!dy || !dx || bad_geom(N, Hin, Win, C, Hout, Wout, lddx, lddy)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const RowLaunch pl = plan_rows((int64_t)N * Hin * Win, C, {dy, dx}, {lddy, lddx});
     const float sh = (float)Hin / (float)Hout, sw = (float)Win / (float)Wout;
+    const int64_t ipix = (int64_t)N * Hin * Win;
+    if ((int64_t)Hout * Wout >= 16 * (int64_t)Hin * Win && ipix <= 65535) {  // strong upsampling: block per input pixel
+        const RowLaunch pb = plan_pixel_blocks(ipix, C, {dy, dx}, {lddy, lddx});
+        HN_LAUNCH_V(pb, bilinear_bwd_pix_kernel, dy, lddy, dx, lddx, N, Hin, Win, C, Hout, Wout, sh, sw);
+        HN_CHECK_LAUNCH();
+        return HN_OK;
+    }
+    const RowLaunch pl = plan_rows(ipix, C, {dy, dx}, {lddy, lddx});
     HN_LAUNCH_V(pl, bilinear_bwd_kernel, dy, lddy, dx, lddx, N, Hin, Win, C, Hout, Wout, sh, sw);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_pyramid_merge_fwd(const float* mainp, int ldm, int n_priors, const float* const* priors, const int* hs,
+                                    const int* ws, const int* lds, float* out, int ldo, int N, int H, int W, int C, int relu,
+                                    void* stream) {
+    if (!mainp || !out || n_priors < 0 || n_priors > 8 || N <= 0 || H <= 0 || W <= 0 || C <= 0 || ldm < C || ldo < C)
+        return HN_EINVAL;
+    if (n_priors > 0 && (!priors || !hs || !ws || !lds)) return HN_EINVAL;
+    PyramidArgs a;
+    a.count = n_priors;
+    bool aligned = true;
+    for (int k = 0; k < 8; ++k) {
+        a.p[k] = k < n_priors ? priors[k] : nullptr;
+        a.h[k] = k < n_priors ? hs[k] : 1;
+        a.w[k] = k < n_priors ? ws[k] : 1;
+        a.ld[k] = k < n_priors ? lds[k] : 4;
+        if (k < n_priors && (!priors[k] || hs[k] <= 0 || ws[k] <= 0 || lds[k] < C)) return HN_EINVAL;
+        if (k < n_priors) aligned = aligned && hn_aligned16(priors[k]) && (lds[k] % 4 == 0);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const RowLaunch pl = plan_rows((int64_t)N * H * W, C, {mainp, out, aligned ? nullptr : (const void*)1}, {ldm, ldo});
+    HN_LAUNCH_V(pl, pyramid_merge_kernel, mainp, ldm, a, out, ldo, N, H, W, C, relu);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

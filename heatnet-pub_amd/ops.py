@@ -382,6 +382,51 @@ def bilinear(x, size):
     return _Bilinear.apply(x, int(size[0]), int(size[1]))
 
 
+class _PyramidMerge(torch.autograd.Function):
+    """relu(main + sum_i bilinear_up(prior_i)): see hn_pyramid_merge_fwd."""
+
+    @staticmethod
+    def forward(ctx, main, *priors):
+        lib = _lib.load()
+        main, ldm = as_nhwc(main)
+        n, c, h, w = main.shape
+        ps = [as_nhwc(p) for p in priors]
+        k = len(ps)
+        ptrs = (ctypes.c_void_p * k)(*[p.data_ptr() for p, _ in ps])
+        hs = (ctypes.c_int * k)(*[p.shape[2] for p, _ in ps])
+        ws = (ctypes.c_int * k)(*[p.shape[3] for p, _ in ps])
+        lds = (ctypes.c_int * k)(*[ld for _, ld in ps])
+        out = new_nhwc(n, c, h, w, main.device)
+        check(lib.hn_pyramid_merge_fwd(_ptr(main), ldm, k, ptrs, hs, ws, lds, _ptr(out), c, n, h, w, c, 1, _stream()),
+              "hn_pyramid_merge_fwd")
+        ctx.sizes = [(p.shape[2], p.shape[3]) for p, _ in ps]
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        (out,) = ctx.saved_tensors
+        dout, ldd = as_nhwc(dout)
+        n, c, h, w = out.shape
+        s = _stream()
+        du = new_nhwc(n, c, h, w, out.device)
+        check(lib.hn_act_bwd(_ptr(dout), ldd, _ptr(out), c, _ptr(du), c, n * h * w, c, ACT_RELU, 0.0, s), "hn_act_bwd")
+        grads = [du]
+        for i, (ph, pw) in enumerate(ctx.sizes):
+            if not ctx.needs_input_grad[1 + i]:
+                grads.append(None)
+                continue
+            dp = new_nhwc(n, c, ph, pw, out.device)
+            check(lib.hn_bilinear_bwd(_ptr(du), c, _ptr(dp), c, n, ph, pw, c, h, w, s), "hn_bilinear_bwd")
+            grads.append(dp)
+        return tuple(grads)
+
+
+def pyramid_merge(main, priors):
+    return _PyramidMerge.apply(main, *priors)
+
+
 class _ScaleNC(torch.autograd.Function):
     """x * mask[n, c] -- Dropout2d with a pre-drawn keep/(1-p) mask."""
 

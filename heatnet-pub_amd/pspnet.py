@@ -25,10 +25,21 @@ class PSPModule(nn.Module):
         return nn.Sequential(HnAdaptiveAvgPool2d((size, size)), HnConv2d(features, features, kernel_size=1, bias=False))
 
     def forward(self, feats):
-        hw = (feats.size(2), feats.size(3))
-        priors = [ops.bilinear(stage[1](stage[0](feats)), hw) for stage in self.stages]
-        bottle = ops.concat(priors + [feats])
-        return self.bottleneck(bottle, act=ops.ACT_RELU)  # ReLU fused in the conv epilogue
+        """relu(bottleneck(cat([up(stage_i(feats))..., feats]))) without building the 5*C-channel concatenation.
+
+        A 1x1 convolution commutes with bilinear resampling, so the bottleneck's weight columns that belong to
+        pyramid level i are applied to the pooled s x s map BEFORE it is upsampled; one fused kernel then adds the
+        four upsampled C_out-channel maps to the full-resolution term and applies the ReLU.  Same parameters, same
+        function, 1/5 of the bottleneck's multiply-adds at full resolution."""
+        w = self.bottleneck.weight
+        f = feats.size(1)
+        levels = []
+        for i, stage in enumerate(self.stages):
+            q = stage[1](stage[0](feats))                       # pool -> 1x1 conv (C -> C) at s x s
+            levels.append(ops.conv2d(q, w[:, i * f:(i + 1) * f]))  # this level's slice of the bottleneck, still s x s
+        k = len(self.stages)
+        main = ops.conv2d(feats, w[:, k * f:(k + 1) * f], self.bottleneck.bias)
+        return ops.pyramid_merge(main, levels)
 
 
 class PSPUpsample(nn.Module):

@@ -160,6 +160,14 @@ int hn_adaptive_avgpool_bwd(const float* dy, int lddy, float* dx, int lddx, int 
 int hn_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int Hin, int Win, int C, int Hout, int Wout, void* stream);
 int hn_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int Hin, int Win, int C, int Hout, int Wout, void* stream);
 
+/* out = relu?(main + sum_i bilinear_up(prior_i -> H x W)), up to 8 priors of sizes hs[i] x ws[i] with pixel strides
+ * lds[i] (host arrays, read at call time).  The merge step of the pyramid-pooling head (cm/models/pspnet.py:21-25) after
+ * the 1x1 bottleneck has been applied per pyramid level at the pooled resolution: a 1x1 convolution commutes with
+ * bilinear resampling, so the 5*2048-channel concatenation is never built. */
+int hn_pyramid_merge_fwd(const float* main, int ldm, int n_priors, const float* const* priors, const int* hs,
+                         const int* ws, const int* lds, float* out, int ldo, int N, int H, int W, int C, int relu,
+                         void* stream);
+
 /* ---- losses ------------------------------------------------------------------------------------------ */
 
 /* nn.CrossEntropyLoss (mean over non-ignored pixels), cm/train_trgb_segnet_conf.py:244,452 and
