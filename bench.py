@@ -174,11 +174,18 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
+    # rehearsal knobs for a 1-GPU box (never set by the driver): every rank on one device, gloo instead of RCCL
+    if os.environ.get("HN_BENCH_SHARE_GPU"):
+        local = 0
+    backend = os.environ.get("HN_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from heatnet_amd import ddp
     model = build(args.workload, dev)
