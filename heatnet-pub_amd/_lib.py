@@ -24,10 +24,10 @@ DP = ctypes.POINTER(HnConvDesc)
 
 # name -> argtypes, exactly the prototypes of include/heatnet_hip.h
 SIGNATURES = {
-    "hn_conv2d_fwd": [P, P, P, P, P, DP, c_int, c_float, P],
+    "hn_conv2d_fwd": [P, P, P, P, P, DP, c_int, c_float, c_int, P],
     "hn_weight_flip_transpose": [P, P, c_int, c_int, c_int, c_int, P],
-    "hn_conv2d_dgrad": [P, P, P, DP, P],
-    "hn_conv2d_wgrad": [P, P, P, DP, c_int, P],
+    "hn_conv2d_dgrad": [P, P, P, DP, c_int, P],
+    "hn_conv2d_wgrad": [P, P, P, DP, c_int, c_int, P],
     "hn_channel_sum": [P, c_int, c_i64, c_int, P, P],
     "hn_channel_stats": [P, c_int, c_i64, c_int, P, P],
     "hn_bn_finalize": [P, c_i64, P, P, P, P, c_float, c_float, P, P, P, P, c_int, P],

@@ -27,14 +27,16 @@
 
 namespace {
 
-#ifndef HN_BK
-#define HN_BK 32
-#endif
-constexpr int BK = HN_BK;      // reduction indices per K step
-constexpr int LDK = BK + 4;    // LDS row stride in floats: 16-B aligned rows, conflict-free ds_read_b128
-constexpr int PR = BK / 4;     // 16-B pieces per staged row
-constexpr int VROWS = 256 / PR;  // rows staged by one pass of the 256 threads (vector path)
-constexpr int SROWS = 256 / BK;  // same, scalar path
+// K step (reduction indices per LDS stage): 32 -> 76 KB of LDS per 128x128 workgroup, 2 workgroups per CU;
+// 16 -> 43 KB, 3 workgroups per CU (finer-grained tail when the grid is a small non-multiple of the CU count).
+template <int BK_>
+struct KStep {
+    static constexpr int BK = BK_;
+    static constexpr int LDK = BK_ + 4;      // LDS row stride in floats: 16-B aligned rows, conflict-free ds_read_b128
+    static constexpr int PR = BK_ / 4;       // 16-B pieces per staged row
+    static constexpr int VROWS = 256 / PR;   // rows staged by one pass of the 256 threads (vector path)
+    static constexpr int SROWS = 256 / BK_;  // same, scalar path
+};
 
 struct ConvArgs {
     const float* x;
@@ -61,8 +63,9 @@ __device__ __forceinline__ f32x4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsi
 
 // STRIDED = the gathered tensor is "dilated" by in_dil > 1 (data gradient of a strided convolution): taps must
 // land on multiples of in_dil.  Kept out of the common instantiation because it costs integer divisions per tap.
-template <int TM, int TN, int MODE>
+template <int TM, int TN, int MODE, int BK>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
+    constexpr int LDK = KStep<BK>::LDK, PR = KStep<BK>::PR, VROWS = KStep<BK>::VROWS, SROWS = KStep<BK>::SROWS;
     constexpr bool VEC = MODE >= MODE_VEC;
     constexpr bool STRIDED = MODE == MODE_SCALAR_STRIDED || MODE == MODE_VEC_STRIDED;
     constexpr bool BUF = MODE == MODE_VEC_BUF;
@@ -392,13 +395,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     else finish(std::false_type{});
 }
 
-template <int TM, int TN, int MODE>
+template <int TM, int TN, int MODE, int BK>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int lds = (2 * (BM + BN) * LDK + BM * 4) * (int)sizeof(float);
+    constexpr int lds = (2 * (BM + BN) * KStep<BK>::LDK + BM * 4) * (int)sizeof(float);
     static bool configured = false;  // raising the dynamic-LDS cap is idempotent; the flag only saves calls
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<TM, TN, MODE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<TM, TN, MODE, BK>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return HN_ELAUNCH;
         configured = true;
@@ -406,31 +409,41 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     ConvArgs p = a;
     p.ntm = (a.M + BM - 1) / BM;
     p.ntn = (a.K + BN - 1) / BN;
-    HN_LAUNCH((conv_igemm_kernel<TM, TN, MODE>), dim3(p.ntm * p.ntn), dim3(256), lds, stream, p);
+    HN_LAUNCH((conv_igemm_kernel<TM, TN, MODE, BK>), dim3(p.ntm * p.ntn), dim3(256), lds, stream, p);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
 
-template <int MODE>
+template <int MODE, int BK>
 int dispatch_tile(const ConvArgs& a, bool tall, bool wide, hipStream_t stream) {
-    if (tall) return wide ? launch_conv<2, 2, MODE>(a, stream) : launch_conv<2, 1, MODE>(a, stream);
-    return wide ? launch_conv<1, 2, MODE>(a, stream) : launch_conv<1, 1, MODE>(a, stream);
+    if (tall) return wide ? launch_conv<2, 2, MODE, BK>(a, stream) : launch_conv<2, 1, MODE, BK>(a, stream);
+    return wide ? launch_conv<1, 2, MODE, BK>(a, stream) : launch_conv<1, 1, MODE, BK>(a, stream);
 }
 
-int dispatch_conv(const ConvArgs& a, hipStream_t stream) {
-    const bool vec = (a.C % BK == 0) && (a.ldx % 4 == 0) && hn_aligned16(a.x) && hn_aligned16(a.w);
-    const bool wide = a.K > 64;
+// variant: 0 = heuristics; otherwise (bk_sel) + 4 * (tm_sel) + 16 * (tn_sel) with bk_sel 1 -> K step 32, 2 -> 16 and
+// tm_sel / tn_sel 1 -> 64-wide, 2 -> 128-wide tile side (0 keeps the heuristic for that field).  All variants give
+// bitwise identical results: the per-element accumulation order does not depend on the tiling.
+int dispatch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
+    if (variant < 0 || variant >= 48) return HN_EINVAL;
+    const int bk_sel = variant & 3, tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3;
+    if (bk_sel == 3 || tm_sel == 3 || tn_sel == 3) return HN_EINVAL;
+    const bool vec = (a.C % 32 == 0) && (a.ldx % 4 == 0) && hn_aligned16(a.x) && hn_aligned16(a.w);
+    bool wide = a.K > 64;
+    if (tn_sel) wide = tn_sel == 2;
     const long blocks128 = (long)((a.M + 127) / 128) * ((a.K + (wide ? 127 : 63)) / (wide ? 128 : 64));
-    const bool tall = blocks128 >= 256;  // enough 128-row tiles to cover the chip; else halve the tile
+    bool tall = blocks128 >= 256;  // enough 128-row tiles to cover the chip; else halve the tile
+    if (tm_sel) tall = tm_sel == 2;
     const bool strided = a.in_dil > 1;
+    const bool bk16 = bk_sel == 2;
     // buffer path: offsets are 32-bit relative to the first image a tile touches (a tile may reach into the next
     // image) and to the tile's first weight row
     const long long image_bytes = (long long)a.H * a.W * a.ldx * 4;
     const bool buf_ok = 3 * image_bytes < (1ll << 31) && 128ll * a.Kdim * 4 < (1ll << 31) &&
                         (long long)a.H * a.W >= 128;
-    if (vec && !strided && buf_ok) return dispatch_tile<MODE_VEC_BUF>(a, tall, wide, stream);
-    if (vec) return strided ? dispatch_tile<MODE_VEC_STRIDED>(a, tall, wide, stream) : dispatch_tile<MODE_VEC>(a, tall, wide, stream);
-    return strided ? dispatch_tile<MODE_SCALAR_STRIDED>(a, tall, wide, stream) : dispatch_tile<MODE_SCALAR>(a, tall, wide, stream);
+    if (vec && !strided && buf_ok)
+        return bk16 ? dispatch_tile<MODE_VEC_BUF, 16>(a, tall, wide, stream) : dispatch_tile<MODE_VEC_BUF, 32>(a, tall, wide, stream);
+    if (vec) return strided ? dispatch_tile<MODE_VEC_STRIDED, 32>(a, tall, wide, stream) : dispatch_tile<MODE_VEC, 32>(a, tall, wide, stream);
+    return strided ? dispatch_tile<MODE_SCALAR_STRIDED, 32>(a, tall, wide, stream) : dispatch_tile<MODE_SCALAR, 32>(a, tall, wide, stream);
 }
 
 int check_desc(const HnConvDesc* d) {
@@ -468,7 +481,7 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_kernel(const float*
 }  // namespace
 
 extern "C" int hn_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, double* stats,
-                             const HnConvDesc* d, int act, float slope, void* stream) {
+                             const HnConvDesc* d, int act, float slope, int variant, void* stream) {
     if (x == nullptr || w == nullptr || y == nullptr) return HN_EINVAL;
     if (act < HN_ACT_NONE || act > HN_ACT_LEAKY) return HN_EINVAL;
     const int rc = check_desc(d);
@@ -483,10 +496,11 @@ extern "C" int hn_conv2d_fwd(const float* x, const float* w, const float* bias, 
     a.ntm = a.ntn = 0;
     a.act = act; a.slope = slope;
     a.x_bytes = (((long long)d->N * d->Hin * d->Win - 1) * d->ldx + d->Cin) * 4;
-    return dispatch_conv(a, static_cast<hipStream_t>(stream));
+    return dispatch_conv(a, variant, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, const HnConvDesc* d, void* stream) {
+extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, const HnConvDesc* d, int variant,
+                               void* stream) {
     if (dy == nullptr || wt == nullptr || dx == nullptr) return HN_EINVAL;
     const int rc = check_desc(d);
     if (rc != HN_OK) return rc;
@@ -502,7 +516,7 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, cons
     a.ntm = a.ntn = 0;
     a.act = HN_ACT_NONE; a.slope = 0.f;
     a.x_bytes = (((long long)d->N * d->Hout * d->Wout - 1) * d->ldy + d->Cout) * 4;
-    return dispatch_conv(a, static_cast<hipStream_t>(stream));
+    return dispatch_conv(a, variant, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int hn_weight_flip_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream) {

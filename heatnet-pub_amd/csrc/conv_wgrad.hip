@@ -363,8 +363,13 @@ int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     const int tiles = a.ntm * a.ntn;
     const int total_chunks = (a.M + BKP - 1) / BKP;
     if (split_k <= 0) {
-        // aim at ~3 blocks per CU, keep at least 8 reduction steps per split
+        // aim at ~3 blocks per CU, keep at least 8 reduction steps per split; -2 / -3 / -4 ask for half / twice / four
+        // times the heuristic (autotuning)
+        const int code = split_k;
         split_k = (768 + tiles - 1) / tiles;
+        if (code == -2) split_k = (split_k + 1) / 2;
+        if (code == -3) split_k *= 2;
+        if (code == -4) split_k *= 4;
         const int cap = (total_chunks + 7) / 8;
         if (split_k > cap) split_k = cap;
         if (split_k < 1) split_k = 1;
@@ -389,12 +394,15 @@ int dispatch_wgrad(const WgradArgs& a, bool wide_m, bool wide_n, int split_k, hi
 
 }  // namespace
 
-extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k,
+extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant,
                                void* stream) {
     if (x == nullptr || dy == nullptr || dw == nullptr || d == nullptr) return HN_EINVAL;
     if (d->N <= 0 || d->Hin <= 0 || d->Win <= 0 || d->Cin <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0 ||
         d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->dil <= 0 || d->pad < 0 || d->ldx < d->Cin || d->ldy < d->Cout)
         return HN_EINVAL;
+    if (variant < 0 || variant >= 48) return HN_EINVAL;
+    const int tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3;  // same encoding as hn_conv2d_fwd (K step unused)
+    if (tm_sel == 3 || tn_sel == 3) return HN_EINVAL;
     WgradArgs a;
     a.x = x; a.dy = dy; a.dw = dw;
     a.H = d->Hin; a.W = d->Win; a.C = d->Cin; a.ldx = d->ldx;
@@ -407,12 +415,16 @@ extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const
     a.dy_bytes = (((long long)a.M - 1) * d->ldy + d->Cout) * 4;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool aligned = (d->ldx % 4 == 0) && (d->ldy % 4 == 0) && hn_aligned16(x) && hn_aligned16(dy);
-    const bool wide_m = d->Cout > 64;
+    bool wide_m = d->Cout > 64;
+    if (tm_sel) wide_m = tm_sel == 2;
     if (aligned && d->Cout % 4 == 0 && d->Cin % 64 == 0) {
-        const bool wide_n = d->Cin % 128 == 0;
+        bool wide_n = d->Cin % 128 == 0;
+        if (tn_sel == 1) wide_n = false;  // a 128-wide column tile needs Cin % 128 == 0; 64 is always allowed here
         const bool buf_ok = a.x_bytes < 0xFFFF0000ll && a.dy_bytes + 64ll * d->ldy * 4 < 0xFFFF0000ll;
         return buf_ok ? dispatch_wgrad<WG_VEC_BUF>(a, wide_m, wide_n, split_k, s)
                       : dispatch_wgrad<WG_VEC>(a, wide_m, wide_n, split_k, s);
     }
-    return dispatch_wgrad<WG_SCALAR>(a, wide_m, a.Kdim > 64, split_k, s);
+    bool wide_n = a.Kdim > 64;
+    if (tn_sel) wide_n = tn_sel == 2;
+    return dispatch_wgrad<WG_SCALAR>(a, wide_m, wide_n, split_k, s);
 }

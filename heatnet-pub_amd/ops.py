@@ -7,6 +7,7 @@ reference produces) but are physically NHWC: a 4-D tensor here has stride(1) == 
 allocation, autograd bookkeeping and streams only -- no arithmetic of the hot path runs in ATen.
 """
 import ctypes
+import os
 
 import torch
 
@@ -95,6 +96,52 @@ def _desc(n, h, w, cin, ldx, ho, wo, cout, ldy, kh, kw, stride, pad, dil):
     return HnConvDesc(n, h, w, cin, ldx, ho, wo, cout, ldy, kh, kw, stride, pad, dil)
 
 
+# ---- per-shape kernel-variant selection ---------------------------------------------------------------------------
+# hn_conv2d_* take a `variant` (tile sides, K step) whose results are bitwise identical; which one is fastest depends
+# on how the grid divides over the 256 CUs.  On first use of a geometry every candidate is timed once with HIP events
+# and the winner is cached.  HEATNET_AUTOTUNE=0 keeps the library's built-in heuristics.
+AUTOTUNE = os.environ.get("HEATNET_AUTOTUNE", "1") != "0"
+_variant_cache = {}
+
+
+def _variant(bk=0, tm=0, tn=0):
+    return bk + 4 * tm + 16 * tn
+
+
+def _pick(kind, d, candidates, launch):
+    if not AUTOTUNE:
+        return candidates[0]
+    key = (kind,) + tuple(getattr(d, f) for f, _ in HnConvDesc._fields_)
+    hit = _variant_cache.get(key)
+    if hit is not None:
+        return hit
+    best, best_t = candidates[0], float("inf")
+    for cand in candidates:
+        launch(cand)  # warm-up (first launch of an instantiation also sets its LDS attribute)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch(cand)
+        launch(cand)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if t < best_t:
+            best, best_t = cand, t
+    _variant_cache[key] = best
+    return best
+
+
+def _igemm_candidates(cout):
+    tiles = [(0, 0), (1, 2), (2, 1)] if cout > 64 else [(0, 0), (1, 1)]
+    return [_variant(bk, tm, tn) for tm, tn in tiles for bk in (1, 2)]
+
+
+def _wgrad_candidates(cout, cin):
+    tms = (0, 1) if cout > 64 else (0,)
+    tns = (0, 1) if cin % 128 == 0 else (0,)
+    return [(split, _variant(0, tm, tn)) for tm in tms for tn in tns for split in (0, -2, -3)]
+
+
 _conv_prof = None  # bench.py: list receiving (kind, algorithmic flops, start event, end event) per conv launch
 
 
@@ -149,9 +196,12 @@ class _Conv2d(torch.autograd.Function):
         else:
             stats = None
         d = _desc(n, h, wd, cin, ldx, ho, wo, cout, cout, kh, kw, stride, pad, dil)
+        s = _stream()
+        var = _pick("fwd", d, _igemm_candidates(cout), lambda v: check(
+            lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), None, ctypes.byref(d), act, slope, v, s), "hn_conv2d_fwd"))
         with _ConvTimer("fwd", d):
-            check(lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(stats), ctypes.byref(d), act, slope,
-                                    _stream()), "hn_conv2d_fwd")
+            check(lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(stats), ctypes.byref(d), act, slope, var, s),
+                  "hn_conv2d_fwd")
         ctx.geom = (stride, pad, dil, act, slope)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
@@ -184,12 +234,17 @@ class _Conv2d(torch.autograd.Function):
             check(lib.hn_weight_flip_transpose(_ptr(w), _ptr(wt), cout, kh, kw, cin, s), "hn_weight_flip_transpose")
             dx = new_nhwc(n, cin, h, wd, x.device)
             dd = _desc(n, h, wd, cin, cin, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
+            var = _pick("dgrad", dd, _igemm_candidates(cin), lambda v: check(
+                lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(dx), ctypes.byref(dd), v, s), "hn_conv2d_dgrad"))
             with _ConvTimer("dgrad", dd):
-                check(lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(dx), ctypes.byref(dd), s), "hn_conv2d_dgrad")
+                check(lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(dx), ctypes.byref(dd), var, s), "hn_conv2d_dgrad")
         if ctx.needs_input_grad[1]:
             dw = torch.empty((cout, kh, kw, cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
+            split, var = _pick("wgrad", d, _wgrad_candidates(cout, cin), lambda sv: check(
+                lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), sv[0], sv[1], s), "hn_conv2d_wgrad"))
             with _ConvTimer("wgrad", d):
-                check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), 0, s), "hn_conv2d_wgrad")
+                check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), split, var, s),
+                      "hn_conv2d_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(cout, device=x.device, dtype=torch.float32)
             check(lib.hn_channel_sum(_ptr(dy), lddy, npix, cout, _ptr(db), s), "hn_channel_sum")

@@ -61,12 +61,16 @@ int hn_version(void);
 /* ---- convolution: nn.Conv2d in cm/models/extractors.py:71-77,111-146, cm/models/pspnet.py:13,18,32,57,
  *      cm/discriminator_model.py:40-44.  Implicit GEMM on v_mfma_f32_32x32x2_f32. ------------------------- */
 
-/* y = act(conv(x, w) + bias).  `bias` may be NULL.  If `stats` is non-NULL it must hold
+/* `variant` selects the kernel tiling: 0 = built-in heuristics, else bk + 4*tm + 16*tn with bk 1/2 = K step 32/16
+ * (2 or 3 resident workgroups per CU) and tm/tn 1/2 = 64/128-row/-column block tile (0 = heuristic for that field).
+ * Results are bitwise identical across variants; callers may time them per shape (heatnet-pub_amd/ops.py does).
+ *
+ * y = act(conv(x, w) + bias).  `bias` may be NULL.  If `stats` is non-NULL it must hold
  * HN_STAT_REPLICAS*2*Cout DOUBLES, zero on entry; the kernel adds per-channel sum and sum of squares of the PRE-activation output
  * (the batch statistics nn.BatchNorm2d needs, cm/models/extractors.py:72,75,77).  Statistics are accumulated
  * in double (global_atomic_add_f64), as the reference's CPU BatchNorm does. */
 int hn_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, double* stats,
-                  const HnConvDesc* d, int act, float slope, void* stream);
+                  const HnConvDesc* d, int act, float slope, int variant, void* stream);
 
 /* wt[Cin][KH][KW][Cout] = w[Cout][KH-1-kh][KW-1-kw][Cin]: operand of hn_conv2d_dgrad. */
 int hn_weight_flip_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
@@ -74,10 +78,13 @@ int hn_weight_flip_transpose(const float* w, float* wt, int Cout, int KH, int KW
 /* dx = conv_transpose(dy, w) for the forward geometry `d` (dy is N x Hout x Wout x Cout with pixel stride
  * d->ldy, dx is N x Hin x Win x Cin with pixel stride d->ldx); `wt` from hn_weight_flip_transpose.
  * Overwrites dx. */
-int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, const HnConvDesc* d, void* stream);
+int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, const HnConvDesc* d, int variant, void* stream);
 
-/* dw[Cout][KH][KW][Cin] = sum over pixels of dy (x) x.  Overwrites dw.  split_k <= 0 picks one. */
-int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, void* stream);
+/* dw[Cout][KH][KW][Cin] = sum over pixels of dy (x) x.  Overwrites dw.  split_k > 0: that many reduction splits;
+ * 0 / -1: heuristic; -2 / -3 / -4: half / twice / four times the heuristic.  `variant`: tile selection, encoded as for
+ * hn_conv2d_fwd (K step field ignored). */
+int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant,
+                    void* stream);
 
 /* out[c] = sum over npix pixels of x[p*ld + c]  (bias gradient).  `out` is overwritten. */
 int hn_channel_sum(const float* x, int ld, int64_t npix, int C, float* out, void* stream);

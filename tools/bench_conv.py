@@ -17,6 +17,10 @@ DEFAULT = ["8,40,88,10240,1024,1,1,1", "8,40,88,1024,2048,1,1,1", "8,40,88,1024,
            "8,80,176,64,64,3,1,1", "8,320,704,64,64,3,1,1", "8,40,88,256,256,3,1,2"]
 
 
+VAR = int(os.environ.get("VARIANT", "0"))
+SPLIT = int(os.environ.get("SPLIT", "0"))
+
+
 def timeit(fn, reps=6, rounds=6):
     """Best of `rounds` (each the mean of `reps` back-to-back launches): robust against clock / tenancy noise."""
     for _ in range(3):
@@ -58,11 +62,11 @@ def main():
         flops = 2.0 * n * ho * wo * cout * k * k * cin
         res = {}
         if "fwd" in kinds:
-            res["fwd"] = timeit(lambda: _lib.check(lib.hn_conv2d_fwd(P(x), P(wt), None, P(y), None, ctypes.byref(d), 0, 0.0, s), "fwd"))
+            res["fwd"] = timeit(lambda: _lib.check(lib.hn_conv2d_fwd(P(x), P(wt), None, P(y), None, ctypes.byref(d), 0, 0.0, VAR, s), "fwd"))
         if "dgrad" in kinds:
-            res["dgrad"] = timeit(lambda: _lib.check(lib.hn_conv2d_dgrad(P(dy), P(wflip), P(dx), ctypes.byref(d), s), "dgrad"))
+            res["dgrad"] = timeit(lambda: _lib.check(lib.hn_conv2d_dgrad(P(dy), P(wflip), P(dx), ctypes.byref(d), VAR, s), "dgrad"))
         if "wgrad" in kinds:
-            res["wgrad"] = timeit(lambda: _lib.check(lib.hn_conv2d_wgrad(P(x), P(dy), P(dw), ctypes.byref(d), 0, s), "wgrad"))
+            res["wgrad"] = timeit(lambda: _lib.check(lib.hn_conv2d_wgrad(P(x), P(dy), P(dw), ctypes.byref(d), SPLIT, VAR, s), "wgrad"))
         cols = ["%10.1f" % (flops / res[k2] / 1e9) if k2 in res else "%10s" % "-" for k2 in ("fwd", "dgrad", "wgrad")]
         print("%-34s %8.1f %s" % (sh, flops / 1e9, " ".join(cols)))
 
