@@ -44,6 +44,8 @@ struct ConvArgs {
     const float* bias;
     float* y;
     double* stats;
+    const float* addend;     // optional tensor added to the output (gradient of a branch that by-passed this conv)
+    int ldadd;
     int H, W, C, ldx;        // input tensor
     int Ho, Wo, K, ldy;      // output tensor (K = output channels)
     int KH, KW, stride, pad, dil, in_dil;
@@ -369,8 +371,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ro = (r & 3) + 8 * (r >> 2);
-                    const float v = acc[i][j][r];
+                    float v = acc[i][j][r];
                     if (FULL || (rbase + ro < p.M && cok)) {
+                        if (p.addend != nullptr) v += p.addend[(size_t)(rbase + ro) * p.ldadd + col];
                         s1 += v;
                         s2 += v * v;
                         dst[(size_t)ro * p.ldy] = v > 0.f ? v : v * neg_slope;
@@ -487,7 +490,7 @@ extern "C" int hn_conv2d_fwd(const float* x, const float* w, const float* bias, 
     const int rc = check_desc(d);
     if (rc != HN_OK) return rc;
     ConvArgs a;
-    a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats;
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats; a.addend = nullptr; a.ldadd = 0;
     a.H = d->Hin; a.W = d->Win; a.C = d->Cin; a.ldx = d->ldx;
     a.Ho = d->Hout; a.Wo = d->Wout; a.K = d->Cout; a.ldy = d->ldy;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.in_dil = 1;
@@ -499,14 +502,15 @@ extern "C" int hn_conv2d_fwd(const float* x, const float* w, const float* bias, 
     return dispatch_conv(a, variant, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, const HnConvDesc* d, int variant,
-                               void* stream) {
+extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* addend, int ldadd,
+                               const HnConvDesc* d, int variant, void* stream) {
     if (dy == nullptr || wt == nullptr || dx == nullptr) return HN_EINVAL;
+    if (addend != nullptr && (d == nullptr || ldadd < d->Cin)) return HN_EINVAL;
     const int rc = check_desc(d);
     if (rc != HN_OK) return rc;
     if (d->dil * (d->KH - 1) < d->pad || d->dil * (d->KW - 1) < d->pad) return HN_ESHAPE;
     ConvArgs a;
-    a.x = dy; a.w = wt; a.bias = nullptr; a.y = dx; a.stats = nullptr;
+    a.x = dy; a.w = wt; a.bias = nullptr; a.y = dx; a.stats = nullptr; a.addend = addend; a.ldadd = ldadd;
     a.H = d->Hout; a.W = d->Wout; a.C = d->Cout; a.ldx = d->ldy;      // gathered tensor: dY
     a.Ho = d->Hin; a.Wo = d->Win; a.K = d->Cin; a.ldy = d->ldx;        // produced tensor: dX
     a.KH = d->KH; a.KW = d->KW; a.stride = 1; a.dil = d->dil; a.in_dil = d->stride;

@@ -71,15 +71,18 @@ class HnBatchNorm2d(nn.BatchNorm2d):
         return self._ws
 
 
-def conv_bn_act(x, conv, bn, act=ops.ACT_NONE, residual=None, prelu_weight=None):
-    """conv -> BatchNorm (batch statistics from the conv epilogue) -> (+residual) -> activation."""
+def conv_bn_act(x, conv, bn, act=ops.ACT_NONE, residual=None, prelu_weight=None, passthrough=False):
+    """conv -> BatchNorm (batch statistics from the conv epilogue) -> (+residual) -> activation.
+
+    `passthrough=True` additionally returns an alias of `x` to be used for the block's skip connection: its gradient
+    then joins this conv's data gradient inside the dgrad kernel instead of in a separate elementwise add."""
     s, p, d = conv.geometry()
-    if bn.training:
-        stats = bn.workspace(x.device).stats  # the conv epilogue adds into it, hn_bn_finalize re-zeroes it
-        y = ops.conv2d(x, conv.weight, conv.bias, s, p, d, want_stats=stats)
-    else:
-        y, stats = ops.conv2d(x, conv.weight, conv.bias, s, p, d), None
-    return bn(y, residual=residual, act=act, stats=stats, prelu_weight=prelu_weight)
+    stats = bn.workspace(x.device).stats if bn.training else None  # conv epilogue adds into it, hn_bn_finalize re-zeroes
+    out = ops.conv2d(x, conv.weight, conv.bias, s, p, d, want_stats=stats if stats is not None else False,
+                     passthrough=passthrough)
+    y, skip = out if passthrough else (out, None)
+    z = bn(y, residual=residual, act=act, stats=stats, prelu_weight=prelu_weight)
+    return (z, skip) if passthrough else z
 
 
 class HnPReLU(nn.PReLU):

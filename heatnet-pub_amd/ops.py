@@ -179,8 +179,9 @@ class _Conv2d(torch.autograd.Function):
     """y = act(conv(x, w) + b) [+ per-channel batch statistics of the pre-activation output]."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, dil, act, slope, want_stats):
+    def forward(ctx, x, w, b, stride, pad, dil, act, slope, want_stats, passthrough):
         lib = _lib.load()
+        x_in = x
         x, ldx = as_nhwc(x)
         w = weight_ohwi(w)
         n, cin, h, wd = x.shape
@@ -205,15 +206,21 @@ class _Conv2d(torch.autograd.Function):
         ctx.geom = (stride, pad, dil, act, slope)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.passthrough = passthrough
+        if passthrough:
+            # second output = the input itself (an alias): whatever consumes it (the block's skip connection) sends
+            # its gradient back through THIS node, where it is added in the dgrad epilogue
+            return y, x_in.view_as(x_in)
         if want_stats is True:
             ctx.mark_non_differentiable(stats)
             return y, stats
         return y  # a caller-owned accumulator is not returned (it is an input)
 
     @staticmethod
-    def backward(ctx, dy, *unused):
+    def backward(ctx, dy, *extra):
         lib = _lib.load()
         x, w, y = ctx.saved_tensors
+        dskip = extra[0] if (ctx.passthrough and extra) else None  # gradient that by-passed this conv
         stride, pad, dil, act, slope = ctx.geom
         x, ldx = as_nhwc(x)
         dy, lddy = as_nhwc(dy)
@@ -235,9 +242,13 @@ class _Conv2d(torch.autograd.Function):
             dx = new_nhwc(n, cin, h, wd, x.device)
             dd = _desc(n, h, wd, cin, cin, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
             var = _pick("dgrad", dd, _igemm_candidates(cin), lambda v: check(
-                lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(dx), ctypes.byref(dd), v, s), "hn_conv2d_dgrad"))
+                lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(dx), None, 0, ctypes.byref(dd), v, s), "hn_conv2d_dgrad"))
+            add, ldadd = (None, 0) if dskip is None else as_nhwc(dskip)
             with _ConvTimer("dgrad", dd):
-                check(lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(dx), ctypes.byref(dd), var, s), "hn_conv2d_dgrad")
+                check(lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(dx), _ptr(add), ldadd, ctypes.byref(dd), var, s),
+                      "hn_conv2d_dgrad")
+        elif dskip is not None:
+            dx = dskip
         if ctx.needs_input_grad[1]:
             dw = torch.empty((cout, kh, kw, cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
             split, var = _pick("wgrad", d, _wgrad_candidates(cout, cin), lambda sv: check(
@@ -248,12 +259,16 @@ class _Conv2d(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(cout, device=x.device, dtype=torch.float32)
             check(lib.hn_channel_sum(_ptr(dy), lddy, npix, cout, _ptr(db), s), "hn_channel_sum")
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, pad=0, dil=1, act=ACT_NONE, slope=0.0, want_stats=False):
-    """`want_stats`: False, True (fresh accumulator) or a zeroed float64 [STAT_REPLICAS*2*Cout] accumulator."""
-    return _Conv2d.apply(x, w, b, int(stride), int(pad), int(dil), int(act), float(slope), want_stats)
+def conv2d(x, w, b=None, stride=1, pad=0, dil=1, act=ACT_NONE, slope=0.0, want_stats=False, passthrough=False):
+    """`want_stats`: False, True (fresh accumulator) or a zeroed float64 [STAT_REPLICAS*2*Cout] accumulator.
+    `passthrough=True` returns (y, x) with x an alias of the input whose gradient is folded into this conv's dgrad
+    (needs a caller-owned accumulator or no statistics)."""
+    if passthrough and want_stats is True:
+        raise ValueError("conv2d: passthrough cannot be combined with want_stats=True")
+    return _Conv2d.apply(x, w, b, int(stride), int(pad), int(dil), int(act), float(slope), want_stats, bool(passthrough))
 
 
 # ------------------------------------------------------------------------------------------------------

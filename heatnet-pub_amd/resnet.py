@@ -28,6 +28,14 @@ def _shortcut(block, x):
     return conv_bn_act(x, block.downsample[0], block.downsample[1], ops.ACT_NONE)
 
 
+def _first_conv(block, x):
+    """conv1 + bn1 + ReLU of a residual block.  When a gradient will flow, `x` is re-bound to conv1's pass-through
+    alias, so the skip connection's gradient is added inside conv1's dgrad kernel rather than by a separate pass."""
+    if x.requires_grad:
+        return conv_bn_act(x, block.conv1, block.bn1, ops.ACT_RELU, passthrough=True)
+    return conv_bn_act(x, block.conv1, block.bn1, ops.ACT_RELU), x
+
+
 class BasicBlock(nn.Module):
     """Two 3x3 convs (ResNet-18/34), models/extractors.py:34-63."""
     expansion = 1
@@ -42,7 +50,7 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = conv_bn_act(x, self.conv1, self.bn1, ops.ACT_RELU)
+        out, x = _first_conv(self, x)
         return conv_bn_act(out, self.conv2, self.bn2, ops.ACT_RELU, residual=_shortcut(self, x))
 
 
@@ -62,7 +70,7 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = conv_bn_act(x, self.conv1, self.bn1, ops.ACT_RELU)
+        out, x = _first_conv(self, x)
         out = conv_bn_act(out, self.conv2, self.bn2, ops.ACT_RELU)
         return conv_bn_act(out, self.conv3, self.bn3, ops.ACT_RELU, residual=_shortcut(self, x))
 

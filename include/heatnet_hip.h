@@ -75,10 +75,13 @@ int hn_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, d
 /* wt[Cin][KH][KW][Cout] = w[Cout][KH-1-kh][KW-1-kw][Cin]: operand of hn_conv2d_dgrad. */
 int hn_weight_flip_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
 
-/* dx = conv_transpose(dy, w) for the forward geometry `d` (dy is N x Hout x Wout x Cout with pixel stride
- * d->ldy, dx is N x Hin x Win x Cin with pixel stride d->ldx); `wt` from hn_weight_flip_transpose.
+/* dx = conv_transpose(dy, w) [+ addend] for the forward geometry `d` (dy is N x Hout x Wout x Cout with pixel stride
+ * d->ldy, dx is N x Hin x Win x Cin with pixel stride d->ldx); `wt` from hn_weight_flip_transpose.  `addend`
+ * (optional, pixel stride ldadd, may alias dx) is a gradient that reached the same tensor through another branch --
+ * the residual skip of cm/models/extractors.py:96-99 -- and is added in the epilogue instead of by a separate pass.
  * Overwrites dx. */
-int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, const HnConvDesc* d, int variant, void* stream);
+int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* addend, int ldadd,
+                    const HnConvDesc* d, int variant, void* stream);
 
 /* dw[Cout][KH][KW][Cin] = sum over pixels of dy (x) x.  Overwrites dw.  split_k > 0: that many reduction splits;
  * 0 / -1: heuristic; -2 / -3 / -4: half / twice / four times the heuristic.  `variant`: tile selection, encoded as for

@@ -64,7 +64,7 @@ def main():
         if "fwd" in kinds:
             res["fwd"] = timeit(lambda: _lib.check(lib.hn_conv2d_fwd(P(x), P(wt), None, P(y), None, ctypes.byref(d), 0, 0.0, VAR, s), "fwd"))
         if "dgrad" in kinds:
-            res["dgrad"] = timeit(lambda: _lib.check(lib.hn_conv2d_dgrad(P(dy), P(wflip), P(dx), ctypes.byref(d), VAR, s), "dgrad"))
+            res["dgrad"] = timeit(lambda: _lib.check(lib.hn_conv2d_dgrad(P(dy), P(wflip), P(dx), None, 0, ctypes.byref(d), VAR, s), "dgrad"))
         if "wgrad" in kinds:
             res["wgrad"] = timeit(lambda: _lib.check(lib.hn_conv2d_wgrad(P(x), P(dy), P(dw), ctypes.byref(d), SPLIT, VAR, s), "wgrad"))
         cols = ["%10.1f" % (flops / res[k2] / 1e9) if k2 in res else "%10s" % "-" for k2 in ("fwd", "dgrad", "wgrad")]
