@@ -17,27 +17,46 @@ import torch.distributed as dist
 
 
 class GradBuckets:
-    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, average=True):
+    """`params`: the buckets allocate their own flat gradient storage.  `arenas` (optim.ParamArena): the buckets are
+    contiguous slices of the arenas' flat gradient buffers -- the optimizer then reads the reduced gradients in place."""
+
+    def __init__(self, params=None, bucket_bytes=64 << 20, process_group=None, average=True, arenas=None):
         self.group = process_group
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []  # dicts: flat, params, pending, work
+        if arenas is not None:
+            arenas = [a for a in arenas if a.active()]
+            self.params = [p for a in arenas for p in a.params]
+        else:
+            self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("GradBuckets: no trainable parameters")
         self.device = self.params[0].device
         self.on_gpu = self.device.type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
-        order = list(reversed(self.params))  # backward reaches the last-registered parameters first
-        self.buckets = []  # dicts: flat, params, pending, work, event
-        cur, cur_bytes = [], 0
-        for p in order:
-            cur.append(p)
-            cur_bytes += p.numel() * 4
-            if cur_bytes >= bucket_bytes:
+        if arenas is not None:
+            for a in arenas:
+                start, cur = 0, []
+                for p, off in zip(a.params, a.offsets):
+                    cur.append(p)
+                    end = off + p.numel()
+                    if (end - start) * 4 >= bucket_bytes:
+                        self._adopt(a.grad[start:end], cur)
+                        start, cur = end, []
+                if cur:
+                    self._adopt(a.grad[start:a.numel], cur)
+        else:
+            order = list(reversed(self.params))  # backward reaches the last-registered parameters first
+            cur, cur_bytes = [], 0
+            for p in order:
+                cur.append(p)
+                cur_bytes += p.numel() * 4
+                if cur_bytes >= bucket_bytes:
+                    self._seal(cur)
+                    cur, cur_bytes = [], 0
+            if cur:
                 self._seal(cur)
-                cur, cur_bytes = [], 0
-        if cur:
-            self._seal(cur)
         self._hooks = []
         self._index = {}
         for bi, b in enumerate(self.buckets):
@@ -45,6 +64,9 @@ class GradBuckets:
                 self._index[p] = bi
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._active = False
+
+    def _adopt(self, flat, plist):
+        self.buckets.append({"flat": flat, "params": list(plist), "pending": 0, "work": None})
 
     def _seal(self, plist):
         n = sum(p.numel() for p in plist)
@@ -55,7 +77,7 @@ class GradBuckets:
             view = flat[off:off + p.numel()].as_strided(p.size(), p.stride())
             p.grad = view
             off += p.numel()
-        self.buckets.append({"flat": flat, "params": list(plist), "pending": 0, "work": None, "event": None})
+        self.buckets.append({"flat": flat, "params": list(plist), "pending": 0, "work": None})
 
     # -- per-step protocol -------------------------------------------------------------------------------
     def begin_step(self):

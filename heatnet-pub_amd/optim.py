@@ -1,0 +1,118 @@
+"""Flat parameter arenas and the fused optimizer updates of the HeatNet trainers.
+
+The reference steps `torch.optim.RMSprop(all parameters, lr=1e-4)` (cm/train_trgb_segnet_conf.py:270) or
+`torch.optim.Adam` (scripts/main.py:159) tensor by tensor.  Here the parameters of one training phase live in ONE flat
+fp32 buffer (each `Parameter` is a view that keeps its own strides, so conv weights stay channels-last), their
+gradients in a second flat buffer of the same layout, and an optimizer step is a single HBM-bound kernel launch
+(`hn_rmsprop_step` / `hn_adam_step`) over the whole range; `zero_grad` is one memset.  The same flat gradient buffer
+is what `ddp.GradBuckets` all-reduces, so there is no gather/scatter of gradients either.
+
+Semantics follow torch >= 2.0 as the reference runs today: a parameter group whose parameters do not require grad in
+the current phase (`conv_segnet.setPhase`) is skipped entirely -- its `square_avg` does not decay.
+"""
+import torch
+
+from . import ops
+
+
+def _dense(p):
+    return p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+
+
+class ParamArena:
+    """Re-homes `params` into one flat buffer (+ one flat gradient buffer); order is kept."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        if not self.params:
+            raise ValueError("ParamArena: empty parameter list")
+        dev = self.params[0].device
+        for p in self.params:
+            if p.device != dev or p.dtype != torch.float32 or not _dense(p):
+                raise ValueError("ParamArena: parameters must be dense fp32 tensors on one device")
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(self.numel, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        self.offsets = []
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                view = self.flat[off:off + n].as_strided(p.size(), p.stride())
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.grad[off:off + n].as_strided(p.size(), p.stride())
+                self.offsets.append(off)
+                off += n
+
+    def active(self):
+        """True when this arena's parameters take part in the current phase."""
+        return self.params[0].requires_grad
+
+    def check(self):
+        base, end = self.grad.data_ptr(), self.grad.data_ptr() + 4 * self.numel
+        for p in self.params:
+            g = p.grad
+            if g is None or not (base <= g.data_ptr() < end):
+                raise RuntimeError("ParamArena: a gradient left the arena (zero_grad(set_to_none=True) was used?)")
+
+
+class _FlatOptimizer(torch.optim.Optimizer):
+    """Common part: one param group per arena (so LR schedulers and state_dict-style access keep working)."""
+
+    def __init__(self, arenas, defaults):
+        if isinstance(arenas, ParamArena):
+            arenas = [arenas]
+        self.arenas = list(arenas)
+        groups = [{"params": a.params} for a in self.arenas]
+        super().__init__(groups, defaults)  # param_groups[i] <-> arenas[i]
+
+    def zero_grad(self, set_to_none=False):
+        """Always in place (one memset per arena); `set_to_none` is accepted for API compatibility and ignored."""
+        for a in self.arenas:
+            if a.active():
+                a.grad.zero_()
+
+
+class FlatRMSprop(_FlatOptimizer):
+    """torch.optim.RMSprop(lr, alpha=0.99, eps=1e-8, weight_decay=0, momentum=0, centered=False) on arenas."""
+
+    def __init__(self, arenas, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0):
+        super().__init__(arenas, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay))
+        self.square_avg = [torch.zeros_like(a.flat) for a in self.arenas]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for g, a, sq in zip(self.param_groups, self.arenas, self.square_avg):
+            if not a.active():
+                continue
+            ops.rmsprop_step_(a.flat, a.grad, sq, g["lr"], g["alpha"], g["eps"], g["weight_decay"])
+
+
+class FlatAdam(_FlatOptimizer):
+    """torch.optim.Adam(lr, betas, eps, weight_decay) on arenas (no amsgrad)."""
+
+    def __init__(self, arenas, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(arenas, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.exp_avg = [torch.zeros_like(a.flat) for a in self.arenas]
+        self.exp_avg_sq = [torch.zeros_like(a.flat) for a in self.arenas]
+        self.steps = [0 for _ in self.arenas]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for i, (g, a) in enumerate(zip(self.param_groups, self.arenas)):
+            if not a.active():
+                continue
+            self.steps[i] += 1
+            ops.adam_step_(a.flat, a.grad, self.exp_avg[i], self.exp_avg_sq[i], self.steps[i], g["lr"], g["betas"][0],
+                           g["betas"][1], g["eps"], g["weight_decay"])
+
+
+def arenas_for(model):
+    """One arena per training phase of a `conv_segnet` (segmentation net, critics), or one for a plain network."""
+    if hasattr(model, "trgb_segnet"):
+        groups = [list(model.trgb_segnet.parameters())]
+        if hasattr(model, "critics"):
+            groups.append(list(model.critics.parameters()))
+        return [ParamArena(g) for g in groups]
+    return [ParamArena(list(model.parameters()))]

@@ -69,7 +69,7 @@ def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_w
     `model` is a `conv_segnet` (possibly wrapped so that `.module` exists); `grad_sync`, when given, is a
     `ddp.GradBuckets` whose all-reduce overlaps the backward pass.  Returns the loss tensors (no host sync).
     """
-    optimizer.zero_grad(set_to_none=grad_sync is None)
+    optimizer.zero_grad(set_to_none=grad_sync is None)  # flat-arena optimizers always zero in place
     if grad_sync is not None:
         grad_sync.begin_step()
     out = model(day, night)

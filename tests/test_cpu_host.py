@@ -115,3 +115,36 @@ def test_config_file_is_the_reference_file():
     conf = json.load(open(os.path.join(ROOT, "experiments", "heatnet_conf.json")))
     assert conf["optimizer"]["learning_rate"] == 1e-05 and conf["optimizer"]["batch_size"] == 30
     assert conf["network"]["arch"] == "resnext50" and conf["optimizer"]["clip"] == 0
+
+
+def test_checkpoint_interchange_with_reference_format(tmp_path):
+    """Reference-format checkpoints (`module.`-prefixed keys, {'epoch','state_dict',...}) load into our networks and
+    ours load back into the oracle (= reference layout); snapshot files `<name>_<epoch>` go through build_network."""
+    from heatnet_amd import checkpoint
+    from heatnet_amd.pspnet import PSPNet
+    from oracle import heatnet_ref as R
+    from _seeded import seeded_state
+    ref = R.RefPSPNet(backend="resnet50", late_fusion=True, in_channels=4)
+    state = seeded_state(ref, seed=3)
+    ckpt = {"epoch": 7, "state_dict": {"module.trgb_segnet." + k: v for k, v in state.items()}, "best_iou": 0.5}
+    path = tmp_path / "training_nc_irrgb_best.pth"
+    torch.save(ckpt, str(path))
+    mine = PSPNet(backend="resnet50", pretrained=False, late_fusion=True, in_channels=4)
+    checkpoint.init_model_renamed(mine, str(path), "module.trgb_segnet.", "")
+    got = mine.state_dict()
+    assert all(torch.equal(got[k], state[k]) for k in state)
+    assert mine.feats.layer4[0].conv2.weight.is_contiguous(memory_format=torch.channels_last)
+    # ours -> reference layout
+    out = tmp_path / "ours.pth.tar"
+    checkpoint.save_checkpoint({"epoch": 1, "state_dict": mine.state_dict(), "best_iou": 0.0}, True, str(out))
+    back = torch.load(str(out))
+    ref2 = R.RefPSPNet(backend="resnet50", late_fusion=True, in_channels=4)
+    ref2.load_state_dict(back["state_dict"])
+    assert all(v.is_contiguous() for v in back["state_dict"].values() if torch.is_tensor(v))
+    assert os.path.exists(str(out) + "_best.pth.tar")
+    # snapshot convention of build_network: "<name>_<epoch>"
+    from heatnet_amd import build_net
+    snap = tmp_path / "PSPNet_12"
+    torch.save(mine.state_dict(), str(snap))
+    net = build_net.build_network(str(snap), "resnet50", in_channels=4, late_fusion=True)
+    assert torch.equal(net.state_dict()["final.0.bias"].cpu(), state["final.0.bias"])

@@ -41,7 +41,7 @@ def _model():
     return _Net()
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, use_arena):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -54,7 +54,13 @@ def _worker(rank, world, port, ret):
     ref = _model()
     same = all(torch.equal(a, b) for a, b in zip(m.parameters(), ref.parameters()))
 
-    buckets = ddp.GradBuckets(list(m.parameters()), bucket_bytes=256)  # several small buckets
+    if use_arena:  # gradients live in the optimizer's flat arena; buckets are slices of it
+        from heatnet_amd import optim
+        arena = optim.ParamArena(list(m.parameters()))
+        buckets = ddp.GradBuckets(arenas=[arena], bucket_bytes=256)
+        assert all(b["flat"].data_ptr() >= arena.grad.data_ptr() for b in buckets.buckets)
+    else:
+        buckets = ddp.GradBuckets(list(m.parameters()), bucket_bytes=256)  # several small buckets
     assert len(buckets.buckets) >= 2
     opt = torch.optim.SGD(m.parameters(), lr=0.1)
     g = torch.Generator().manual_seed(100 + rank)
@@ -87,11 +93,12 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_grad_buckets_two_ranks():
+@pytest.mark.parametrize("use_arena", [False, True])
+def test_grad_buckets_two_ranks(use_arena):
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, use_arena), nprocs=world, join=True)
     for rank in range(world):
         same, err, drift = ret[rank]
         assert same

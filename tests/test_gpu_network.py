@@ -188,3 +188,57 @@ def test_confusion_maximisation_steps(dev, golden_dir, adv):
         floor = 1e-4 * max(norms.values())  # conv biases in front of a BatchNorm have a zero true gradient
         worst = max((abs(got[k] - norms[k]) / max(norms[k], floor), k) for k in names)
         assert worst[0] < (5e-3 if step == 0 else 5e-2), worst
+
+
+def test_flat_arena_rmsprop_matches_torch(dev):
+    """FlatRMSprop / FlatAdam on a ParamArena == torch.optim over three steps (same gradients), views stay attached."""
+    from heatnet_amd import optim
+    from heatnet_amd.critics import FCDiscriminator
+    torch.manual_seed(0)
+    a, b = FCDiscriminator(13).to(dev), FCDiscriminator(13).to(dev)
+    b.load_state_dict(a.state_dict())
+    for flat_cls, ref_cls, kw in ((optim.FlatRMSprop, torch.optim.RMSprop, dict(lr=1e-4)),
+                                  (optim.FlatAdam, torch.optim.Adam, dict(lr=1e-3))):
+        arena = optim.ParamArena(list(a.parameters()))
+        fo, ro = flat_cls([arena], **kw), ref_cls(b.parameters(), **kw)
+        assert a.conv1.weight.is_contiguous(memory_format=torch.channels_last)
+        for step in range(3):
+            fo.zero_grad()
+            ro.zero_grad()
+            g = torch.Generator().manual_seed(step)
+            for pa, pb in zip(a.parameters(), b.parameters()):
+                grad = torch.randn(pa.shape, generator=g).to(dev)
+                pa.grad.copy_(grad)
+                pb.grad = grad.clone()
+            arena.check()
+            fo.step()
+            ro.step()
+        for (k, pa), pb in zip(a.named_parameters(), b.parameters()):
+            assert (pa - pb).abs().max().item() < 2e-6, k
+        for p in a.parameters():  # detach from the arena before the next optimizer re-homes them
+            p.data = p.data.clone()
+            p.grad = None
+
+
+def test_validation_convention_matches_oracle(dev):
+    """validate_model(reference_mode=True): duplicated 2-sample batches in train mode, row 0, argmax, calculate_ious."""
+    from heatnet_amd import validate
+    from oracle import heatnet_ref as R
+    rgb, ir, lab = seeded_inputs(3, 64, 96, seed=21, n_classes=14)
+    ref = R.RefPSPNet(backend="resnet50", late_fusion=True, in_channels=4)
+    ref.load_state_dict(seeded_state(ref, seed=1))
+    ref.train()
+    set_dropout(ref, 0.0)
+    preds = []
+    with torch.no_grad():
+        for b in range(3):
+            out, _, _ = ref(rgb[b:b + 1].repeat(2, 1, 1, 1), ir[b:b + 1].repeat(2, 1, 1, 1))
+            preds.append(out[0].argmax(0))
+    ref_ious = R.calculate_ious(torch.stack(preds).numpy(), lab.numpy())
+    net = _build(True, 1, dev)
+    res = validate.validate_model(net, [(rgb.to(dev), ir.to(dev), lab.to(dev))], reference_mode=True)
+    assert net.training  # mode restored (the fixture model was built in train mode)
+    assert res["confusion"].sum() == 3 * 64 * 96
+    assert abs(np.nanmean(ref_ious) - res["miou"]) < 1e-3
+    # BatchNorm running statistics moved, as they do in the reference's validation
+    assert int(net.state_dict()["feats.bn1.num_batches_tracked"]) == 3
