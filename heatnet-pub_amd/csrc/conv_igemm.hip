@@ -357,8 +357,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 
     // branch-free activation: out = v > 0 ? v : v * neg_slope  (none: 1, relu: 0, leaky/prelu: slope)
     const float neg_slope = p.act == HN_ACT_NONE ? 1.f : (p.act == HN_ACT_RELU ? 0.f : p.slope);
-    auto finish = [&](auto full_tag) {
+    auto finish = [&](auto full_tag, auto add_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
+        constexpr bool ADD = decltype(add_tag)::value;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + (wn * TN + j) * 32 + lr;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
                     const int ro = (r & 3) + 8 * (r >> 2);
                     float v = acc[i][j][r];
                     if (FULL || (rbase + ro < p.M && cok)) {
-                        if (p.addend != nullptr) v += p.addend[(size_t)(rbase + ro) * p.ldadd + col];
+                        if constexpr (ADD) v += p.addend[(size_t)(rbase + ro) * p.ldadd + col];
                         s1 += v;
                         s2 += v * v;
                         dst[(size_t)ro * p.ldy] = v > 0.f ? v : v * neg_slope;
@@ -394,8 +395,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
             }
         }
     };
-    if (full) finish(std::true_type{});
-    else finish(std::false_type{});
+    if (p.addend != nullptr) {  // data gradient joined by a skip-path gradient
+        if (full) finish(std::true_type{}, std::true_type{});
+        else finish(std::false_type{}, std::true_type{});
+    } else {
+        if (full) finish(std::true_type{}, std::false_type{});
+        else finish(std::false_type{}, std::false_type{});
+    }
 }
 
 template <int TM, int TN, int MODE, int BK>

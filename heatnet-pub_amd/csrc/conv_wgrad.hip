@@ -276,18 +276,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     auto k_step = [&](int buf, auto write_tag, auto fetch_tag) {
         Frag f0, f1;
         read_frag(buf, 0, f0);
+#ifndef HN_EXP_NOWRITE
         if constexpr (decltype(write_tag)::value) store_lds(buf ^ 1);
+#endif
         read_frag(buf, 1, f1);
         HN_PIN();
         mfma16(f0);
         HN_PIN();
         read_frag(buf, 2, f0);
+#ifndef HN_EXP_NOLOAD
         if constexpr (decltype(fetch_tag)::value) load_a();
+#endif
         HN_PIN();
         mfma16(f1);
         HN_PIN();
         read_frag(buf, 3, f1);
+#ifndef HN_EXP_NOLOAD
         if constexpr (decltype(fetch_tag)::value) load_b();
+#endif
         HN_PIN();
         mfma16(f0);
         HN_PIN();
@@ -338,6 +344,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
             }
         }
     };
+#ifdef HN_EXP_NOEPI
+    if (p.M >= 0) return;
+#endif
     if (p.atomic) {
         if (full) finish(std::true_type{}, std::true_type{});
         else finish(std::false_type{}, std::true_type{});
@@ -363,14 +372,12 @@ int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     const int tiles = a.ntm * a.ntn;
     const int total_chunks = (a.M + BKP - 1) / BKP;
     if (split_k <= 0) {
-        // aim at ~3 blocks per CU, keep at least 8 reduction steps per split; -2 / -3 / -4 ask for half / twice / four
-        // times the heuristic (autotuning)
+        // Fill whole rounds of the 512 workgroups the chip holds (2 per CU): the largest split with
+        // tiles * split <= 512 * rounds.  0 / -1: two rounds; -2 / -3 / -4 / -5: one / three / four / six rounds.
         const int code = split_k;
-        split_k = (768 + tiles - 1) / tiles;
-        if (code == -2) split_k = (split_k + 1) / 2;
-        if (code == -3) split_k *= 2;
-        if (code == -4) split_k *= 4;
-        const int cap = (total_chunks + 7) / 8;
+        const int rounds = code == -2 ? 1 : code == -3 ? 3 : code == -4 ? 4 : code == -5 ? 6 : 2;
+        split_k = (512 * rounds) / tiles;
+        const int cap = (total_chunks + 3) / 4;  // at least 4 reduction steps per split
         if (split_k > cap) split_k = cap;
         if (split_k < 1) split_k = 1;
     }

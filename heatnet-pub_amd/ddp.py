@@ -38,9 +38,9 @@ class GradBuckets:
         if arenas is not None:
             for a in arenas:
                 start, cur = 0, []
-                for p, off in zip(a.params, a.offsets):
+                ends = a.offsets[1:] + [a.numel]  # parameter slots are padded to 256 B; padding stays zero
+                for p, end in zip(a.params, ends):
                     cur.append(p)
-                    end = off + p.numel()
                     if (end - start) * 4 >= bucket_bytes:
                         self._adopt(a.grad[start:end], cur)
                         start, cur = end, []

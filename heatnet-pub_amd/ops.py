@@ -115,18 +115,21 @@ def _pick(kind, d, candidates, launch):
     hit = _variant_cache.get(key)
     if hit is not None:
         return hit
-    best, best_t = candidates[0], float("inf")
     for cand in candidates:
         launch(cand)  # warm-up (first launch of an instantiation also sets its LDS attribute)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        launch(cand)
-        launch(cand)
-        e1.record()
-        e1.synchronize()
-        t = e0.elapsed_time(e1)
-        if t < best_t:
-            best, best_t = cand, t
+    times = {c: float("inf") for c in candidates}
+    for _ in range(4):  # interleaved rounds, best-of: robust against clock ramps and one-off hiccups
+        for cand in candidates:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch(cand)
+            e1.record()
+            e1.synchronize()
+            times[cand] = min(times[cand], e0.elapsed_time(e1))
+    # keep the library's heuristic choice (first candidate) unless another one is clearly faster
+    best = min(candidates, key=lambda c: times[c])
+    if times[best] > 0.97 * times[candidates[0]]:
+        best = candidates[0]
     _variant_cache[key] = best
     return best
 
@@ -139,7 +142,23 @@ def _igemm_candidates(cout):
 def _wgrad_candidates(cout, cin):
     tms = (0, 1) if cout > 64 else (0,)
     tns = (0, 1) if cin % 128 == 0 else (0,)
-    return [(split, _variant(0, tm, tn)) for tm in tms for tn in tns for split in (0, -2, -3)]
+    return [(split, _variant(0, tm, tn)) for tm in tms for tn in tns for split in (0, -2, -3, -4, -5)]
+
+
+# ---- dgrad || wgrad overlap ----------------------------------------------------------------------------------------
+# The two gradient kernels of a convolution are independent.  Launched back to back on one stream, each ends with a
+# partially filled last round of workgroups (grids are small multiples of the 256 CUs); launched on two streams the
+# tails overlap.  Measured on MI355X (bs 8, 320x704): 85.0 ms/step with the overlap vs 83.4 without -- two MFMA-bound
+# kernels mostly contend for the same pipes -- so it is OFF unless HEATNET_OVERLAP=1.
+OVERLAP = os.environ.get("HEATNET_OVERLAP", "0") == "1"
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
 
 
 _conv_prof = None  # bench.py: list receiving (kind, algorithmic flops, start event, end event) per conv launch
@@ -236,6 +255,10 @@ class _Conv2d(torch.autograd.Function):
             dy, lddy = dpre, cout
         d = _desc(n, h, wd, cin, ldx, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
         dx = dw = db = None
+        fork = None
+        if OVERLAP and _conv_prof is None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            fork = torch.cuda.Event()
+            fork.record()  # dy (and the activation backward that produced it) is complete up to here
         if ctx.needs_input_grad[0]:
             wt = torch.empty(cin * kh * kw * cout, device=x.device, dtype=torch.float32)
             check(lib.hn_weight_flip_transpose(_ptr(w), _ptr(wt), cout, kh, kw, cin, s), "hn_weight_flip_transpose")
@@ -253,9 +276,17 @@ class _Conv2d(torch.autograd.Function):
             dw = torch.empty((cout, kh, kw, cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
             split, var = _pick("wgrad", d, _wgrad_candidates(cout, cin), lambda sv: check(
                 lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), sv[0], sv[1], s), "hn_conv2d_wgrad"))
-            with _ConvTimer("wgrad", d):
-                check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), split, var, s),
-                      "hn_conv2d_wgrad")
+            if OVERLAP and _conv_prof is None and ctx.needs_input_grad[0]:
+                # the dgrad above is already queued on the main stream; wgrad runs beside it on the side stream
+                main, side = torch.cuda.current_stream(), _side_stream(x.device)
+                side.wait_event(fork)
+                check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), split, var,
+                                          ctypes.c_void_p(side.cuda_stream)), "hn_conv2d_wgrad")
+                main.wait_stream(side)
+            else:
+                with _ConvTimer("wgrad", d):
+                    check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), split, var, s),
+                          "hn_conv2d_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(cout, device=x.device, dtype=torch.float32)
             check(lib.hn_channel_sum(_ptr(dy), lddy, npix, cout, _ptr(db), s), "hn_channel_sum")

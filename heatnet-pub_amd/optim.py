@@ -30,20 +30,24 @@ class ParamArena:
         for p in self.params:
             if p.device != dev or p.dtype != torch.float32 or not _dense(p):
                 raise ValueError("ParamArena: parameters must be dense fp32 tensors on one device")
-        self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.empty(self.numel, device=dev, dtype=torch.float32)
-        self.grad = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        # every parameter starts on a 256-B boundary: the conv kernels take their 16-B vector / buffer-load paths only
+        # for aligned weight pointers (a 1-element PReLU slope would otherwise misalign everything behind it)
+        align = 64
         self.offsets = []
         off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + align - 1) // align * align
+        self.numel = off
+        self.flat = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(self.numel, device=dev, dtype=torch.float32)
         with torch.no_grad():
-            for p in self.params:
+            for p, off in zip(self.params, self.offsets):
                 n = p.numel()
                 view = self.flat[off:off + n].as_strided(p.size(), p.stride())
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.grad[off:off + n].as_strided(p.size(), p.stride())
-                self.offsets.append(off)
-                off += n
 
     def active(self):
         """True when this arena's parameters take part in the current phase."""
