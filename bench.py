@@ -70,7 +70,7 @@ def make_step(workload, model, opt, batch, buckets):
                                          adv="MSE", grad_sync=buckets)
 
 
-def measure_conv_roofline(step_fn, steps, workload):
+def measure_conv_roofline(step_fn, steps, workload, scale=1.0):
     """Instrumented pass: HIP events (torch's current stream = the launch stream) around every conv-kernel launch."""
     from heatnet_amd import ops
     records = []
@@ -84,7 +84,9 @@ def measure_conv_roofline(step_fn, steps, workload):
     per_kind = {}
     flops = ms = 0.0
     table = {}
-    for kind, fl, e0, e1, shape in records:
+    nbytes = 0.0
+    for kind, fl, e0, e1, shape, by in records:
+        nbytes += by
         t = e0.elapsed_time(e1)
         row = table.setdefault((kind,) + shape, [0, 0.0, 0.0])
         row[0] += 1
@@ -107,9 +109,11 @@ def measure_conv_roofline(step_fn, steps, workload):
                   "ms_per_step": v[2] / steps, "avg_launch_us": 1e3 * v[2] / v[0], "tflops": v[1] / v[2] / 1e9}
               for k, v in per_kind.items()}
     achieved = flops / ms / 1e9 if ms > 0 else 0.0
-    ref_tflop = REFERENCE_CONV_TFLOP.get(workload)
+    ref_tflop = REFERENCE_CONV_TFLOP.get(workload) if scale == 1.0 else None
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": pmc_traffic(),
+            "algorithmic_bytes_per_launch": round(nbytes / max(launches, 1)),
             "kernel": "conv_igemm_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32)",
             "launches_per_step": launches // steps,
             # executed = 2*M*N*K of the launches actually made (the pyramid bottleneck is applied per level at the
@@ -120,6 +124,18 @@ def measure_conv_roofline(step_fn, steps, workload):
             "achieved_vs_reference_op_count": round(ref_tflop * 1e3 / (ms / steps), 2) if ref_tflop else None,
             "conv_ms_per_step": round(ms / steps, 3), "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
             "by_kind": detail}
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE, separate runs of this same benchmark, FETCH_SIZE doubled per MI355X_MICROARCH.md): counters
+    cannot be collected from inside this process, so the figure is read from profiles/ and is null if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return round(json.load(f)["conv_igemm_kernel<2, 2, 4, 32>"]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(workload):
@@ -163,6 +179,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="seg", choices=["seg", "confmax_seg", "confmax_critic"])
+    ap.add_argument("--height", type=int, default=H, help="input height (default: the BASELINE metric's 320)")
+    ap.add_argument("--width", type=int, default=W, help="input width (default 704)")
+    ap.add_argument("--batch", type=int, default=BS, help="images per GPU (default 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -194,7 +213,7 @@ def main():
     arenas = optim.arenas_for(model)          # flat parameter / gradient storage per training phase
     opt = optim.FlatRMSprop(arenas, lr=1e-4)  # one fused kernel launch per step (cm/train_trgb_segnet_conf.py:270)
     buckets = ddp.GradBuckets(arenas=arenas) if world > 1 else None
-    batch = synthetic_batch(rank, dev)
+    batch = synthetic_batch(rank, dev, args.batch, args.height, args.width)
     step = make_step(args.workload, model, opt, batch, buckets)
 
     for _ in range(args.warmup):
@@ -218,7 +237,8 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        roof = measure_conv_roofline(step, max(1, min(3, args.steps)), args.workload)
+        roof = measure_conv_roofline(step, max(1, min(3, args.steps)), args.workload,
+                                     scale=(args.height * args.width * args.batch) / float(H * W * BS))
     if world > 1:
         dist.barrier()
     base = None
@@ -230,11 +250,12 @@ def main():
                         "backward + RMSprop",
                  "confmax_seg": "configs[2]: confusion-maximisation train_seg iteration (day+night passes, 6 critics)",
                  "confmax_critic": "configs[2]: confusion-maximisation train_critic iteration (day+night passes, 6 critics)"}
-        out = {"metric": "training images/s at 320x704 RGB+IR, bs=8/GPU", "value": round(world * BS * args.steps / elapsed, 3),
+        out = {"metric": "training images/s at 320x704 RGB+IR, bs=8/GPU", "value": round(world * args.batch * args.steps / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": names[args.workload], "global_batch": world * BS, "height": H, "width": W,
+               "config": {"workload": names[args.workload], "global_batch": world * args.batch, "height": args.height,
+                          "width": args.width,
                           "parallelism": "dp%d" % world, "optimizer": "RMSprop lr=1e-4 (fused, flat arena)", "weights": "random init"},
                "roofline": roof, "cpu_baseline": base}
         print(json.dumps(out))

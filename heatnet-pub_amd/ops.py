@@ -178,6 +178,8 @@ class _ConvTimer:
             self.kind = kind
             self.flops = 2.0 * d.N * d.Hout * d.Wout * d.Cout * d.KH * d.KW * d.Cin
             self.shape = (d.N, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.Cout, d.KH, d.stride, d.dil)
+            # compulsory HBM traffic: each of the three tensors of the convolution touched once
+            self.bytes = 4.0 * (d.N * d.Hin * d.Win * d.Cin + d.Cout * d.KH * d.KW * d.Cin + d.N * d.Hout * d.Wout * d.Cout)
             self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def __enter__(self):
@@ -187,7 +189,7 @@ class _ConvTimer:
     def __exit__(self, *exc):
         if self.on:
             self.e1.record()
-            _conv_prof.append((self.kind, self.flops, self.e0, self.e1, self.shape))
+            _conv_prof.append((self.kind, self.flops, self.e0, self.e1, self.shape, self.bytes))
 
 
 # ------------------------------------------------------------------------------------------------------
