@@ -24,9 +24,10 @@
 
 namespace {
 
-constexpr int BKP = 32;  // pixels per reduction step
+// pixels per reduction step (template parameter BKP): 32 -> 64 KB of LDS per 128x128 workgroup (2 per CU), 16 -> 32 KB
+// (3 per CU with the 146 VGPRs of the register-staged loaders)
 
-enum : int { WG_SCALAR = 0, WG_VEC = 1, WG_VEC_BUF = 2 };
+enum : int { WG_SCALAR = 0, WG_VEC = 1, WG_VEC_BUF = 2, WG_VEC_DMA = 3 };
 
 struct WgradArgs {
     const float* x;
@@ -47,10 +48,20 @@ __device__ __forceinline__ f32x4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsi
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
 }
 
-template <int TM, int TN, int MODE>
+// buffer_load_dwordx4 ... offen lds: each lane's 16 B go to (wave-uniform LDS base) + lane * 16.  The builtin only
+// exists in the device pass; the host pass just needs the kernel's stub.
+__device__ __forceinline__ void buffer_load16_lds(__amdgpu_buffer_rsrc_t rsrc, float* lds_wave_base, unsigned voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, 0, 0, 0);
+#endif
+}
+
+template <int TM, int TN, int MODE, int BKP>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
+    constexpr int WG_GROUPS = BKP / 8;  // MFMA groups (8 pixels each) per step
     constexpr bool VEC = MODE != WG_SCALAR;
-    constexpr bool BUF = MODE == WG_VEC_BUF;
+    constexpr bool DMA = MODE == WG_VEC_DMA;              // buffer loads that write LDS directly (no VGPR staging)
+    constexpr bool BUF = MODE == WG_VEC_BUF || DMA;
     constexpr int BM = 64 * TM, BN = 64 * TN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                   // [2][BKP][BM]  dY tile
@@ -219,6 +230,45 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
         ++fetch_chunk;
     };
 
+    // LDS-DMA: a wave instruction deposits 64 x 16 B = 1 KiB contiguously at a wave-uniform LDS address, which is
+    // exactly this kernel's tile image (piece index = tid + 256 q, lane-linear); out-of-range offsets deposit zeros.
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto dma_chunk = [&](int buf) {
+        if constexpr (DMA) {
+            const int p0 = fetch_chunk * BKP;
+            const unsigned adv = (unsigned)((long long)p0 * p.ldy * 4);
+            float* a = As + buf * BKP * BM + wave_u * 256;
+            float* b = Bs + buf * BKP * BN + wave_u * 256;
+#pragma unroll
+            for (int q = 0; q < RA; ++q) {
+                const unsigned off = a_voff[q] + adv;
+                buffer_load16_lds(rsrc_dy, a + 1024 * q, off < a_voff[q] ? 0xFFFFFFFFu : off);
+            }
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                const int pix = p0 + b_r0 + ROWS_B * q;
+                const bool ok = (pix < p.M) & ((unsigned)hq[q] < (unsigned)p.H) & ((unsigned)wq[q] < (unsigned)p.W);
+                buffer_load16_lds(rsrc_x, b + 1024 * q, ok ? (unsigned)(xoff[q] * 4) : x_records);
+                wo_[q] += BKP;
+                wq[q] += BKP * p.stride;
+                xoff[q] += BKP * step_w;
+                while (wo_[q] >= p.Wo) {
+                    wo_[q] -= p.Wo;
+                    wq[q] -= p.Wo * p.stride;
+                    ho_[q] += 1;
+                    hq[q] += p.stride;
+                    xoff[q] += wrap_w;
+                    if (ho_[q] >= p.Ho) {
+                        ho_[q] -= p.Ho;
+                        hq[q] -= p.Ho * p.stride;
+                        xoff[q] += wrap_h;
+                    }
+                }
+            }
+            ++fetch_chunk;
+        }
+    };
+
     auto store_lds = [&](int buf) {
         float* a = As + buf * BKP * BM;
         float* b = Bs + buf * BKP * BN;
@@ -274,35 +324,46 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     // same software pipeline as the forward kernel: staging registers -> other LDS buffer at the top of a step,
     // the fetch of the chunk after next issued between the MFMA groups
     auto k_step = [&](int buf, auto write_tag, auto fetch_tag) {
-        Frag f0, f1;
-        read_frag(buf, 0, f0);
+        Frag f[2];
+        read_frag(buf, 0, f[0]);
 #ifndef HN_EXP_NOWRITE
         if constexpr (decltype(write_tag)::value) store_lds(buf ^ 1);
 #endif
-        read_frag(buf, 1, f1);
-        HN_PIN();
-        mfma16(f0);
-        HN_PIN();
-        read_frag(buf, 2, f0);
+#pragma unroll
+        for (int g = 0; g < WG_GROUPS; ++g) {
+            if (g + 1 < WG_GROUPS) read_frag(buf, g + 1, f[(g + 1) & 1]);
 #ifndef HN_EXP_NOLOAD
-        if constexpr (decltype(fetch_tag)::value) load_a();
+            if constexpr (decltype(fetch_tag)::value) {
+                if (g == (WG_GROUPS >= 4 ? 1 : 0)) load_a();
+                if (g == (WG_GROUPS >= 4 ? 2 : WG_GROUPS - 1)) load_b();
+            }
 #endif
-        HN_PIN();
-        mfma16(f1);
-        HN_PIN();
-        read_frag(buf, 3, f1);
-#ifndef HN_EXP_NOLOAD
-        if constexpr (decltype(fetch_tag)::value) load_b();
-#endif
-        HN_PIN();
-        mfma16(f0);
-        HN_PIN();
-        mfma16(f1);
+            mfma16(f[g & 1]);
+        }
         __syncthreads();
     };
 
     const int nch = c_end - c_begin;
-    if (nch > 0) {
+    if constexpr (DMA) {
+        // two LDS buffers: the DMA of chunk kc+1 is issued at the top of step kc into the buffer every wave finished
+        // reading at the previous barrier, and must have landed (vmcnt(0), emitted with the barrier) by the end of it
+        if (nch > 0) {
+            dma_chunk(0);
+            __syncthreads();
+            for (int kc = 0; kc < nch; ++kc) {
+                const int buf = kc & 1;
+                if (kc + 1 < nch) dma_chunk(buf ^ 1);
+                Frag f[2];
+                read_frag(buf, 0, f[0]);
+#pragma unroll
+                for (int g = 0; g < WG_GROUPS; ++g) {
+                    if (g + 1 < WG_GROUPS) read_frag(buf, g + 1, f[(g + 1) & 1]);
+                    mfma16(f[g & 1]);
+                }
+                __syncthreads();
+            }
+        }
+    } else if (nch > 0) {
         load_a();
         load_b();
         store_lds(0);
@@ -356,13 +417,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     }
 }
 
-template <int TM, int TN, int MODE>
+template <int TM, int TN, int MODE, int BKP>
 int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int lds = 2 * BKP * (BM + BN) * (int)sizeof(float);
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<TM, TN, MODE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<TM, TN, MODE, BKP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return HN_ELAUNCH;
         configured = true;
@@ -377,7 +438,7 @@ int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
         const int code = split_k;
         const int rounds = code == -2 ? 1 : code == -3 ? 3 : code == -4 ? 4 : code == -5 ? 6 : 2;
         split_k = (512 * rounds) / tiles;
-        const int cap = (total_chunks + 3) / 4;  // at least 4 reduction steps per split
+        const int cap = (total_chunks * BKP / 32 + 3) / 4;  // at least 128 pixels of reduction per split
         if (split_k > cap) split_k = cap;
         if (split_k < 1) split_k = 1;
     }
@@ -388,15 +449,15 @@ int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     if (a.atomic) {
         if (hipMemsetAsync(a.dw, 0, (size_t)a.K * a.Kdim * sizeof(float), stream) != hipSuccess) return HN_ELAUNCH;
     }
-    HN_LAUNCH((conv_wgrad_kernel<TM, TN, MODE>), dim3(tiles * split_k), dim3(256), lds, stream, a);
+    HN_LAUNCH((conv_wgrad_kernel<TM, TN, MODE, BKP>), dim3(tiles * split_k), dim3(256), lds, stream, a);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
 
-template <int MODE>
+template <int MODE, int BKP>
 int dispatch_wgrad(const WgradArgs& a, bool wide_m, bool wide_n, int split_k, hipStream_t s) {
-    if (wide_m) return wide_n ? launch_wgrad<2, 2, MODE>(a, split_k, s) : launch_wgrad<2, 1, MODE>(a, split_k, s);
-    return wide_n ? launch_wgrad<1, 2, MODE>(a, split_k, s) : launch_wgrad<1, 1, MODE>(a, split_k, s);
+    if (wide_m) return wide_n ? launch_wgrad<2, 2, MODE, BKP>(a, split_k, s) : launch_wgrad<2, 1, MODE, BKP>(a, split_k, s);
+    return wide_n ? launch_wgrad<1, 2, MODE, BKP>(a, split_k, s) : launch_wgrad<1, 1, MODE, BKP>(a, split_k, s);
 }
 
 }  // namespace
@@ -408,8 +469,9 @@ extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const
         d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->dil <= 0 || d->pad < 0 || d->ldx < d->Cin || d->ldy < d->Cout)
         return HN_EINVAL;
     if (variant < 0 || variant >= 48) return HN_EINVAL;
-    const int tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3;  // same encoding as hn_conv2d_fwd (K step unused)
-    if (tm_sel == 3 || tn_sel == 3) return HN_EINVAL;
+    // same encoding as hn_conv2d_fwd; the K-step field selects the pixel step (1 -> 32, 2 -> 16)
+    const int bk_sel = variant & 3, tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3;
+    if (bk_sel == 3 || tm_sel == 3 || tn_sel == 3) return HN_EINVAL;
     WgradArgs a;
     a.x = x; a.dy = dy; a.dw = dw;
     a.H = d->Hin; a.W = d->Win; a.C = d->Cin; a.ldx = d->ldx;
@@ -428,10 +490,16 @@ extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const
         bool wide_n = d->Cin % 128 == 0;
         if (tn_sel == 1) wide_n = false;  // a 128-wide column tile needs Cin % 128 == 0; 64 is always allowed here
         const bool buf_ok = a.x_bytes < 0xFFFF0000ll && a.dy_bytes + 64ll * d->ldy * 4 < 0xFFFF0000ll;
-        return buf_ok ? dispatch_wgrad<WG_VEC_BUF>(a, wide_m, wide_n, split_k, s)
-                      : dispatch_wgrad<WG_VEC>(a, wide_m, wide_n, split_k, s);
+        const bool p16 = bk_sel == 2;
+#ifdef HN_WG_DMA
+        if (buf_ok) return dispatch_wgrad<WG_VEC_DMA, 32>(a, wide_m, wide_n, split_k, s);  // experiment: LDS-DMA staging
+#endif
+        if (buf_ok)
+            return p16 ? dispatch_wgrad<WG_VEC_BUF, 16>(a, wide_m, wide_n, split_k, s)
+                       : dispatch_wgrad<WG_VEC_BUF, 32>(a, wide_m, wide_n, split_k, s);
+        return dispatch_wgrad<WG_VEC, 32>(a, wide_m, wide_n, split_k, s);
     }
     bool wide_n = a.Kdim > 64;
     if (tn_sel) wide_n = tn_sel == 2;
-    return dispatch_wgrad<WG_SCALAR>(a, wide_m, wide_n, split_k, s);
+    return dispatch_wgrad<WG_SCALAR, 32>(a, wide_m, wide_n, split_k, s);
 }

@@ -142,7 +142,7 @@ def _igemm_candidates(cout):
 def _wgrad_candidates(cout, cin):
     tms = (0, 1) if cout > 64 else (0,)
     tns = (0, 1) if cin % 128 == 0 else (0,)
-    return [(split, _variant(0, tm, tn)) for tm in tms for tn in tns for split in (0, -2, -3, -4, -5)]
+    return [(split, _variant(bk, tm, tn)) for tm in tms for tn in tns for bk in (1, 2) for split in (0, -2, -3, -4)]
 
 
 # ---- dgrad || wgrad overlap ----------------------------------------------------------------------------------------

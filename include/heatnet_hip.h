@@ -84,8 +84,8 @@ int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* ad
                     const HnConvDesc* d, int variant, void* stream);
 
 /* dw[Cout][KH][KW][Cin] = sum over pixels of dy (x) x.  Overwrites dw.  split_k > 0: that many reduction splits;
- * 0 / -1: fill two rounds of the chip's 512 resident workgroups; -2 / -3 / -4 / -5: one / three / four / six rounds.  `variant`: tile selection, encoded as for
- * hn_conv2d_fwd (K step field ignored). */
+ * 0 / -1: fill two rounds of the chip's 512 resident workgroups; -2 / -3 / -4 / -5: one / three / four / six rounds.  `variant`: encoded as for hn_conv2d_fwd (the
+ * K-step field selects 32 or 16 pixels per reduction step). */
 int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant,
                     void* stream);
 
