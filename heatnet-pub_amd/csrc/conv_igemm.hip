@@ -48,7 +48,10 @@ struct ConvArgs {
     int ldadd;
     int H, W, C, ldx;        // input tensor
     int Ho, Wo, K, ldy;      // output tensor (K = output channels)
-    int KH, KW, stride, pad, dil, in_dil;
+    int KH, KW, stride, pad, pad_w, dil, in_dil;  // pad = rows, pad_w = columns
+    // output mapping (parity classes of a stride-2 data gradient): output pixel (n, i, j) of this launch is pixel
+    // (n, ostep*i + oph, ostep*j + opw) of a tensor with oH x oW pixels per image; omap = 0 -> dense (identity)
+    int omap, oH, oW, ostep, oph, opw;
     int M, Kdim, ntm, ntn;
     int act;
     float slope;
@@ -85,18 +88,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 
     for (int r = tid; r < BM; r += 256) {
         const int m = m0 + r;
-        int hb = -0x40000000, wb = 0, nb = 0;  // rows past M: every tap lands out of range
+        int hb = -0x40000000, wb = 0, nb = 0, opix = 0;  // rows past M: every tap lands out of range
         if (m < p.M) {
             const int hw = p.Ho * p.Wo;
             const int n = m / hw, rem = m - n * hw;
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
             hb = ho * p.stride - p.pad;
-            wb = wo * p.stride - p.pad;
+            wb = wo * p.stride - p.pad_w;
             nb = n * p.H * p.W;
+            opix = p.omap ? (n * p.oH + p.ostep * ho + p.oph) * p.oW + p.ostep * wo + p.opw : m;
         }
         rowinfo[r * 4 + 0] = hb;
         rowinfo[r * 4 + 1] = wb;
         rowinfo[r * 4 + 2] = nb;
+        rowinfo[r * 4 + 3] = opix;
     }
     __syncthreads();
 
@@ -357,9 +362,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 
     // branch-free activation: out = v > 0 ? v : v * neg_slope  (none: 1, relu: 0, leaky/prelu: slope)
     const float neg_slope = p.act == HN_ACT_NONE ? 1.f : (p.act == HN_ACT_RELU ? 0.f : p.slope);
-    auto finish = [&](auto full_tag, auto add_tag) {
+    auto finish = [&](auto full_tag, auto add_tag, auto map_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr bool ADD = decltype(add_tag)::value;
+        constexpr bool OMAP = decltype(map_tag)::value;  // rows land on interleaved pixels (rowinfo[.][3])
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + (wn * TN + j) * 32 + lr;
@@ -374,10 +380,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
                     const int ro = (r & 3) + 8 * (r >> 2);
                     float v = acc[i][j][r];
                     if (FULL || (rbase + ro < p.M && cok)) {
-                        if constexpr (ADD) v += p.addend[(size_t)(rbase + ro) * p.ldadd + col];
-                        s1 += v;
-                        s2 += v * v;
-                        dst[(size_t)ro * p.ldy] = v > 0.f ? v : v * neg_slope;
+                        if constexpr (OMAP) {
+                            const size_t opix = (size_t)rowinfo[(rbase + ro - m0) * 4 + 3];
+                            if constexpr (ADD) v += p.addend[opix * p.ldadd + col];
+                            p.y[opix * p.ldy + col] = v;
+                        } else {
+                            if constexpr (ADD) v += p.addend[(size_t)(rbase + ro) * p.ldadd + col];
+                            s1 += v;
+                            s2 += v * v;
+                            dst[(size_t)ro * p.ldy] = v > 0.f ? v : v * neg_slope;
+                        }
                     }
                 }
             }
@@ -395,12 +407,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
             }
         }
     };
-    if (p.addend != nullptr) {  // data gradient joined by a skip-path gradient
-        if (full) finish(std::true_type{}, std::true_type{});
-        else finish(std::false_type{}, std::true_type{});
+    if (p.omap) {  // parity class of a strided data gradient (no activation / statistics on this path)
+        if (p.addend != nullptr) finish(std::false_type{}, std::true_type{}, std::true_type{});
+        else finish(std::false_type{}, std::false_type{}, std::true_type{});
+    } else if (p.addend != nullptr) {  // data gradient joined by a skip-path gradient
+        if (full) finish(std::true_type{}, std::true_type{}, std::false_type{});
+        else finish(std::false_type{}, std::true_type{}, std::false_type{});
     } else {
-        if (full) finish(std::true_type{}, std::false_type{});
-        else finish(std::false_type{}, std::false_type{});
+        if (full) finish(std::true_type{}, std::false_type{}, std::false_type{});
+        else finish(std::false_type{}, std::false_type{}, std::false_type{});
     }
 }
 
@@ -469,21 +484,83 @@ int check_desc(const HnConvDesc* d) {
     return HN_OK;
 }
 
-// wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci], one 32x32 (co, ci) tile per block through LDS.
-__global__ __launch_bounds__(256) void weight_flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt,
-                                                                   int Cout, int T, int Cin) {
+// Tap table of the data-gradient weight layout.  Stride 1 (or a stride the parity decomposition does not cover):
+// one block wt[Cin][T][Cout] with the taps flipped.  Stride 2, odd dilation: four consecutive blocks, one per
+// output-parity class (ph, pw) in the order (0,0) (0,1) (1,0) (1,1), block = [Cin][Th*Tw][Cout] holding only the taps
+// that reach that class, flipped within the class.
+struct TapTable {
+    int src[64];   // source tap index kh*KW+kw of destination slot z
+    int dst[64];   // float offset of element (ci = 0, slot, co = 0) of that slot
+    int row[64];   // floats between consecutive ci rows of the slot's block (T_class * Cout)
+    int count;
+};
+
+struct ClassGeom {
+    int k0, T, c;  // first tap, tap count, (ph + pad - k0*dil) / 2
+};
+
+inline ClassGeom class_geom(int K, int pad, int dil, int parity) {
+    ClassGeom g{0, 0, 0};
+    int first = -1;
+    for (int k = 0; k < K; ++k)
+        if (((parity + pad - k * dil) & 1) == 0) {
+            if (first < 0) first = k;
+            ++g.T;
+        }
+    g.k0 = first < 0 ? 0 : first;
+    g.c = first < 0 ? 0 : (parity + pad - g.k0 * dil) / 2;  // exact: numerator is even (may be negative)
+    return g;
+}
+
+inline bool parity_decomposable(int KH, int KW, int stride, int dil) {
+    return stride == 2 && (dil & 1) == 1 && KH * KW <= 64;
+}
+
+inline void build_tap_table(TapTable& t, int Cout, int KH, int KW, int Cin, int stride, int pad, int dil) {
+    const int T = KH * KW;
+    t.count = T;
+    if (!parity_decomposable(KH, KW, stride, dil)) {
+        for (int z = 0; z < T && z < 64; ++z) {
+            t.src[z] = T - 1 - z;
+            t.dst[z] = z * Cout;
+            t.row[z] = T * Cout;
+        }
+        return;
+    }
+    int slot = 0, base = 0;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            const ClassGeom gh = class_geom(KH, pad, dil, ph), gw = class_geom(KW, pad, dil, pw);
+            const int Tc = gh.T * gw.T;
+            for (int a = 0; a < gh.T; ++a)
+                for (int b = 0; b < gw.T; ++b) {  // (a, b) = flipped class-local tap
+                    const int kh = gh.k0 + 2 * (gh.T - 1 - a), kw = gw.k0 + 2 * (gw.T - 1 - b);
+                    t.src[slot] = kh * KW + kw;
+                    t.dst[slot] = base + (a * gw.T + b) * Cout;
+                    t.row[slot] = Tc * Cout;
+                    ++slot;
+                }
+            base += Cin * Tc * Cout;
+        }
+}
+
+// one 32x32 (co, ci) tile of one tap per block, transposed through LDS
+__global__ __launch_bounds__(256) void weight_taps_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                                   int Cout, int T, int Cin, TapTable t) {
     __shared__ float tile[32][33];
-    const int tap = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int z = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int src = t.src[z];
     for (int r = ty; r < 32; r += 8) {
         const int co = co0 + r, ci = ci0 + tx;
-        tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * T + tap) * Cin + ci] : 0.f;
+        tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * T + src) * Cin + ci] : 0.f;
     }
     __syncthreads();
-    const int ftap = T - 1 - tap;
+    float* out = wt + t.dst[z];
+    const int rowstride = t.row[z];
     for (int r = ty; r < 32; r += 8) {
         const int ci = ci0 + r, co = co0 + tx;
-        if (ci < Cin && co < Cout) wt[((size_t)ci * T + ftap) * Cout + co] = tile[tx][r];
+        if (ci < Cin && co < Cout) out[(size_t)ci * rowstride + co] = tile[tx][r];
     }
 }
 
@@ -499,7 +576,8 @@ extern "C" int hn_conv2d_fwd(const float* x, const float* w, const float* bias, 
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats; a.addend = nullptr; a.ldadd = 0;
     a.H = d->Hin; a.W = d->Win; a.C = d->Cin; a.ldx = d->ldx;
     a.Ho = d->Hout; a.Wo = d->Wout; a.K = d->Cout; a.ldy = d->ldy;
-    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.in_dil = 1;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = a.pad_w = d->pad; a.dil = d->dil; a.in_dil = 1;
+    a.omap = 0; a.oH = a.oW = a.oph = a.opw = 0; a.ostep = 1;
     a.M = d->N * d->Hout * d->Wout;
     a.Kdim = d->KH * d->KW * d->Cin;
     a.ntm = a.ntn = 0;
@@ -508,6 +586,8 @@ extern "C" int hn_conv2d_fwd(const float* x, const float* w, const float* bias, 
     return dispatch_conv(a, variant, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int hn_copy(const float* x, int ldx, float* y, int ldy, int64_t npix, int C, void* stream);
+
 extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* addend, int ldadd,
                                const HnConvDesc* d, int variant, void* stream) {
     if (dy == nullptr || wt == nullptr || dx == nullptr) return HN_EINVAL;
@@ -515,25 +595,81 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, cons
     const int rc = check_desc(d);
     if (rc != HN_OK) return rc;
     if (d->dil * (d->KH - 1) < d->pad || d->dil * (d->KW - 1) < d->pad) return HN_ESHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     ConvArgs a;
     a.x = dy; a.w = wt; a.bias = nullptr; a.y = dx; a.stats = nullptr; a.addend = addend; a.ldadd = ldadd;
     a.H = d->Hout; a.W = d->Wout; a.C = d->Cout; a.ldx = d->ldy;      // gathered tensor: dY
-    a.Ho = d->Hin; a.Wo = d->Win; a.K = d->Cin; a.ldy = d->ldx;        // produced tensor: dX
-    a.KH = d->KH; a.KW = d->KW; a.stride = 1; a.dil = d->dil; a.in_dil = d->stride;
-    a.pad = d->dil * (d->KH - 1) - d->pad;
-    a.M = d->N * d->Hin * d->Win;
-    a.Kdim = d->KH * d->KW * d->Cout;
+    a.K = d->Cin; a.ldy = d->ldx;                                     // produced tensor: dX
+    a.stride = 1; a.dil = d->dil;
     a.ntm = a.ntn = 0;
     a.act = HN_ACT_NONE; a.slope = 0.f;
     a.x_bytes = (((long long)d->N * d->Hout * d->Wout - 1) * d->ldy + d->Cout) * 4;
-    return dispatch_conv(a, variant, static_cast<hipStream_t>(stream));
+
+    if (!parity_decomposable(d->KH, d->KW, d->stride, d->dil)) {
+        // stride 1: a plain convolution of dY with the flipped taps; other strides: the same kernel gathering from the
+        // zero-dilated gradient (taps must land on multiples of the stride)
+        a.Ho = d->Hin; a.Wo = d->Win;
+        a.KH = d->KH; a.KW = d->KW; a.in_dil = d->stride;
+        a.pad = d->dil * (d->KH - 1) - d->pad;
+        a.pad_w = d->dil * (d->KW - 1) - d->pad;
+        a.M = d->N * d->Hin * d->Win;
+        a.Kdim = d->KH * d->KW * d->Cout;
+        a.omap = 0; a.oH = a.oW = a.oph = a.opw = 0; a.ostep = 1;
+        return dispatch_conv(a, variant, s);
+    }
+
+    // Stride 2: the pixels of dX split into four parity classes; class (ph, pw) only ever sees the taps with
+    // kh = ph + pad (mod 2), kw = pw + pad (mod 2), and over the class's own (Hin/2 x Win/2) grid that is a stride-1
+    // convolution of dY -- no multiply-adds against inserted zeros.
+    const ClassGeom gh[2] = {class_geom(d->KH, d->pad, d->dil, 0), class_geom(d->KH, d->pad, d->dil, 1)};
+    const ClassGeom gw[2] = {class_geom(d->KW, d->pad, d->dil, 0), class_geom(d->KW, d->pad, d->dil, 1)};
+    const bool some_empty = gh[0].T == 0 || gh[1].T == 0 || gw[0].T == 0 || gw[1].T == 0;
+    if (some_empty) {  // pixels no tap reaches: dX = addend or 0 there
+        const int64_t npix = (int64_t)d->N * d->Hin * d->Win;
+        if (addend != nullptr) {
+            if (addend != dx) {
+                const int rcc = hn_copy(addend, ldadd, dx, d->ldx, npix, d->Cin, stream);
+                if (rcc != HN_OK) return rcc;
+            }
+        } else if (d->ldx == d->Cin) {
+            if (hipMemsetAsync(dx, 0, (size_t)npix * d->Cin * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
+        } else {
+            return HN_ESHAPE;  // zero-filling a channel slice is not needed by any caller
+        }
+    }
+    long long wofs = 0;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            const int Th = gh[ph].T, Tw = gw[pw].T;
+            const long long wsize = (long long)d->Cin * Th * Tw * d->Cout;
+            const int Hc = (d->Hin - ph + 1) / 2, Wc = (d->Win - pw + 1) / 2;
+            if (Th > 0 && Tw > 0 && Hc > 0 && Wc > 0) {
+                ConvArgs c = a;
+                c.w = wt + wofs;
+                c.Ho = Hc; c.Wo = Wc;
+                c.KH = Th; c.KW = Tw; c.in_dil = 1;
+                c.pad = d->dil * (Th - 1) - gh[ph].c;
+                c.pad_w = d->dil * (Tw - 1) - gw[pw].c;
+                c.M = d->N * Hc * Wc;
+                c.Kdim = Th * Tw * d->Cout;
+                c.omap = 1; c.oH = d->Hin; c.oW = d->Win; c.ostep = 2; c.oph = ph; c.opw = pw;
+                const int rcc = dispatch_conv(c, variant, s);
+                if (rcc != HN_OK) return rcc;
+            }
+            wofs += wsize;
+        }
+    return HN_OK;
 }
 
-extern "C" int hn_weight_flip_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream) {
-    if (w == nullptr || wt == nullptr || Cout <= 0 || KH <= 0 || KW <= 0 || Cin <= 0) return HN_EINVAL;
+extern "C" int hn_weight_flip_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, int stride, int pad,
+                                        int dil, void* stream) {
+    if (w == nullptr || wt == nullptr || Cout <= 0 || KH <= 0 || KW <= 0 || Cin <= 0 || stride <= 0 || pad < 0 || dil <= 0)
+        return HN_EINVAL;
+    if (KH * KW > 64) return HN_ESHAPE;
+    TapTable t;
+    build_tap_table(t, Cout, KH, KW, Cin, stride, pad, dil);
     const dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, KH * KW);
-    HN_LAUNCH(weight_flip_transpose_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, wt, Cout,
-                       KH * KW, Cin);
+    HN_LAUNCH(weight_taps_transpose_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, wt, Cout, KH * KW, Cin, t);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

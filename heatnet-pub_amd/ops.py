@@ -263,7 +263,8 @@ class _Conv2d(torch.autograd.Function):
             fork.record()  # dy (and the activation backward that produced it) is complete up to here
         if ctx.needs_input_grad[0]:
             wt = torch.empty(cin * kh * kw * cout, device=x.device, dtype=torch.float32)
-            check(lib.hn_weight_flip_transpose(_ptr(w), _ptr(wt), cout, kh, kw, cin, s), "hn_weight_flip_transpose")
+            check(lib.hn_weight_flip_transpose(_ptr(w), _ptr(wt), cout, kh, kw, cin, stride, pad, dil, s),
+                  "hn_weight_flip_transpose")
             dx = new_nhwc(n, cin, h, wd, x.device)
             dd = _desc(n, h, wd, cin, cin, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
             var = _pick("dgrad", dd, _igemm_candidates(cin), lambda v: check(

@@ -72,8 +72,12 @@ int hn_version(void);
 int hn_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, double* stats,
                   const HnConvDesc* d, int act, float slope, int variant, void* stream);
 
-/* wt[Cin][KH][KW][Cout] = w[Cout][KH-1-kh][KW-1-kw][Cin]: operand of hn_conv2d_dgrad. */
-int hn_weight_flip_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
+/* Operand of hn_conv2d_dgrad for a convolution with this stride / pad / dilation (same element count as w).
+ * Stride 1: wt[Cin][KH][KW][Cout] = w[Cout][KH-1-kh][KW-1-kw][Cin].  Stride 2 with odd dilation: four consecutive blocks,
+ * one per parity class (ph, pw) of the input pixels, each [Cin][Th*Tw][Cout] with only the taps that reach the class --
+ * the data gradient then runs as four small stride-1 convolutions with no arithmetic on inserted zeros. */
+int hn_weight_flip_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, int stride, int pad, int dil,
+                             void* stream);
 
 /* dx = conv_transpose(dy, w) [+ addend] for the forward geometry `d` (dy is N x Hout x Wout x Cout with pixel stride
  * d->ldy, dx is N x Hin x Win x Cin with pixel stride d->ldx); `wt` from hn_weight_flip_transpose.  `addend`
