@@ -52,6 +52,10 @@ struct ConvArgs {
     // output mapping (parity classes of a stride-2 data gradient): output pixel (n, i, j) of this launch is pixel
     // (n, ostep*i + oph, ostep*j + opw) of a tensor with oH x oW pixels per image; omap = 0 -> dense (identity)
     int omap, oH, oW, ostep, oph, opw;
+    // split-K (launches with few output tiles but a long reduction): K steps per split, 0 = no split.  Split launches
+    // add into a pre-initialised output with global_atomic_add_f32 and leave bias / activation / statistics to a
+    // follow-up pass.
+    int cps;
     int M, Kdim, ntm, ntn;
     int act;
     float slope;
@@ -83,7 +87,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int logical = hn_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = logical % p.ntn, tile_m = logical / p.ntn;
+    const int ntiles = p.ntm * p.ntn;
+    const int split = logical / ntiles, tile = logical - split * ntiles;
+    const int tile_n = tile % p.ntn, tile_m = tile / p.ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     for (int r = tid; r < BM; r += 256) {
@@ -274,7 +280,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int lr = lane & 31, lh = lane >> 5;
-    const int nchunks = (p.Kdim + BK - 1) / BK;
+    const int total_chunks = (p.Kdim + BK - 1) / BK;
+    const int kc_first = p.cps > 0 ? split * p.cps : 0;
+    const int nchunks = p.cps > 0 ? min(p.cps, total_chunks - kc_first) : total_chunks;  // >= 1 by construction
+    st_k0 = kc_first * BK;
+    if constexpr (VEC) {
+        const int tap0 = st_k0 / p.C;
+        st_c0 = st_k0 - tap0 * p.C;
+        st_kh = tap0 / p.KW;
+        st_kw = tap0 - st_kh * p.KW;
+    }
 
     // Fragments are double-buffered in registers: the ds_read_b128s of group g+1 are issued before the 16 MFMAs of
     // group g, so LDS latency is exposed once per K step (after the barrier) instead of once per group.
@@ -346,6 +361,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     // The bias is loaded unconditionally (clamped index) and folded in BEFORE any store is issued, and full tiles
     // take a branch-free path: a conditional load inside the store loop makes hipcc wait vmcnt(0) -- i.e. for the
     // previous store -- in front of every store.
+    if (p.cps > 0) {  // split-K partial: accumulate into the pre-initialised output
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + lr;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M && col < p.K) {
+                        const size_t opix = p.omap ? (size_t)rowinfo[(row - m0) * 4 + 3] : (size_t)row;
+                        atomicAdd(p.y + opix * p.ldy + col, acc[i][j][r]);
+                    }
+                }
+            }
+        }
+        return;
+    }
     const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.K);
     float bias_v[TN];
 #pragma unroll
@@ -433,7 +467,13 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     ConvArgs p = a;
     p.ntm = (a.M + BM - 1) / BM;
     p.ntn = (a.K + BN - 1) / BN;
-    HN_LAUNCH((conv_igemm_kernel<TM, TN, MODE, BK>), dim3(p.ntm * p.ntn), dim3(256), lds, stream, p);
+    int splits = 1;
+    if (a.cps > 0) {  // a.cps is expressed in 32-wide K steps; rescale to this instantiation's step
+        const int total = (a.Kdim + BK - 1) / BK;
+        p.cps = a.cps * 32 / BK;
+        splits = (total + p.cps - 1) / p.cps;
+    }
+    HN_LAUNCH((conv_igemm_kernel<TM, TN, MODE, BK>), dim3(p.ntm * p.ntn * splits), dim3(256), lds, stream, p);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -457,6 +497,7 @@ int dispatch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
     const long blocks128 = (long)((a.M + 127) / 128) * ((a.K + (wide ? 127 : 63)) / (wide ? 128 : 64));
     bool tall = blocks128 >= 256;  // enough 128-row tiles to cover the chip; else halve the tile
     if (tm_sel) tall = tm_sel == 2;
+    if (a.cps > 0) tall = false;   // split-K plans are made for 64-row tiles (plan_split_k)
     const bool strided = a.in_dil > 1;
     const bool bk16 = bk_sel == 2;
     // buffer path: offsets are 32-bit relative to the first image a tile touches (a tile may reach into the next
@@ -468,6 +509,29 @@ int dispatch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
         return bk16 ? dispatch_tile<MODE_VEC_BUF, 16>(a, tall, wide, stream) : dispatch_tile<MODE_VEC_BUF, 32>(a, tall, wide, stream);
     if (vec) return strided ? dispatch_tile<MODE_VEC_STRIDED, 32>(a, tall, wide, stream) : dispatch_tile<MODE_VEC, 32>(a, tall, wide, stream);
     return strided ? dispatch_tile<MODE_SCALAR_STRIDED, 32>(a, tall, wide, stream) : dispatch_tile<MODE_SCALAR, 32>(a, tall, wide, stream);
+}
+
+// Split-K plan: K steps (of 32) per split, or 0.  Used when the output has so few tiles that the chip would idle
+// (pyramid levels, critic tails: a few hundred pixels) while the reduction is long.
+int plan_split_k(int M, int K, int Kdim) {
+    if (M > 2048) return 0;
+    const int total = (Kdim + 31) / 32;
+    if (total < 8) return 0;
+    const int tiles = ((M + 63) / 64) * ((K + (K > 64 ? 127 : 63)) / (K > 64 ? 128 : 64));
+    int splits = 512 / tiles;
+    if (splits > total / 4) splits = total / 4;
+    if (splits < 2) return 0;
+    return (total + splits - 1) / splits;
+}
+
+// y = act(y + bias[c]) over npix x C (after a split-K accumulation)
+__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, int ld, const float* __restrict__ bias, int npix,
+                                                      int C, float neg_slope) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * C) return;
+    const int pix = idx / C, c = idx - pix * C;
+    float v = y[(size_t)pix * ld + c] + (bias != nullptr ? bias[c] : 0.f);
+    y[(size_t)pix * ld + c] = v > 0.f ? v : v * neg_slope;
 }
 
 int check_desc(const HnConvDesc* d) {
@@ -577,16 +641,42 @@ extern "C" int hn_conv2d_fwd(const float* x, const float* w, const float* bias, 
     a.H = d->Hin; a.W = d->Win; a.C = d->Cin; a.ldx = d->ldx;
     a.Ho = d->Hout; a.Wo = d->Wout; a.K = d->Cout; a.ldy = d->ldy;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = a.pad_w = d->pad; a.dil = d->dil; a.in_dil = 1;
-    a.omap = 0; a.oH = a.oW = a.oph = a.opw = 0; a.ostep = 1;
+    a.omap = 0; a.oH = a.oW = a.oph = a.opw = 0; a.ostep = 1; a.cps = 0;
     a.M = d->N * d->Hout * d->Wout;
     a.Kdim = d->KH * d->KW * d->Cin;
     a.ntm = a.ntn = 0;
     a.act = act; a.slope = slope;
     a.x_bytes = (((long long)d->N * d->Hin * d->Win - 1) * d->ldx + d->Cin) * 4;
-    return dispatch_conv(a, variant, static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    a.cps = (d->ldy == d->Cout) ? plan_split_k(a.M, a.K, a.Kdim) : 0;
+    if (a.cps == 0) return dispatch_conv(a, variant, s);
+    // split-K: zero y, accumulate partial products, then bias / activation and (for BatchNorm) the statistics
+    if (hipMemsetAsync(y, 0, (size_t)a.M * a.K * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
+    a.bias = nullptr; a.stats = nullptr; a.act = HN_ACT_NONE;
+    const int rcs = dispatch_conv(a, variant & ~3, s);
+    if (rcs != HN_OK) return rcs;
+    if (bias != nullptr || act != HN_ACT_NONE) {
+        const float neg_slope = act == HN_ACT_NONE ? 1.f : (act == HN_ACT_RELU ? 0.f : slope);
+        HN_LAUNCH(bias_act_kernel, dim3((a.M * a.K + 255) / 256), dim3(256), 0, s, y, d->ldy, bias, a.M, a.K, neg_slope);
+        HN_CHECK_LAUNCH();
+    }
+    if (stats != nullptr) {
+        if (act != HN_ACT_NONE) return HN_EINVAL;  // statistics are defined on the pre-activation output
+        return hn_channel_stats(y, d->ldy, a.M, a.K, stats, stream);
+    }
+    return HN_OK;
 }
 
-extern "C" int hn_copy(const float* x, int ldx, float* y, int ldy, int64_t npix, int C, void* stream);
+namespace {
+// dX = addend, or zero: what the accumulating (split-K / partially covered) data-gradient paths start from
+int init_output(float* dx, int ldx, const float* addend, int ldadd, int64_t npix, int C, void* stream) {
+    if (addend != nullptr) return addend == dx ? HN_OK : hn_copy(addend, ldadd, dx, ldx, npix, C, stream);
+    if (ldx != C) return HN_ESHAPE;  // zero-filling a channel slice is not needed by any caller
+    if (hipMemsetAsync(dx, 0, (size_t)npix * C * sizeof(float), static_cast<hipStream_t>(stream)) != hipSuccess)
+        return HN_ELAUNCH;
+    return HN_OK;
+}
+}  // namespace
 
 extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* addend, int ldadd,
                                const HnConvDesc* d, int variant, void* stream) {
@@ -615,6 +705,13 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, cons
         a.M = d->N * d->Hin * d->Win;
         a.Kdim = d->KH * d->KW * d->Cout;
         a.omap = 0; a.oH = a.oW = a.oph = a.opw = 0; a.ostep = 1;
+        a.cps = (d->ldx == d->Cin && d->stride == 1) ? plan_split_k(a.M, a.K, a.Kdim) : 0;
+        if (a.cps > 0) {  // split-K partials add into dX, which therefore starts as the addend (or zero)
+            const int rci = init_output(dx, d->ldx, addend, ldadd, (int64_t)a.M, d->Cin, stream);
+            if (rci != HN_OK) return rci;
+            a.addend = nullptr;
+            variant &= ~3;
+        }
         return dispatch_conv(a, variant, s);
     }
 
@@ -624,18 +721,16 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, cons
     const ClassGeom gh[2] = {class_geom(d->KH, d->pad, d->dil, 0), class_geom(d->KH, d->pad, d->dil, 1)};
     const ClassGeom gw[2] = {class_geom(d->KW, d->pad, d->dil, 0), class_geom(d->KW, d->pad, d->dil, 1)};
     const bool some_empty = gh[0].T == 0 || gh[1].T == 0 || gw[0].T == 0 || gw[1].T == 0;
-    if (some_empty) {  // pixels no tap reaches: dX = addend or 0 there
-        const int64_t npix = (int64_t)d->N * d->Hin * d->Win;
-        if (addend != nullptr) {
-            if (addend != dx) {
-                const int rcc = hn_copy(addend, ldadd, dx, d->ldx, npix, d->Cin, stream);
-                if (rcc != HN_OK) return rcc;
-            }
-        } else if (d->ldx == d->Cin) {
-            if (hipMemsetAsync(dx, 0, (size_t)npix * d->Cin * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
-        } else {
-            return HN_ESHAPE;  // zero-filling a channel slice is not needed by any caller
-        }
+    // split-K when the classes are tiny (critic tails): every class then ADDS into a pre-initialised dX
+    const int Mc = d->N * ((d->Hin + 1) / 2) * ((d->Win + 1) / 2);
+    const bool split = d->ldx == d->Cin && plan_split_k(Mc, d->Cin, gh[1].T * gw[1].T * d->Cout) > 0;
+    if (some_empty || split) {  // pixels no tap reaches, or accumulation target: dX = addend or 0
+        const int rci = init_output(dx, d->ldx, addend, ldadd, (int64_t)d->N * d->Hin * d->Win, d->Cin, stream);
+        if (rci != HN_OK) return rci;
+    }
+    if (split) {
+        a.addend = nullptr;
+        variant &= ~3;
     }
     long long wofs = 0;
     for (int ph = 0; ph < 2; ++ph)
@@ -653,6 +748,11 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, cons
                 c.M = d->N * Hc * Wc;
                 c.Kdim = Th * Tw * d->Cout;
                 c.omap = 1; c.oH = d->Hin; c.oW = d->Win; c.ostep = 2; c.oph = ph; c.opw = pw;
+                c.cps = 0;
+                if (split) {
+                    c.cps = plan_split_k(c.M, c.K, c.Kdim);
+                    if (c.cps == 0) c.cps = (c.Kdim + 31) / 32;  // one split, but through the accumulating epilogue
+                }
                 const int rcc = dispatch_conv(c, variant, s);
                 if (rcc != HN_OK) return rcc;
             }
