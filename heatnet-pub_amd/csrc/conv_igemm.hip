@@ -271,15 +271,36 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     };
 
     // ---- main loop ---------------------------------------------------------------------------------------
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const int lr = lane & 31, lh = lane >> 5;
+    // Accumulators start at zero -- or at the addend (a gradient that reached this tensor through another branch): its
+    // loads are issued here, ahead of the operand prologue, and their latency disappears behind the first K steps, so
+    // the epilogue stays a pure store loop.  The addend never overlaps the output (header contract).
+    f32x16 acc[TM][TN];
+    if (p.addend != nullptr && p.cps == 0) {
+        const float* __restrict__ add = p.addend;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + lr;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rloc = (wm * TM + i) * 32 + 4 * lh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rloc + (r & 3) + 8 * (r >> 2);
+                    float v = 0.f;
+                    if (m0 + row < p.M && col < p.K) v = add[(size_t)rowinfo[row * 4 + 3] * p.ldadd + col];
+                    acc[i][j][r] = v;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
     const int total_chunks = (p.Kdim + BK - 1) / BK;
     const int kc_first = p.cps > 0 ? split * p.cps : 0;
     const int nchunks = p.cps > 0 ? min(p.cps, total_chunks - kc_first) : total_chunks;  // >= 1 by construction
@@ -396,9 +417,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 
     // branch-free activation: out = v > 0 ? v : v * neg_slope  (none: 1, relu: 0, leaky/prelu: slope)
     const float neg_slope = p.act == HN_ACT_NONE ? 1.f : (p.act == HN_ACT_RELU ? 0.f : p.slope);
-    auto finish = [&](auto full_tag, auto add_tag, auto map_tag) {
+    auto finish = [&](auto full_tag, auto map_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
-        constexpr bool ADD = decltype(add_tag)::value;
         constexpr bool OMAP = decltype(map_tag)::value;  // rows land on interleaved pixels (rowinfo[.][3])
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -408,18 +428,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
-                float* dst = p.y + (size_t)rbase * p.ldy + col;
+                float* __restrict__ dst = p.y + (size_t)rbase * p.ldy + col;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ro = (r & 3) + 8 * (r >> 2);
-                    float v = acc[i][j][r];
+                    const float v = acc[i][j][r];
                     if (FULL || (rbase + ro < p.M && cok)) {
                         if constexpr (OMAP) {
                             const size_t opix = (size_t)rowinfo[(rbase + ro - m0) * 4 + 3];
-                            if constexpr (ADD) v += p.addend[opix * p.ldadd + col];
                             p.y[opix * p.ldy + col] = v;
                         } else {
-                            if constexpr (ADD) v += p.addend[(size_t)(rbase + ro) * p.ldadd + col];
                             s1 += v;
                             s2 += v * v;
                             dst[(size_t)ro * p.ldy] = v > 0.f ? v : v * neg_slope;
@@ -442,14 +460,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         }
     };
     if (p.omap) {  // parity class of a strided data gradient (no activation / statistics on this path)
-        if (p.addend != nullptr) finish(std::false_type{}, std::true_type{}, std::true_type{});
-        else finish(std::false_type{}, std::false_type{}, std::true_type{});
-    } else if (p.addend != nullptr) {  // data gradient joined by a skip-path gradient
-        if (full) finish(std::true_type{}, std::true_type{}, std::false_type{});
-        else finish(std::false_type{}, std::true_type{}, std::false_type{});
+        finish(std::false_type{}, std::true_type{});
+    } else if (full) {
+        finish(std::true_type{}, std::false_type{});
     } else {
-        if (full) finish(std::true_type{}, std::false_type{}, std::false_type{});
-        else finish(std::false_type{}, std::false_type{}, std::false_type{});
+        finish(std::false_type{}, std::false_type{});
     }
 }
 

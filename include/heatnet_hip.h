@@ -81,7 +81,7 @@ int hn_weight_flip_transpose(const float* w, float* wt, int Cout, int KH, int KW
 
 /* dx = conv_transpose(dy, w) [+ addend] for the forward geometry `d` (dy is N x Hout x Wout x Cout with pixel stride
  * d->ldy, dx is N x Hin x Win x Cin with pixel stride d->ldx); `wt` from hn_weight_flip_transpose.  `addend`
- * (optional, pixel stride ldadd, may alias dx) is a gradient that reached the same tensor through another branch --
+ * (optional, pixel stride ldadd, must not overlap dx) is a gradient that reached the same tensor through another branch --
  * the residual skip of cm/models/extractors.py:96-99 -- and is added in the epilogue instead of by a separate pass.
  * Overwrites dx. */
 int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* addend, int ldadd,
