@@ -249,4 +249,5 @@ extern "C" const char* hn_strerror(int code) {
     }
 }
 
-extern "C" int hn_version(void) { return 1; }
+// bumped whenever kernel tilings / variants change (invalidates heatnet-pub_amd/tune_cache.json)
+extern "C" int hn_version(void) { return 3; }

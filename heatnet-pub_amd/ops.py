@@ -102,6 +102,48 @@ def _desc(n, h, w, cin, ldx, ho, wo, cout, ldy, kh, kw, stride, pad, dil):
 # and the winner is cached.  HEATNET_AUTOTUNE=0 keeps the library's built-in heuristics.
 AUTOTUNE = os.environ.get("HEATNET_AUTOTUNE", "1") != "0"
 _variant_cache = {}
+# Choices persist across processes in a small JSON file (geometry -> variant) so that later runs, and profiled runs,
+# contain no candidate-timing launches.  HEATNET_TUNE_CACHE overrides the location; an unreadable / unwritable file is
+# simply ignored.  Only rank 0 writes.
+_TUNE_FILE = os.environ.get("HEATNET_TUNE_CACHE") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                  "tune_cache.json")
+_tune_dirty = False
+
+
+def _load_tune_cache():
+    import json
+    try:
+        with open(_TUNE_FILE) as f:
+            data = json.load(f)
+        if data.pop("_version", None) != _lib.load().hn_version():
+            return  # timings of another kernel generation
+        for k, v in data.items():
+            if True:
+                key = tuple(int(x) if x.lstrip("-").isdigit() else x for x in k.split(","))
+                _variant_cache[key] = tuple(v) if isinstance(v, list) else v
+    except (OSError, ValueError, RuntimeError):
+        pass
+
+
+def _save_tune_cache():
+    import json
+    if not _tune_dirty or os.environ.get("RANK", "0") != "0":
+        return
+    try:
+        data = {",".join(str(x) for x in k): (list(v) if isinstance(v, tuple) else v) for k, v in _variant_cache.items()}
+        data["_version"] = _lib.load().hn_version()
+        tmp = _TUNE_FILE + ".tmp.%d" % os.getpid()
+        with open(tmp, "w") as f:
+            json.dump(data, f, indent=0, sort_keys=True)
+        os.replace(tmp, _TUNE_FILE)
+    except OSError:
+        pass
+
+
+if AUTOTUNE:
+    import atexit
+    _load_tune_cache()
+    atexit.register(_save_tune_cache)
 
 
 def _variant(bk=0, tm=0, tn=0):
@@ -130,7 +172,9 @@ def _pick(kind, d, candidates, launch):
     best = min(candidates, key=lambda c: times[c])
     if times[best] > 0.97 * times[candidates[0]]:
         best = candidates[0]
+    global _tune_dirty
     _variant_cache[key] = best
+    _tune_dirty = True
     return best
 
 
