@@ -148,3 +148,34 @@ def test_checkpoint_interchange_with_reference_format(tmp_path):
     torch.save(mine.state_dict(), str(snap))
     net = build_net.build_network(str(snap), "resnet50", in_channels=4, late_fusion=True)
     assert torch.equal(net.state_dict()["final.0.bias"].cpu(), state["final.0.bias"])
+
+
+def test_phase_schedule_matches_oracle():
+    """train_trgb_segnet_conf.py:361-367,577-592: critic warm-up, then alternating seg / critic phases."""
+    from heatnet_amd.train_step import PhaseSchedule
+    from oracle import heatnet_ref as R
+    a, b = PhaseSchedule(initial_critic=5, seg=3, critic=4), R.PhaseSchedule(initial_critic=5, seg=3, critic=4)
+    for _ in range(40):
+        assert a.state == b.state
+        assert a.tick() == b.tick()
+    c = PhaseSchedule(no_conf=True)
+    assert c.state == "train_seg" and not c.tick() and c.state == "train_seg"
+
+
+def test_flat_arena_layout_on_cpu():
+    """ParamArena: 256-B slots, parameter views keep their strides, gradients are views of one flat buffer."""
+    from heatnet_amd import optim
+    from heatnet_amd.critics import FCDiscriminator
+    net = FCDiscriminator(13)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    arena = optim.ParamArena(list(net.parameters()))
+    assert all(off % 64 == 0 for off in arena.offsets) and arena.numel % 64 == 0
+    assert all(torch.equal(v, before[k]) for k, v in net.state_dict().items())
+    assert net.conv1.weight.is_contiguous(memory_format=torch.channels_last)
+    for p in net.parameters():
+        assert p.grad is not None and p.grad.stride() == p.stride()
+    arena.check()
+    net.conv1.weight.grad.fill_(1.0)
+    assert float(arena.grad.sum()) == net.conv1.weight.numel()
+    groups = optim.arenas_for(net)
+    assert len(groups) == 1

@@ -331,3 +331,29 @@ def test_optimizer_steps(dev):
         opt2.step()
         ops.adam_step_(pd2, g.to(dev), m, v, step, 1e-3)
     close(pd2, pr2, atol=1e-6, rtol=1e-5, what="adam")
+
+
+def test_c_abi_rejects_bad_arguments(dev):
+    """Error behaviour of the C ABI: negative HN_E* codes, nothing thrown, nothing launched."""
+    import ctypes
+    from heatnet_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros(1, 8, 8, 64, device=dev)
+    w = torch.zeros(64, 1, 1, 64, device=dev)
+    y = torch.zeros(1, 8, 8, 64, device=dev)
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    good = _lib.HnConvDesc(1, 8, 8, 64, 64, 8, 8, 64, 64, 1, 1, 1, 0, 1)
+    assert lib.hn_conv2d_fwd(P(x), P(w), None, P(y), None, ctypes.byref(good), 0, 0.0, 0, s) == 0
+    assert lib.hn_conv2d_fwd(None, P(w), None, P(y), None, ctypes.byref(good), 0, 0.0, 0, s) == -1      # HN_EINVAL
+    assert lib.hn_conv2d_fwd(P(x), P(w), None, P(y), None, ctypes.byref(good), 7, 0.0, 0, s) == -1      # bad activation
+    assert lib.hn_conv2d_fwd(P(x), P(w), None, P(y), None, ctypes.byref(good), 0, 0.0, 99, s) == -1     # bad variant
+    bad_shape = _lib.HnConvDesc(1, 8, 8, 64, 64, 7, 8, 64, 64, 1, 1, 1, 0, 1)                           # Hout inconsistent
+    assert lib.hn_conv2d_fwd(P(x), P(w), None, P(y), None, ctypes.byref(bad_shape), 0, 0.0, 0, s) == -4  # HN_ESHAPE
+    bad_ld = _lib.HnConvDesc(1, 8, 8, 64, 32, 8, 8, 64, 64, 1, 1, 1, 0, 1)                              # ldx < Cin
+    assert lib.hn_conv2d_fwd(P(x), P(w), None, P(y), None, ctypes.byref(bad_ld), 0, 0.0, 0, s) == -1
+    assert lib.hn_bn_act_fwd(P(x), 64, None, None, None, 0, P(y), 64, 64, 64, 1, None, 0.0, s) == -1
+    assert lib.hn_ce_fwd(P(x), 64, P(y), 64, 64, -100, P(y), s) == -1                                   # C > 32 classes
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        _lib.check(-1, "probe")
+    torch.cuda.synchronize()
