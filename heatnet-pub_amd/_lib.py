@@ -32,10 +32,11 @@ SIGNATURES = {
     "hn_channel_stats": [P, c_int, c_i64, c_int, P, P],
     "hn_bn_finalize": [P, c_i64, P, P, P, P, c_float, c_float, P, P, P, P, c_int, P],
     "hn_bn_eval_params": [P, P, P, P, c_float, P, P, P, P, c_int, P],
-    "hn_bn_act_fwd": [P, c_int, P, P, P, c_int, P, c_int, c_i64, c_int, c_int, P, c_float, P],
-    "hn_bn_act_bwd_reduce": [P, c_int, P, c_int, P, c_int, P, P, P, P, c_i64, c_int, c_int, P, c_float, P, P, P],
+    "hn_bn_act_fwd": [P, c_int, P, P, P, c_int, P, c_int, c_i64, c_int, c_int, P, c_float, P, c_i64, P],
+    "hn_bn_act_bwd_reduce": [P, c_int, P, c_int, P, c_int, P, P, P, P, c_i64, c_int, c_int, P, c_float, P, P, P, c_i64,
+                             P],
     "hn_bn_act_bwd_apply": [P, c_int, P, c_int, P, c_int, P, P, P, P, P, P, c_i64, c_int, P, c_int, P, c_int,
-                            c_i64, c_int, c_int, P, c_float, P],
+                            c_i64, c_int, c_int, P, c_float, P, c_i64, P],
     "hn_act_bwd": [P, c_int, P, c_int, P, c_int, c_i64, c_int, c_int, c_float, P],
     "hn_scale_nc": [P, c_int, P, P, c_int, c_int, c_i64, c_int, P],
     "hn_add": [P, c_int, P, c_int, P, c_int, c_i64, c_int, P],
@@ -47,6 +48,7 @@ SIGNATURES = {
     "hn_bilinear_fwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_bilinear_bwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_pyramid_merge_fwd": [P, c_int, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "hn_pyramid_pool_bwd": [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "hn_ce_fwd": [P, c_int, P, c_i64, c_int, c_i64, P, P],
     "hn_ce_bwd": [P, c_int, P, c_i64, c_int, c_i64, P, P, P, c_int, P],
     "hn_adv_loss_fwd": [P, c_i64, c_float, c_int, P, P],

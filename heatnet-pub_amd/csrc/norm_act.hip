@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ res, int ldr, float* __restrict__ z,
                                                         int ldz, int64_t npix, int C, int act, const float* slope_p,
-                                                        float leaky) {
+                                                        float leaky, const float* __restrict__ mask, int64_t hw) {
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (c >= C) return;
     float sc[V], sh[V];
@@ -89,14 +89,16 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     ldv<V>(shift + c, sh);
     const float slope = act == HN_ACT_PRELU ? *slope_p : leaky;
     for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
-        float v[V], r[V], o[V];
+        float v[V], r[V], o[V], m[V];
         ldv<V>(y + pix * ldy + c, v);
         if (res != nullptr) ldv<V>(res + pix * ldr + c, r);
+        if (mask != nullptr) ldv<V>(mask + (pix / hw) * C + c, m);  // Dropout2d keep/(1-p) factor of (image, channel)
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             float u = v[i] * sc[i] + sh[i];
             if (res != nullptr) u += r[i];
             o[i] = hn_apply_act(u, act, slope);
+            if (mask != nullptr) o[i] *= m[i];
         }
         stv<V>(z + pix * ldz + c, o);
     }
@@ -110,7 +112,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                int64_t npix, int C, int act, const float* slope_p, float leaky,
-                                                               double* __restrict__ sums) {
+                                                               double* __restrict__ sums, const float* __restrict__ mask,
+                                                               int64_t hw) {
     __shared__ double red[2 * 256 * 4 + 256];
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     const bool live = c < C;
@@ -135,6 +138,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
             float ds = 0.f;
             ldv<V>(dz + pix * lddz + c, g);
             ldv<V>(y + pix * ldy + c, yy);
+            if (mask != nullptr) {
+                float m[V];
+                ldv<V>(mask + (pix / hw) * C + c, m);
+#pragma unroll
+                for (int i = 0; i < V; ++i) g[i] *= m[i];
+            }
             if (zmask) ldv<V>(z + pix * ldz + c, zz);
             else {
 #pragma unroll
@@ -207,7 +216,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
                                                               const float* __restrict__ shift, const float* __restrict__ dparams,
                                                               float inv_count, int training, float* __restrict__ dy, int lddy,
                                                               float* __restrict__ dres, int lddr, int64_t npix, int C, int act,
-                                                              const float* slope_p, float leaky) {
+                                                              const float* slope_p, float leaky, const float* __restrict__ mask,
+                                                              int64_t hw) {
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (c >= C) return;
     float sc[V], sh[V], mu[V], is[V], ga[V], m1[V], m2[V];
@@ -230,6 +240,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
         float g[V], zz[V], yy[V], du[V], o[V];
         ldv<V>(dz + pix * lddz + c, g);
         ldv<V>(y + pix * ldy + c, yy);
+        if (mask != nullptr) {
+            float m[V];
+            ldv<V>(mask + (pix / hw) * C + c, m);
+#pragma unroll
+            for (int i = 0; i < V; ++i) g[i] *= m[i];
+        }
         if (zmask) ldv<V>(z + pix * ldz + c, zz);
         else {
 #pragma unroll
@@ -443,12 +459,14 @@ extern "C" int hn_bn_eval_params(const float* gamma, const float* beta, const fl
 
 extern "C" int hn_bn_act_fwd(const float* y, int ldy, const float* scale, const float* shift, const float* residual,
                              int ldr, float* z, int ldz, int64_t npix, int C, int act, const float* slope,
-                             float leaky_slope, void* stream) {
+                             float leaky_slope, const float* mask, int64_t hw, void* stream) {
     if (!y || !scale || !shift || !z || act < 0 || act > 3 || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
+    if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
     if (bad_rows(npix, C, {ldy, ldz}) || (residual && ldr < C)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const RowLaunch pl = plan_rows(npix, C, {y, z, residual, scale, shift}, {ldy, ldz, residual ? ldr : 4});
-    HN_LAUNCH_V(pl, bn_act_fwd_kernel, y, ldy, scale, shift, residual, ldr, z, ldz, npix, C, act, slope, leaky_slope);
+    const RowLaunch pl = plan_rows(npix, C, {y, z, residual, scale, shift, mask}, {ldy, ldz, residual ? ldr : 4});
+    HN_LAUNCH_V(pl, bn_act_fwd_kernel, y, ldy, scale, shift, residual, ldr, z, ldz, npix, C, act, slope, leaky_slope, mask,
+                hw);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -456,8 +474,9 @@ extern "C" int hn_bn_act_fwd(const float* y, int ldy, const float* scale, const 
 extern "C" int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                                     const float* mean, const float* invstd, const float* scale, const float* shift,
                                     int64_t npix, int C, int act, const float* slope, float leaky_slope, double* sums,
-                                    float* dparams, void* stream) {
+                                    float* dparams, const float* mask, int64_t hw, void* stream) {
     if (!dz || !y || !mean || !invstd || !scale || !shift || !sums || !dparams || act < 0 || act > 3) return HN_EINVAL;
+    if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
     if (act == HN_ACT_PRELU && !slope) return HN_EINVAL;
     if (bad_rows(npix, C, {lddz, ldy}) || (z && ldz < C)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -465,7 +484,7 @@ extern "C" int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, i
     const RowLaunch pl = plan_rows(npix, C, {dz, y, zmask ? z : nullptr, mean, invstd, scale, shift},
                                    {lddz, ldy, zmask ? ldz : 4}, 2048);
     HN_LAUNCH_V(pl, bn_act_bwd_reduce_kernel, dz, lddz, z, ldz, y, ldy, mean, invstd, scale, shift, npix, C, act, slope,
-                leaky_slope, sums);
+                leaky_slope, sums, mask, hw);
     HN_CHECK_LAUNCH();
     HN_LAUNCH(f64_to_f32_reset_kernel, dim3((2 * C + 1 + 255) / 256), dim3(256), 0, s, sums, dparams, 2 * C + 1);
     HN_CHECK_LAUNCH();
@@ -476,8 +495,9 @@ extern "C" int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, in
                                    const float* mean, const float* invstd, const float* gamma, const float* scale,
                                    const float* shift, const float* dparams, int64_t count, int training, float* dy,
                                    int lddy, float* dres, int lddr, int64_t npix, int C, int act, const float* slope,
-                                   float leaky_slope, void* stream) {
+                                   float leaky_slope, const float* mask, int64_t hw, void* stream) {
     if (!dz || !y || !mean || !invstd || !gamma || !scale || !shift || !dy || act < 0 || act > 3) return HN_EINVAL;
+    if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
     if ((training && (!dparams || count <= 0)) || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
     if (bad_rows(npix, C, {lddz, ldy, lddy}) || (dres && lddr < C) || (z && ldz < C)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -487,7 +507,7 @@ extern "C" int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, in
                   {lddz, ldy, lddy, dres ? lddr : 4, zmask ? ldz : 4});
     const float inv_count = training ? (float)(1.0 / (double)count) : 0.f;
     HN_LAUNCH_V(pl, bn_act_bwd_apply_kernel, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, dparams, inv_count,
-                training, dy, lddy, dres, lddr, npix, C, act, slope, leaky_slope);
+                training, dy, lddy, dres, lddr, npix, C, act, slope, leaky_slope, mask, hw);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

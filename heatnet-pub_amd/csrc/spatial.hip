@@ -414,6 +414,42 @@ __global__ __launch_bounds__(256) void pyramid_merge_kernel(const float* __restr
     }
 }
 
+// dx = sum over pyramid levels of adaptive_avg_pool backward: every level's gradient is scattered back to the
+// full-resolution map in ONE pass (one write of dx instead of one per level plus the adds between them).  The bins
+// that contain row h at output size s are i in [floor(h*s/H), ceil((h+1)*s/H) - 1] (1 or 2 of them).
+template <int V>
+__global__ __launch_bounds__(256) void pyramid_pool_bwd_kernel(PyramidArgs a, float* __restrict__ dx, int lddx, int N, int H,
+                                                              int W, int C) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (c >= C) return;
+    const int64_t npix = (int64_t)N * H * W;
+    HN_PIX_LOOP(npix) {
+        const int w = (int)(pix % W);
+        const int64_t t = pix / W;
+        const int h = (int)(t % H), n = (int)(t / H);
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int k = 0; k < a.count; ++k) {
+            const int Ho = a.h[k], Wo = a.w[k], ld = a.ld[k];
+            const int i_lo = h * Ho / H, i_hi = ((h + 1) * Ho + H - 1) / H - 1;
+            const int j_lo = w * Wo / W, j_hi = ((w + 1) * Wo + W - 1) / W - 1;
+            const float* base = a.p[k] + (int64_t)n * Ho * Wo * ld + c;
+            for (int i = i_lo; i <= i_hi; ++i) {
+                const int bh = bin_end(i, H, Ho) - bin_start(i, H, Ho);
+                for (int j = j_lo; j <= j_hi; ++j) {
+                    const float inv = 1.f / (float)(bh * (bin_end(j, W, Wo) - bin_start(j, W, Wo)));
+                    float g[V];
+                    ldv<V>(base + (int64_t)(i * Wo + j) * ld, g);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[e] += g[e] * inv;
+                }
+            }
+        }
+        stv<V>(dx + pix * lddx + c, acc);
+    }
+}
+
 bool bad_geom(int N, int H, int W, int C, int Ho, int Wo, int lda, int ldb) {
     return N <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || lda < C || ldb < C;
 }
@@ -524,6 +560,30 @@ extern "C" int hn_pyramid_merge_fwd(const float* mainp, int ldm, int n_priors, c
     hipStream_t s = static_cast<hipStream_t>(stream);
     const RowLaunch pl = plan_rows((int64_t)N * H * W, C, {mainp, out, aligned ? nullptr : (const void*)1}, {ldm, ldo});
     HN_LAUNCH_V(pl, pyramid_merge_kernel, mainp, ldm, a, out, ldo, N, H, W, C, relu);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_pyramid_pool_bwd(int n_levels, const float* const* dys, const int* hos, const int* wos, const int* lds,
+                                   float* dx, int lddx, int N, int H, int W, int C, void* stream) {
+    if (!dx || n_levels <= 0 || n_levels > 8 || !dys || !hos || !wos || !lds || N <= 0 || H <= 0 || W <= 0 || C <= 0 ||
+        lddx < C)
+        return HN_EINVAL;
+    PyramidArgs a;
+    a.count = n_levels;
+    bool aligned = true;
+    for (int k = 0; k < 8; ++k) {
+        const bool on = k < n_levels;
+        if (on && (!dys[k] || hos[k] <= 0 || wos[k] <= 0 || lds[k] < C)) return HN_EINVAL;
+        a.p[k] = on ? dys[k] : nullptr;
+        a.h[k] = on ? hos[k] : 1;
+        a.w[k] = on ? wos[k] : 1;
+        a.ld[k] = on ? lds[k] : 4;
+        if (on) aligned = aligned && hn_aligned16(dys[k]) && (lds[k] % 4 == 0);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const RowLaunch pl = plan_rows((int64_t)N * H * W, C, {dx, aligned ? nullptr : (const void*)1}, {lddx});
+    HN_LAUNCH_V(pl, pyramid_pool_bwd_kernel, a, dx, lddx, N, H, W, C);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

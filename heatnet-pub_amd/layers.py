@@ -54,13 +54,14 @@ class HnBatchNorm2d(nn.BatchNorm2d):
         self._pending_batches = 0
         super()._load_from_state_dict(*args, **kwargs)
 
-    def forward(self, x, residual=None, act=ops.ACT_NONE, stats=None, prelu_weight=None):
+    def forward(self, x, residual=None, act=ops.ACT_NONE, stats=None, prelu_weight=None, drop_mask=None):
         training = self.training or self.running_mean is None
         if training and self.num_batches_tracked is not None:
             self._pending_batches += 1  # host-side counter: no 1-element kernel per layer per step
         momentum = 0.1 if self.momentum is None else self.momentum
         return ops.bn_act(x, stats, self.weight, self.bias, self.running_mean, self.running_var, residual,
-                          prelu_weight, training, momentum, self.eps, act, ws=self.workspace(x.device))
+                          prelu_weight, training, momentum, self.eps, act, ws=self.workspace(x.device),
+                          drop_mask=drop_mask)
 
     _ws = None
 
@@ -71,7 +72,7 @@ class HnBatchNorm2d(nn.BatchNorm2d):
         return self._ws
 
 
-def conv_bn_act(x, conv, bn, act=ops.ACT_NONE, residual=None, prelu_weight=None, passthrough=False):
+def conv_bn_act(x, conv, bn, act=ops.ACT_NONE, residual=None, prelu_weight=None, passthrough=False, drop_mask=None):
     """conv -> BatchNorm (batch statistics from the conv epilogue) -> (+residual) -> activation.
 
     `passthrough=True` additionally returns an alias of `x` to be used for the block's skip connection: its gradient
@@ -81,7 +82,7 @@ def conv_bn_act(x, conv, bn, act=ops.ACT_NONE, residual=None, prelu_weight=None,
     out = ops.conv2d(x, conv.weight, conv.bias, s, p, d, want_stats=stats if stats is not None else False,
                      passthrough=passthrough)
     y, skip = out if passthrough else (out, None)
-    z = bn(y, residual=residual, act=act, stats=stats, prelu_weight=prelu_weight)
+    z = bn(y, residual=residual, act=act, stats=stats, prelu_weight=prelu_weight, drop_mask=drop_mask)
     return (z, skip) if passthrough else z
 
 
@@ -96,6 +97,13 @@ class HnPReLU(nn.PReLU):
 class HnDropout2d(nn.Dropout2d):
     def forward(self, x, mask=None):
         return ops.dropout2d(x, self.p, self.training, mask)
+
+    def mask_for(self, n, c, device):
+        """The [N, C] keep/(1-p) factors this layer would apply now (None when it is the identity), for producers
+        that fold the multiplication into their own output pass."""
+        if not self.training or self.p == 0.0:
+            return None
+        return ops.drop_mask(n, c, self.p, device)
 
 
 class HnMaxPool3x3s2(nn.Module):

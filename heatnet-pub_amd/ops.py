@@ -359,7 +359,7 @@ class _BnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, stats, gamma, beta, running_mean, running_var, residual, prelu_w, training, momentum, eps,
-                act, leaky, ws):
+                act, leaky, ws, drop_mask):
         lib = _lib.load()
         y, ldy = as_nhwc(y)
         n, c, h, w = y.shape
@@ -385,8 +385,11 @@ class _BnAct(torch.autograd.Function):
                 raise RuntimeError("bn_act: a residual input is only supported with ReLU / no activation")
             residual, ldr = as_nhwc(residual)
         z = new_nhwc(n, c, h, w, dev)
+        if drop_mask is not None:
+            drop_mask = drop_mask.contiguous()
         check(lib.hn_bn_act_fwd(_ptr(y), ldy, _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(z), c, npix, c, act,
-                                _ptr(prelu_w), leaky, s), "hn_bn_act_fwd")
+                                _ptr(prelu_w), leaky, _ptr(drop_mask), h * w, s), "hn_bn_act_fwd")
+        ctx.drop_mask = drop_mask
         ctx.cfg = (training, act, leaky, residual is not None)
         ctx.ws = ws
         # the ReLU mask is recomputed from y in backward unless a residual entered u (then z is kept)
@@ -410,8 +413,8 @@ class _BnAct(torch.autograd.Function):
                                                          dtype=torch.float64)
         dpar = torch.empty(2 * c + 1, device=y.device, dtype=torch.float32)   # dbeta | dgamma | dslope
         check(lib.hn_bn_act_bwd_reduce(_ptr(dz), lddz, _ptr(z), ldz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(scale),
-                                       _ptr(shift), npix, c, act, _ptr(prelu_w), leaky, _ptr(sums), _ptr(dpar), s),
-              "hn_bn_act_bwd_reduce")
+                                       _ptr(shift), npix, c, act, _ptr(prelu_w), leaky, _ptr(sums), _ptr(dpar),
+                                       _ptr(ctx.drop_mask), h * w, s), "hn_bn_act_bwd_reduce")
         dy = new_nhwc(n, c, h, w, y.device) if ctx.needs_input_grad[0] else None
         dres = new_nhwc(n, c, h, w, y.device) if (has_res and ctx.needs_input_grad[6]) else None
         if dy is not None or dres is not None:
@@ -419,12 +422,12 @@ class _BnAct(torch.autograd.Function):
                 dy = new_nhwc(n, c, h, w, y.device)
             check(lib.hn_bn_act_bwd_apply(_ptr(dz), lddz, _ptr(z), ldz, _ptr(y), ldy, _ptr(mean), _ptr(invstd),
                                           _ptr(gamma), _ptr(scale), _ptr(shift), _ptr(dpar), npix, int(training),
-                                          _ptr(dy), c, _ptr(dres), c, npix, c, act, _ptr(prelu_w), leaky, s),
-                  "hn_bn_act_bwd_apply")
+                                          _ptr(dy), c, _ptr(dres), c, npix, c, act, _ptr(prelu_w), leaky,
+                                          _ptr(ctx.drop_mask), h * w, s), "hn_bn_act_bwd_apply")
         dgamma = dpar[c:2 * c] if ctx.needs_input_grad[2] else None
         dbeta = dpar[0:c] if ctx.needs_input_grad[3] else None
         dprelu = dpar[2 * c:2 * c + 1] if (prelu_w is not None and ctx.needs_input_grad[7]) else None
-        return dy, None, dgamma, dbeta, None, None, dres, dprelu, None, None, None, None, None, None
+        return dy, None, dgamma, dbeta, None, None, dres, dprelu, None, None, None, None, None, None, None
 
 
 class BnWorkspace:
@@ -437,9 +440,15 @@ class BnWorkspace:
 
 
 def bn_act(y, stats, gamma, beta, running_mean, running_var, residual=None, prelu_weight=None, training=True,
-           momentum=0.1, eps=1e-5, act=ACT_NONE, leaky=0.0, ws=None):
+           momentum=0.1, eps=1e-5, act=ACT_NONE, leaky=0.0, ws=None, drop_mask=None):
+    """`drop_mask` [N, C]: Dropout2d keep/(1-p) factors applied to the output in the same pass (see `drop_mask()`)."""
     return _BnAct.apply(y, stats, gamma, beta, running_mean, running_var, residual, prelu_weight, bool(training),
-                        float(momentum), float(eps), int(act), float(leaky), ws)
+                        float(momentum), float(eps), int(act), float(leaky), ws, drop_mask)
+
+
+def drop_mask(n, c, p, device):
+    """nn.Dropout2d's per-(image, channel) factor: 0 with probability p, else 1/(1-p)."""
+    return torch.bernoulli(torch.full((n, c), 1.0 - p, device=device, dtype=torch.float32)) / (1.0 - p)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -503,6 +512,48 @@ class _AdaptiveAvgPool(torch.autograd.Function):
 def adaptive_avg_pool(x, size):
     ho, wo = (size, size) if isinstance(size, int) else size
     return _AdaptiveAvgPool.apply(x, int(ho), int(wo))
+
+
+class _PyramidPool(torch.autograd.Function):
+    """The adaptive average poolings of all pyramid levels of one map; their gradients return to the map in one
+    kernel (hn_pyramid_pool_bwd) instead of one full-size tensor per level plus autograd's adds."""
+
+    @staticmethod
+    def forward(ctx, x, *sizes):
+        lib = _lib.load()
+        x, ldx = as_nhwc(x)
+        n, c, h, w = x.shape
+        outs = []
+        for ho, wo in sizes:
+            y = new_nhwc(n, c, ho, wo, x.device)
+            check(lib.hn_adaptive_avgpool_fwd(_ptr(x), ldx, _ptr(y), c, n, h, w, c, ho, wo, _stream()),
+                  "hn_adaptive_avgpool_fwd")
+            outs.append(y)
+        ctx.shape = (n, c, h, w)
+        ctx.sizes = sizes
+        ctx.set_materialize_grads(False)  # a level nobody differentiates through is skipped, not zero-filled
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = _lib.load()
+        n, c, h, w = ctx.shape
+        live = [(as_nhwc(dy), sz) for dy, sz in zip(dys, ctx.sizes) if dy is not None]
+        dx = new_nhwc(n, c, h, w, live[0][0][0].device)
+        k = len(live)
+        ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for (t, _), _ in live])
+        hos = (ctypes.c_int * k)(*[sz[0] for _, sz in live])
+        wos = (ctypes.c_int * k)(*[sz[1] for _, sz in live])
+        lds = (ctypes.c_int * k)(*[ld for (_, ld), _ in live])
+        check(lib.hn_pyramid_pool_bwd(k, ptrs, hos, wos, lds, _ptr(dx), c, n, h, w, c, _stream()),
+              "hn_pyramid_pool_bwd")
+        return (dx,) + (None,) * len(ctx.sizes)
+
+
+def pyramid_pool(x, sizes):
+    """[adaptive_avg_pool(x, s) for s in sizes] with a single fused backward."""
+    sizes = tuple((int(s), int(s)) if isinstance(s, int) else (int(s[0]), int(s[1])) for s in sizes)
+    return _PyramidPool.apply(x, *sizes)
 
 
 class _Bilinear(torch.autograd.Function):
@@ -605,8 +656,7 @@ def dropout2d(x, p, training, mask=None):
     if mask is None:
         if not training or p == 0.0:
             return x
-        n, c = x.shape[0], x.shape[1]
-        mask = torch.bernoulli(torch.full((n, c), 1.0 - p, device=x.device, dtype=torch.float32)) / (1.0 - p)
+        mask = drop_mask(x.shape[0], x.shape[1], p, x.device)
     return _ScaleNC.apply(x, mask)
 
 

@@ -33,12 +33,18 @@ class PSPModule(nn.Module):
         function, 1/5 of the bottleneck's multiply-adds at full resolution."""
         w = self.bottleneck.weight
         f = feats.size(1)
+        k = len(self.stages)
+        if feats.requires_grad:
+            # the pooled branches read the main conv's pass-through alias: their (single, fused) gradient enters the
+            # main conv's dgrad kernel as its addend instead of being summed by autograd
+            main, feats = ops.conv2d(feats, w[:, k * f:(k + 1) * f], self.bottleneck.bias, passthrough=True)
+        else:
+            main = ops.conv2d(feats, w[:, k * f:(k + 1) * f], self.bottleneck.bias)
+        pooled = ops.pyramid_pool(feats, [stage[0].output_size for stage in self.stages])
         levels = []
         for i, stage in enumerate(self.stages):
-            q = stage[1](stage[0](feats))                       # pool -> 1x1 conv (C -> C) at s x s
+            q = stage[1](pooled[i])                              # 1x1 conv (C -> C) at s x s
             levels.append(ops.conv2d(q, w[:, i * f:(i + 1) * f]))  # this level's slice of the bottleneck, still s x s
-        k = len(self.stages)
-        main = ops.conv2d(feats, w[:, k * f:(k + 1) * f], self.bottleneck.bias)
         return ops.pyramid_merge(main, levels)
 
 
@@ -50,9 +56,13 @@ class PSPUpsample(nn.Module):
         self.conv = nn.Sequential(HnConv2d(in_channels, out_channels, 3, padding=1), HnBatchNorm2d(out_channels),
                                   HnPReLU())
 
-    def forward(self, x):
+    def forward(self, x, drop=None):
+        """`drop`: the Dropout2d layer that follows this block in PSPNet; its channel mask is applied in the BN/PReLU
+        kernel's output pass instead of by a pass of its own."""
         p = ops.bilinear(x, (2 * x.size(2), 2 * x.size(3)))
-        return conv_bn_act(p, self.conv[0], self.conv[1], ops.ACT_PRELU, prelu_weight=self.conv[2].weight)
+        mask = drop.mask_for(x.size(0), self.conv[0].out_channels, x.device) if drop is not None else None
+        return conv_bn_act(p, self.conv[0], self.conv[1], ops.ACT_PRELU, prelu_weight=self.conv[2].weight,
+                           drop_mask=mask)
 
 
 class PSPNet(nn.Module):
@@ -85,9 +95,9 @@ class PSPNet(nn.Module):
             f = self.feats(modal_1, modal_2)
             top = f[0]
         p = self.drop_1(self.psp(top))
-        p = self.drop_2(self.up_1(p))
-        p = self.drop_2(self.up_2(p))
-        p = self.drop_2(self.up_3(p))
+        p = self.up_1(p, self.drop_2)  # drop_2 folded into each decoder block's BN/PReLU pass
+        p = self.up_2(p, self.drop_2)
+        p = self.up_3(p, self.drop_2)
         out = self.final(p)
         if self.rgb_only:
             return out

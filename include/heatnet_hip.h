@@ -116,11 +116,13 @@ int hn_bn_finalize(double* stats, int64_t count, const float* gamma, const float
 int hn_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, float* mean, float* invstd, float* scale, float* shift, int C, void* stream);
 
-/* z = act(y*scale[c] + shift[c] + residual).  residual may be NULL; `slope` is a device pointer for
- * HN_ACT_PRELU, ignored otherwise (HN_ACT_LEAKY uses leaky_slope). */
+/* z = act(y*scale[c] + shift[c] + residual) [* mask[n*C + c]].  residual may be NULL; `slope` is a device pointer for
+ * HN_ACT_PRELU, ignored otherwise (HN_ACT_LEAKY uses leaky_slope).  `mask` (optional, with hw = pixels per image) is a
+ * Dropout2d keep/(1-p) factor per (image, channel), cm/models/pspnet.py:55,66-72, applied in the same pass; the two
+ * backward entry points take the same mask and fold it into dz. */
 int hn_bn_act_fwd(const float* y, int ldy, const float* scale, const float* shift,
                   const float* residual, int ldr, float* z, int ldz, int64_t npix, int C,
-                  int act, const float* slope, float leaky_slope, void* stream);
+                  int act, const float* slope, float leaky_slope, const float* mask, int64_t hw, void* stream);
 
 /* First backward pass.  du = dz * act'(u), u = y*scale+shift(+residual).  Accumulates into the double workspace
  * sums[HN_STAT_REPLICAS][2C+1] (must be all zero on entry; it is zero again on return) and writes
@@ -130,7 +132,7 @@ int hn_bn_act_fwd(const float* y, int ldy, const float* scale, const float* shif
 int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                          const float* mean, const float* invstd, const float* scale, const float* shift,
                          int64_t npix, int C, int act, const float* slope, float leaky_slope,
-                         double* sums, float* dparams, void* stream);
+                         double* sums, float* dparams, const float* mask, int64_t hw, void* stream);
 
 /* Second backward pass: dy = gamma*invstd*(du - dbeta/count - xhat*dgamma/count) when `training`,
  * dy = gamma*invstd*du otherwise; dres = du when dres != NULL (gradient of the residual input).
@@ -139,7 +141,7 @@ int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, cons
                         const float* mean, const float* invstd, const float* gamma, const float* scale,
                         const float* shift, const float* dparams, int64_t count, int training,
                         float* dy, int lddy, float* dres, int lddr, int64_t npix, int C,
-                        int act, const float* slope, float leaky_slope, void* stream);
+                        int act, const float* slope, float leaky_slope, const float* mask, int64_t hw, void* stream);
 
 /* dx = dy * act'(y_out) for an activation applied in a conv epilogue (LeakyReLU / ReLU: the sign of the
  * output equals the sign of the pre-activation).  In place allowed (dx == dy). */
@@ -181,6 +183,12 @@ int hn_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H
 int hn_pyramid_merge_fwd(const float* main, int ldm, int n_priors, const float* const* priors, const int* hs,
                          const int* ws, const int* lds, float* out, int ldo, int N, int H, int W, int C, int relu,
                          void* stream);
+
+/* dx[n,h,w,c] = sum over levels l of adaptive_avg_pool2d backward of dys[l] ([N, hos[l], wos[l], C], row stride lds[l])
+ * at input size H x W: the gradient of the four pyramid poolings of PSPModule (cm/models/pspnet.py:22-24,30) written in
+ * one pass.  n_levels <= 8.  dx is overwritten. */
+int hn_pyramid_pool_bwd(int n_levels, const float* const* dys, const int* hos, const int* wos, const int* lds,
+                        float* dx, int lddx, int N, int H, int W, int C, void* stream);
 
 /* ---- losses ------------------------------------------------------------------------------------------ */
 

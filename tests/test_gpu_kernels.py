@@ -160,6 +160,64 @@ def test_bn_act(dev, act, training, residual):
         close(sd.grad, sr.grad, atol=2e-3, rtol=1e-4, what="dslope")
 
 
+@pytest.mark.parametrize("act", ["relu", "prelu"])
+def test_bn_act_with_folded_dropout_mask(dev, act):
+    """Dropout2d folded into the BN/activation pass == BatchNorm -> act -> per-(image, channel) scaling
+    (reference pspnet.py:66-72: drop_2 after each PSPUpsample)."""
+    ops = _ops()
+    n, c, h, w = 3, 64, 9, 11
+    y = rnd(n, c, h, w, seed=11, scale=2.0) + 0.3
+    gamma, beta = rnd(c, seed=12).abs() + 0.5, rnd(c, seed=13) * 0.1
+    mask = (torch.from_numpy(np.random.RandomState(5).uniform(size=(n, c))) > 0.3).float() / 0.7
+    slope = torch.tensor([0.25])
+    gz = rnd(n, c, h, w, seed=14)
+
+    yr, gr, br, sr = (t.clone().requires_grad_() for t in (y, gamma, beta, slope))
+    u = F.batch_norm(yr, torch.zeros(c), torch.ones(c), gr, br, training=True, momentum=0.1, eps=1e-5)
+    zr = (F.relu(u) if act == "relu" else F.prelu(u, sr)) * mask[:, :, None, None]
+    zr.backward(gz)
+
+    yd = y.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    gd, bd, sd = gamma.to(dev).requires_grad_(), beta.to(dev).requires_grad_(), slope.to(dev).requires_grad_()
+    z = ops.bn_act(yd, None, gd, bd, torch.zeros(c, device=dev), torch.ones(c, device=dev),
+                   prelu_weight=sd if act == "prelu" else None, training=True,
+                   act=ops.ACT_RELU if act == "relu" else ops.ACT_PRELU, drop_mask=mask.to(dev))
+    close(z, zr, atol=2e-5, rtol=1e-5, what="z")
+    z.backward(gz.to(dev))
+    close(yd.grad, yr.grad, atol=3e-5, rtol=1e-4, what="dy")
+    close(gd.grad, gr.grad, atol=2e-3, rtol=1e-4, what="dgamma")
+    close(bd.grad, br.grad, atol=2e-3, rtol=1e-4, what="dbeta")
+    if act == "prelu":
+        close(sd.grad, sr.grad, atol=2e-3, rtol=1e-4, what="dslope")
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 10, 14), (1, 12, 7, 5), (2, 6, 40, 88)])
+def test_pyramid_pool_fused_backward(dev, shape):
+    """All pyramid levels' adaptive poolings (reference pspnet.py:22-24) with their gradients scattered back in one pass;
+    7x5 and 40x88 have overlapping bins at sizes 2, 3, 6."""
+    ops = _ops()
+    n, c, h, w = shape
+    sizes = (1, 2, 3, 6)
+    x = rnd(n, c, h, w, seed=21)
+    gs = [rnd(n, c, s, s, seed=22 + s) for s in sizes]
+    xr = x.clone().requires_grad_()
+    yr = [F.adaptive_avg_pool2d(xr, (s, s)) for s in sizes]
+    sum((y * g).sum() for y, g in zip(yr, gs)).backward()
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    yd = ops.pyramid_pool(xd, sizes)
+    for a, b, s in zip(yd, yr, sizes):
+        close(a, b, atol=1e-6, rtol=1e-5, what="pool%d" % s)
+    sum((y * g.to(dev)).sum() for y, g in zip(yd, gs)).backward()
+    close(xd.grad, xr.grad, atol=1e-6, rtol=1e-5, what="dx")
+    # a level without gradient is skipped
+    xd2 = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    y2 = ops.pyramid_pool(xd2, sizes)
+    (y2[1] * gs[1].to(dev)).sum().backward()
+    xr.grad = None
+    (F.adaptive_avg_pool2d(xr, (2, 2)) * gs[1]).sum().backward()
+    close(xd2.grad, xr.grad, atol=1e-6, rtol=1e-5, what="dx(level 2 only)")
+
+
 def test_bn_stats_from_conv_epilogue_match_standalone(dev):
     """conv_bn_act (statistics from the conv epilogue) == conv then BatchNorm on CPU, incl. narrow C with ld tails."""
     from heatnet_amd.layers import HnBatchNorm2d, HnConv2d, conv_bn_act
@@ -352,7 +410,9 @@ def test_c_abi_rejects_bad_arguments(dev):
     assert lib.hn_conv2d_fwd(P(x), P(w), None, P(y), None, ctypes.byref(bad_shape), 0, 0.0, 0, s) == -4  # HN_ESHAPE
     bad_ld = _lib.HnConvDesc(1, 8, 8, 64, 32, 8, 8, 64, 64, 1, 1, 1, 0, 1)                              # ldx < Cin
     assert lib.hn_conv2d_fwd(P(x), P(w), None, P(y), None, ctypes.byref(bad_ld), 0, 0.0, 0, s) == -1
-    assert lib.hn_bn_act_fwd(P(x), 64, None, None, None, 0, P(y), 64, 64, 64, 1, None, 0.0, s) == -1
+    assert lib.hn_bn_act_fwd(P(x), 64, None, None, None, 0, P(y), 64, 64, 64, 1, None, 0.0, None, 0, s) == -1
+    assert lib.hn_bn_act_fwd(P(x), 64, P(w), P(w), None, 0, P(y), 64, 64, 64, 1, None, 0.0, P(w), 48, s) == -1  # hw !| npix
+    assert lib.hn_pyramid_pool_bwd(9, None, None, None, None, P(y), 64, 1, 8, 8, 64, s) == -1            # > 8 levels
     assert lib.hn_ce_fwd(P(x), 64, P(y), 64, 64, -100, P(y), s) == -1                                   # C > 32 classes
     with pytest.raises(RuntimeError, match="invalid argument"):
         _lib.check(-1, "probe")
