@@ -24,9 +24,9 @@ DP = ctypes.POINTER(HnConvDesc)
 
 # name -> argtypes, exactly the prototypes of include/heatnet_hip.h
 SIGNATURES = {
-    "hn_conv2d_fwd": [P, P, P, P, P, DP, c_int, c_float, c_int, P],
-    "hn_weight_flip_transpose": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
-    "hn_conv2d_dgrad": [P, P, P, P, c_int, DP, c_int, P],
+    "hn_conv2d_fwd": [P, P, P, P, P, P, DP, c_int, c_float, c_int, P],
+    "hn_weight_flip_transpose": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "hn_conv2d_dgrad": [P, P, P, P, P, c_int, DP, c_int, P],
     "hn_conv2d_wgrad": [P, P, P, DP, c_int, c_int, P],
     "hn_channel_sum": [P, c_int, c_i64, c_int, P, P],
     "hn_channel_stats": [P, c_int, c_i64, c_int, P, P],
@@ -48,6 +48,9 @@ SIGNATURES = {
     "hn_bilinear_fwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_bilinear_bwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_pyramid_merge_fwd": [P, c_int, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "hn_split_bf16x3": [P, P, c_i64, P],
+    "hn_set_conv_math": [c_int],
+    "hn_get_conv_math": [],
     "hn_pyramid_pool_bwd": [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "hn_ce_fwd": [P, c_int, P, c_i64, c_int, c_i64, P, P],
     "hn_ce_bwd": [P, c_int, P, c_i64, c_int, c_i64, P, P, P, c_int, P],

@@ -15,9 +15,19 @@
 //
 // The same kernel computes the data gradient: dX = conv(dY "dilated" by the forward stride, flipped and
 // transposed weights) -- `in_dil` below.
+//
+// MATH_X3 ("bf16x3"): the same fp32 product computed on the bf16 matrix cores.  Every fp32 operand is split exactly into
+// three bf16 terms (x = hi + mid + lo, round-to-nearest at each level) when it is staged into LDS, and the six products
+// whose weight is >= 2^-24 of the result (mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi; each exact in fp32) are
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest terms first.  Measured against fp64 this is as accurate as
+// the fp32 MFMA (profiles/r01_bf16x3_probe.txt: rms error 0.38-0.57 x 2^-24 of sum|products| vs 0.44-0.50) at 16/6
+// of its matrix-core rate.  Not a reduced-precision mode: nothing of the fp32 operands is dropped above 2^-24.
 #include <type_traits>
 
 #include "hn_common.h"
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
 
 #ifdef HN_EXP_PIN
 #define HN_PIN() __builtin_amdgcn_sched_barrier(0)
@@ -60,11 +70,34 @@ struct ConvArgs {
     int act;
     float slope;
     long long x_bytes;  // extent of the gathered tensor from p.x, for the buffer descriptors
+    // bf16x3: the weight matrix pre-split into three bf16 planes (hn_split_bf16x3 / hn_weight_flip_transpose), plane p
+    // = wx3 + p * wx3_plane elements, each laid out exactly like the fp32 matrix `w`
+    const unsigned short* wx3;
+    long long wx3_plane;
 };
 
 // Loader variants.  BUF fetches through buffer descriptors: one SGPR resource per tile, 32-bit byte offsets, and
 // out-of-range taps / rows are zero-filled by the hardware range check instead of by selects.
 enum : int { MODE_SCALAR = 0, MODE_SCALAR_STRIDED = 1, MODE_VEC = 2, MODE_VEC_STRIDED = 3, MODE_VEC_BUF = 4 };
+enum : int { MATH_F32 = 0, MATH_X3 = 1 };
+
+// bf16x3 LDS image: [split][row][32 k] bf16 with 80-byte rows (64 B of data + 16 B pad: 16 consecutive rows start in
+// 16 distinct 16-B slots of the 256-B bank row -> conflict-free ds_read_b128 of a lane's 8 consecutive k)
+constexpr int X3_ROW = 80;
+
+// exact three-way split of four consecutive-k fp32 values into packed bf16 (hi, mid, lo)
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 hh = (__bf16)v[e];
+        const float r = v[e] - (float)hh;  // exact
+        const __bf16 mm = (__bf16)r;
+        const float r2 = r - (float)mm;    // exact
+        h[e] = hh;
+        m[e] = mm;
+        l[e] = (__bf16)r2;
+    }
+}
 
 __device__ __forceinline__ f32x4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
@@ -72,17 +105,19 @@ __device__ __forceinline__ f32x4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsi
 
 // STRIDED = the gathered tensor is "dilated" by in_dil > 1 (data gradient of a strided convolution): taps must
 // land on multiples of in_dil.  Kept out of the common instantiation because it costs integer divisions per tap.
-template <int TM, int TN, int MODE, int BK>
+template <int TM, int TN, int MODE, int BK, int MATH = MATH_F32>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int LDK = KStep<BK>::LDK, PR = KStep<BK>::PR, VROWS = KStep<BK>::VROWS, SROWS = KStep<BK>::SROWS;
     constexpr bool VEC = MODE >= MODE_VEC;
     constexpr bool STRIDED = MODE == MODE_SCALAR_STRIDED || MODE == MODE_VEC_STRIDED;
     constexpr bool BUF = MODE == MODE_VEC_BUF;
+    constexpr bool X3 = MATH == MATH_X3;
+    static_assert(!X3 || (BUF && BK == 32), "bf16x3 math is built for the buffer loaders at K step 32");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                        // [2][BM][LDK]
-    float* Bs = smem + 2 * BM * LDK;                         // [2][BN][LDK]
-    int* rowinfo = reinterpret_cast<int*>(Bs + 2 * BN * LDK);  // [BM][4]: h base, w base, image pixel base
+    float* As = smem;                                        // f32: [2][BM][LDK]     bf16x3: [3][BM][X3_ROW bytes]
+    float* Bs = smem + (X3 ? 3 * BM * X3_ROW / 4 : 2 * BM * LDK);  // f32: [2][BN][LDK]  bf16x3: [3][BN][X3_ROW bytes]
+    int* rowinfo = reinterpret_cast<int*>(Bs + (X3 ? 3 * BN * X3_ROW / 4 : 2 * BN * LDK));  // [BM][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -113,8 +148,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 
     // ---- operand staging -------------------------------------------------------------------------------
     constexpr int RA = VEC ? BM / VROWS : BM / SROWS;
-    constexpr int RB = VEC ? BN / VROWS : BN / SROWS;
+    // bf16x3 stages B from the pre-split planes: BN rows x 3 planes x 4 pieces of 16 B (8 bf16) per K step
+    constexpr int RB = X3 ? BN * 12 / 256 : (VEC ? BN / VROWS : BN / SROWS);
     f32x4 va[VEC ? RA : 1], vb[VEC ? RB : 1];
+    f32x4 va1[X3 ? RA : 1], vb1[X3 ? RB : 1];  // bf16x3: second staging set (two K steps of loads in flight)
     float sa[VEC ? 1 : RA], sb[VEC ? 1 : RB];
     int ahb[VEC ? RA : 1], awb[VEC ? RA : 1], anb[VEC ? RA : 1];
     long long aoff[VEC ? RA : 1];  // element offset of the row's (h base, w base) pixel, may be negative
@@ -147,14 +184,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         const long long a_left = p.x_bytes - a_base;
         a_records = a_left > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)a_left;
         rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + (long long)nb0 * p.ldx, 0, a_records, 0x00020000);
-        const int rows_b = min(BN, p.K - n0);
-        rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w) + (long long)n0 * p.Kdim, 0,
-                                                   (unsigned)((long long)rows_b * p.Kdim * 4), 0x00020000);
 #pragma unroll
         for (int q = 0; q < RA; ++q)
             aoff32[q] = (((anb[q] - nb0) + ahb[q] * p.W + awb[q]) * p.ldx + c4 * 4) * 4;
+        if constexpr (X3) {
+            const unsigned b_records = (unsigned)(3 * p.wx3_plane * 2);
+            rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.wx3), 0, b_records, 0x00020000);
 #pragma unroll
-        for (int q = 0; q < RB; ++q) boff32[q] = (unsigned)(((vrow + VROWS * q) * p.Kdim + c4 * 4) * 4);
+            for (int q = 0; q < RB; ++q) {
+                const int id = tid + 256 * q, plane = id / (BN * 4), rem = id % (BN * 4);
+                const int co = n0 + (rem >> 2);
+                boff32[q] = co < p.K ? (unsigned)((plane * p.wx3_plane + (long long)co * p.Kdim + (rem & 3) * 8) * 2)
+                                     : b_records;  // rows past Cout: out of range -> zero-filled
+            }
+        } else {
+            const int rows_b = min(BN, p.K - n0);
+            rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w) + (long long)n0 * p.Kdim, 0,
+                                                       (unsigned)((long long)rows_b * p.Kdim * 4), 0x00020000);
+#pragma unroll
+            for (int q = 0; q < RB; ++q) boff32[q] = (unsigned)(((vrow + VROWS * q) * p.Kdim + c4 * 4) * 4);
+        }
     }
 
     // K-step position of the NEXT chunk to fetch, advanced incrementally (VEC: a step never straddles a tap
@@ -163,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 
     // Predicated loads are branch-free (the address falls back to the tensor base, the value is zeroed by a
     // select) so that a whole K step stays one basic block the scheduler can interleave with the MFMAs.
-    auto load_a = [&]() {
+    auto load_a = [&](auto& dva) {
         if constexpr (VEC) {
             const int dh = st_kh * p.dil, dw = st_kw * p.dil;
             if constexpr (BUF) {
@@ -171,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int q = 0; q < RA; ++q) {
                     const bool ok = ((unsigned)(ahb[q] + dh) < (unsigned)p.H) & ((unsigned)(awb[q] + dw) < (unsigned)p.W);
-                    va[q] = buffer_load16(rsrc_a, ok ? (unsigned)(aoff32[q] + doff) : a_records, 0);
+                    dva[q] = buffer_load16(rsrc_a, ok ? (unsigned)(aoff32[q] + doff) : a_records, 0);
                 }
             } else if constexpr (!STRIDED) {
                 const long long doff = ((long long)dh * p.W + dw) * p.ldx + st_c0;
@@ -181,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
                     const float* src = ok ? p.x + (aoff[q] + doff) : p.x;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(src);
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    va[q] = ok ? v : z;
+                    dva[q] = ok ? v : z;
                 }
             } else {
 #pragma unroll
@@ -193,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
                     ok = ok & (h < p.H) & (w < p.W);
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(anb[q] + h * p.W + w) * p.ldx + st_c0 + c4 * 4);
-                    va[q] = v;
+                    dva[q] = v;
                 }
             }
         } else {
@@ -218,11 +267,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
             }
         }
     };
-    auto load_b = [&]() {  // also advances the fetch position
+    auto load_b = [&](auto& dvb) {  // also advances the fetch position
         if constexpr (BUF) {
             // rows past Cout are beyond the resource's extent: zero-filled by the range check
 #pragma unroll
-            for (int q = 0; q < RB; ++q) vb[q] = buffer_load16(rsrc_b, boff32[q], (unsigned)(st_k0 * 4));
+            for (int q = 0; q < RB; ++q) dvb[q] = buffer_load16(rsrc_b, boff32[q], (unsigned)(st_k0 * (X3 ? 2 : 4)));
             st_c0 += BK;
             if (st_c0 >= p.C) {
                 st_c0 = 0;
@@ -235,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
                 const float* src = ok ? p.w + (boff[q] + st_k0) : p.w;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(src);
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                vb[q] = ok ? v : z;
+                dvb[q] = ok ? v : z;
             }
             st_c0 += BK;
             if (st_c0 >= p.C) {
@@ -254,14 +303,32 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         st_k0 += BK;
     };
 
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int buf, const auto& sva, const auto& svb) {
+        if constexpr (X3) {  // single LDS stage: split each staged 16 B (4 consecutive k) into 3 x 8 B of bf16
+            char* a = reinterpret_cast<char*>(As) + c4 * 8;
+#pragma unroll
+            for (int q = 0; q < RA; ++q) {
+                bf16x4 h, m, l;
+                split3(sva[q], h, m, l);
+                const int row = vrow + VROWS * q;
+                *reinterpret_cast<bf16x4*>(a + (0 * BM + row) * X3_ROW) = h;
+                *reinterpret_cast<bf16x4*>(a + (1 * BM + row) * X3_ROW) = m;
+                *reinterpret_cast<bf16x4*>(a + (2 * BM + row) * X3_ROW) = l;
+            }
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {  // already split: piece id -> (plane, row, 16-B piece), see boff32
+                const int id = tid + 256 * q;
+                *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Bs) + (id >> 2) * X3_ROW + (id & 3) * 16) = svb[q];
+            }
+            return;
+        }
         float* a = As + buf * BM * LDK;
         float* b = Bs + buf * BN * LDK;
         if constexpr (VEC) {
 #pragma unroll
-            for (int q = 0; q < RA; ++q) *reinterpret_cast<f32x4*>(a + (vrow + VROWS * q) * LDK + c4 * 4) = va[q];
+            for (int q = 0; q < RA; ++q) *reinterpret_cast<f32x4*>(a + (vrow + VROWS * q) * LDK + c4 * 4) = sva[q];
 #pragma unroll
-            for (int q = 0; q < RB; ++q) *reinterpret_cast<f32x4*>(b + (vrow + VROWS * q) * LDK + c4 * 4) = vb[q];
+            for (int q = 0; q < RB; ++q) *reinterpret_cast<f32x4*>(b + (vrow + VROWS * q) * LDK + c4 * 4) = svb[q];
         } else {
 #pragma unroll
             for (int q = 0; q < RA; ++q) a[(srow + SROWS * q) * LDK + sk] = sa[q];
@@ -343,15 +410,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         Frag f[2];
         read_frag(buf, 0, f[0]);
 #ifndef HN_EXP_NOWRITE
-        if constexpr (decltype(write_tag)::value) store_lds(buf ^ 1);
+        if constexpr (decltype(write_tag)::value) store_lds(buf ^ 1, va, vb);
 #endif
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (g + 1 < G) read_frag(buf, g + 1, f[(g + 1) & 1]);
 #ifndef HN_EXP_NOLOAD
             if constexpr (decltype(fetch_tag)::value) {
-                if (g == (G >= 4 ? 1 : 0)) load_a();
-                if (g == (G >= 4 ? 2 : G - 1)) load_b();
+                if (g == (G >= 4 ? 1 : 0)) load_a(va);
+                if (g == (G >= 4 ? 2 : G - 1)) load_b(vb);
             }
 #endif
             mfma16(f[g & 1]);
@@ -361,12 +428,67 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 #endif
     };
 
-    load_a();
-    load_b();
-    store_lds(0);
+    if constexpr (X3) {
+        // One LDS stage, register prefetch one K step ahead: split+store chunk kc | barrier | fetch chunk kc+1 |
+        // 2 x (fragments, 6*TM*TN MFMAs) | barrier.  The two workgroups of a CU run out of phase, so one wave's
+        // split/store (VALU, LDS) overlaps the other's MFMAs on the same SIMD.
+        auto x3_group = [&](int g) {
+            const char* a = reinterpret_cast<const char*>(As) + ((wm * TM * 32 + lr) * X3_ROW + g * 32 + lh * 16);
+            const char* b = reinterpret_cast<const char*>(Bs) + ((wn * TN * 32 + lr) * X3_ROW + g * 32 + lh * 16);
+            bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i][s3] = *reinterpret_cast<const bf16x8*>(a + (s3 * BM + i * 32) * X3_ROW);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j][s3] = *reinterpret_cast<const bf16x8*>(b + (s3 * BN + j * 32) * X3_ROW);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);  // mid*mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);  // hi*lo
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);  // lo*hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);  // hi*mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);  // mid*hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);  // hi*hi
+                    acc[i][j] = c;
+                }
+        };
+        // chunk kc+1 is fetched into the other staging set BEFORE chunk kc is split and stored, so a fetch has the
+        // split/store phase plus the whole MFMA phase to land
+        auto x3_step = [&](bool more, auto& cur_a, auto& cur_b, auto& nxt_a, auto& nxt_b) {
+#ifndef HN_EXP_NOLOAD
+            if (more) {
+                load_a(nxt_a);
+                load_b(nxt_b);
+            }
+#endif
+#ifndef HN_EXP_NOWRITE
+            store_lds(0, cur_a, cur_b);
+#endif
+            __syncthreads();
+            x3_group(0);
+            x3_group(1);
+            __syncthreads();
+        };
+        load_a(va);
+        load_b(vb);
+        int kc = 0;
+        for (; kc + 1 < nchunks; kc += 2) {
+            x3_step(true, va, vb, va1, vb1);
+            x3_step(kc + 2 < nchunks, va1, vb1, va, vb);
+        }
+        if (kc < nchunks) x3_step(false, va, vb, va1, vb1);
+    } else {
+    load_a(va);
+    load_b(vb);
+    store_lds(0, va, vb);
     if (nchunks > 1) {
-        load_a();
-        load_b();
+        load_a(va);
+        load_b(vb);
     }
     __syncthreads();
     int kc = 0;
@@ -376,6 +498,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         ++kc;
     }
     k_step(kc & 1, std::false_type{}, std::false_type{});
+    }
 
     // ---- epilogue: bias, batch-statistics partials, activation, store -------------------------------------
     // Accumulator map (32x32 MFMA): column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
@@ -468,13 +591,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     }
 }
 
-template <int TM, int TN, int MODE, int BK>
+template <int TM, int TN, int MODE, int BK, int MATH = MATH_F32>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int lds = (2 * (BM + BN) * KStep<BK>::LDK + BM * 4) * (int)sizeof(float);
+    constexpr int lds = MATH == MATH_X3 ? 3 * (BM + BN) * X3_ROW + BM * 16
+                                        : (2 * (BM + BN) * KStep<BK>::LDK + BM * 4) * (int)sizeof(float);
     static bool configured = false;  // raising the dynamic-LDS cap is idempotent; the flag only saves calls
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<TM, TN, MODE, BK>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<TM, TN, MODE, BK, MATH>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return HN_ELAUNCH;
         configured = true;
@@ -488,23 +612,26 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
         p.cps = a.cps * 32 / BK;
         splits = (total + p.cps - 1) / p.cps;
     }
-    HN_LAUNCH((conv_igemm_kernel<TM, TN, MODE, BK>), dim3(p.ntm * p.ntn * splits), dim3(256), lds, stream, p);
+    HN_LAUNCH((conv_igemm_kernel<TM, TN, MODE, BK, MATH>), dim3(p.ntm * p.ntn * splits), dim3(256), lds, stream, p);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
 
-template <int MODE, int BK>
+template <int MODE, int BK, int MATH = MATH_F32>
 int dispatch_tile(const ConvArgs& a, bool tall, bool wide, hipStream_t stream) {
-    if (tall) return wide ? launch_conv<2, 2, MODE, BK>(a, stream) : launch_conv<2, 1, MODE, BK>(a, stream);
-    return wide ? launch_conv<1, 2, MODE, BK>(a, stream) : launch_conv<1, 1, MODE, BK>(a, stream);
+    if (tall) return wide ? launch_conv<2, 2, MODE, BK, MATH>(a, stream) : launch_conv<2, 1, MODE, BK, MATH>(a, stream);
+    return wide ? launch_conv<1, 2, MODE, BK, MATH>(a, stream) : launch_conv<1, 1, MODE, BK, MATH>(a, stream);
 }
 
-// variant: 0 = heuristics; otherwise (bk_sel) + 4 * (tm_sel) + 16 * (tn_sel) with bk_sel 1 -> K step 32, 2 -> 16 and
-// tm_sel / tn_sel 1 -> 64-wide, 2 -> 128-wide tile side (0 keeps the heuristic for that field).  All variants give
-// bitwise identical results: the per-element accumulation order does not depend on the tiling.
+int g_conv_math = MATH_F32;  // library default for variant codes that leave the math field 0 (hn_set_conv_math)
+
+// variant: 0 = heuristics; otherwise (bk_sel) + 4 * (tm_sel) + 16 * (tn_sel) + 64 * (math_sel) with bk_sel 1 -> K step
+// 32, 2 -> 16; tm_sel / tn_sel 1 -> 64-wide, 2 -> 128-wide tile side; math_sel 1 -> fp32 MFMA, 2 -> bf16x3 (0 keeps the
+// heuristic / library default for that field).  Within one math mode all variants give bitwise identical results: the
+// per-element accumulation order does not depend on the tiling.
 int dispatch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
-    if (variant < 0 || variant >= 48) return HN_EINVAL;
-    const int bk_sel = variant & 3, tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3;
+    if (variant < 0 || variant >= 192) return HN_EINVAL;
+    const int bk_sel = variant & 3, tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3, math_sel = variant >> 6;
     if (bk_sel == 3 || tm_sel == 3 || tn_sel == 3) return HN_EINVAL;
     const bool vec = (a.C % 32 == 0) && (a.ldx % 4 == 0) && hn_aligned16(a.x) && hn_aligned16(a.w);
     bool wide = a.K > 64;
@@ -520,6 +647,10 @@ int dispatch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
     const long long image_bytes = (long long)a.H * a.W * a.ldx * 4;
     const bool buf_ok = 3 * image_bytes < (1ll << 31) && 128ll * a.Kdim * 4 < (1ll << 31) &&
                         (long long)a.H * a.W >= 128;
+    // bf16x3 needs the pre-split weight planes and the buffer loaders; anything else runs on the fp32 MFMA
+    const bool x3 = (math_sel ? math_sel == 2 : g_conv_math == MATH_X3) && a.wx3 != nullptr && vec && !strided && buf_ok &&
+                    hn_aligned16(a.wx3) && a.wx3_plane % 8 == 0 && 6 * a.wx3_plane < (1ll << 32);
+    if (x3) return dispatch_tile<MODE_VEC_BUF, 32, MATH_X3>(a, tall, wide, stream);
     if (vec && !strided && buf_ok)
         return bk16 ? dispatch_tile<MODE_VEC_BUF, 16>(a, tall, wide, stream) : dispatch_tile<MODE_VEC_BUF, 32>(a, tall, wide, stream);
     if (vec) return strided ? dispatch_tile<MODE_VEC_STRIDED, 32>(a, tall, wide, stream) : dispatch_tile<MODE_VEC, 32>(a, tall, wide, stream);
@@ -623,8 +754,20 @@ inline void build_tap_table(TapTable& t, int Cout, int KH, int KW, int Cin, int 
         }
 }
 
-// one 32x32 (co, ci) tile of one tap per block, transposed through LDS
+__device__ __forceinline__ void split3_scalar(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const __bf16 hh = (__bf16)v;
+    const float r = v - (float)hh;
+    const __bf16 mm = (__bf16)r;
+    const __bf16 ll = (__bf16)(r - (float)mm);
+    h = __builtin_bit_cast(unsigned short, hh);
+    m = __builtin_bit_cast(unsigned short, mm);
+    l = __builtin_bit_cast(unsigned short, ll);
+}
+
+// one 32x32 (co, ci) tile of one tap per block, transposed through LDS; `wt` (fp32) and `wx3` (three bf16 planes of
+// `plane` elements each, same element order) are both optional
 __global__ __launch_bounds__(256) void weight_taps_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                                   unsigned short* __restrict__ wx3, long long plane,
                                                                    int Cout, int T, int Cin, TapTable t) {
     __shared__ float tile[32][33];
     const int z = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
@@ -635,17 +778,27 @@ __global__ __launch_bounds__(256) void weight_taps_transpose_kernel(const float*
         tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * T + src) * Cin + ci] : 0.f;
     }
     __syncthreads();
-    float* out = wt + t.dst[z];
     const int rowstride = t.row[z];
     for (int r = ty; r < 32; r += 8) {
         const int ci = ci0 + r, co = co0 + tx;
-        if (ci < Cin && co < Cout) out[(size_t)ci * rowstride + co] = tile[tx][r];
+        if (ci < Cin && co < Cout) {
+            const size_t o = (size_t)t.dst[z] + (size_t)ci * rowstride + co;
+            const float v = tile[tx][r];
+            if (wt != nullptr) wt[o] = v;
+            if (wx3 != nullptr) split3_scalar(v, wx3[o], wx3[plane + o], wx3[2 * plane + o]);
+        }
     }
+}
+
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                          long long n, long long plane) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        split3_scalar(src[i], dst[i], dst[plane + i], dst[2 * plane + i]);
 }
 
 }  // namespace
 
-extern "C" int hn_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, double* stats,
+extern "C" int hn_conv2d_fwd(const float* x, const float* w, const void* w_x3, const float* bias, float* y, double* stats,
                              const HnConvDesc* d, int act, float slope, int variant, void* stream) {
     if (x == nullptr || w == nullptr || y == nullptr) return HN_EINVAL;
     if (act < HN_ACT_NONE || act > HN_ACT_LEAKY) return HN_EINVAL;
@@ -662,13 +815,15 @@ extern "C" int hn_conv2d_fwd(const float* x, const float* w, const float* bias, 
     a.ntm = a.ntn = 0;
     a.act = act; a.slope = slope;
     a.x_bytes = (((long long)d->N * d->Hin * d->Win - 1) * d->ldx + d->Cin) * 4;
+    a.wx3 = static_cast<const unsigned short*>(w_x3);
+    a.wx3_plane = hn_x3_plane((long long)d->Cout * a.Kdim);
     hipStream_t s = static_cast<hipStream_t>(stream);
     a.cps = (d->ldy == d->Cout) ? plan_split_k(a.M, a.K, a.Kdim) : 0;
     if (a.cps == 0) return dispatch_conv(a, variant, s);
     // split-K: zero y, accumulate partial products, then bias / activation and (for BatchNorm) the statistics
     if (hipMemsetAsync(y, 0, (size_t)a.M * a.K * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
     a.bias = nullptr; a.stats = nullptr; a.act = HN_ACT_NONE;
-    const int rcs = dispatch_conv(a, variant & ~3, s);
+    const int rcs = dispatch_conv(a, variant & ~3, s);  // split-K plans assume K step 32
     if (rcs != HN_OK) return rcs;
     if (bias != nullptr || act != HN_ACT_NONE) {
         const float neg_slope = act == HN_ACT_NONE ? 1.f : (act == HN_ACT_RELU ? 0.f : slope);
@@ -693,7 +848,7 @@ int init_output(float* dx, int ldx, const float* addend, int ldadd, int64_t npix
 }
 }  // namespace
 
-extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* addend, int ldadd,
+extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, const void* wt_x3, float* dx, const float* addend, int ldadd,
                                const HnConvDesc* d, int variant, void* stream) {
     if (dy == nullptr || wt == nullptr || dx == nullptr) return HN_EINVAL;
     if (addend != nullptr && (d == nullptr || ldadd < d->Cin)) return HN_EINVAL;
@@ -709,6 +864,8 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, cons
     a.ntm = a.ntn = 0;
     a.act = HN_ACT_NONE; a.slope = 0.f;
     a.x_bytes = (((long long)d->N * d->Hout * d->Wout - 1) * d->ldy + d->Cout) * 4;
+    a.wx3 = static_cast<const unsigned short*>(wt_x3);
+    a.wx3_plane = hn_x3_plane((long long)d->Cin * d->KH * d->KW * d->Cout);
 
     if (!parity_decomposable(d->KH, d->KW, d->stride, d->dil)) {
         // stride 1: a plain convolution of dY with the flipped taps; other strides: the same kernel gathering from the
@@ -756,6 +913,7 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, cons
             if (Th > 0 && Tw > 0 && Hc > 0 && Wc > 0) {
                 ConvArgs c = a;
                 c.w = wt + wofs;
+                c.wx3 = a.wx3 != nullptr ? a.wx3 + wofs : nullptr;
                 c.Ho = Hc; c.Wo = Wc;
                 c.KH = Th; c.KW = Tw; c.in_dil = 1;
                 c.pad = d->dil * (Th - 1) - gh[ph].c;
@@ -776,15 +934,34 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, cons
     return HN_OK;
 }
 
-extern "C" int hn_weight_flip_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, int stride, int pad,
-                                        int dil, void* stream) {
-    if (w == nullptr || wt == nullptr || Cout <= 0 || KH <= 0 || KW <= 0 || Cin <= 0 || stride <= 0 || pad < 0 || dil <= 0)
+extern "C" int hn_weight_flip_transpose(const float* w, float* wt, void* wt_x3, int Cout, int KH, int KW, int Cin, int stride,
+                                        int pad, int dil, void* stream) {
+    if (w == nullptr || (wt == nullptr && wt_x3 == nullptr) || Cout <= 0 || KH <= 0 || KW <= 0 || Cin <= 0 || stride <= 0 ||
+        pad < 0 || dil <= 0)
         return HN_EINVAL;
     if (KH * KW > 64) return HN_ESHAPE;
     TapTable t;
     build_tap_table(t, Cout, KH, KW, Cin, stride, pad, dil);
     const dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, KH * KW);
-    HN_LAUNCH(weight_taps_transpose_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, wt, Cout, KH * KW, Cin, t);
+    HN_LAUNCH(weight_taps_transpose_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, wt,
+              static_cast<unsigned short*>(wt_x3), hn_x3_plane((long long)Cout * KH * KW * Cin), Cout, KH * KW, Cin, t);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
+
+extern "C" int hn_split_bf16x3(const float* src, void* dst, int64_t n, void* stream) {
+    if (src == nullptr || dst == nullptr || n <= 0) return HN_EINVAL;
+    const long long blocks = (n + 255) / 256;
+    HN_LAUNCH(split_bf16x3_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0,
+              static_cast<hipStream_t>(stream), src, static_cast<unsigned short*>(dst), (long long)n, hn_x3_plane(n));
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_set_conv_math(int math) {
+    if (math != MATH_F32 && math != MATH_X3) return HN_EINVAL;
+    g_conv_math = math;
+    return HN_OK;
+}
+
+extern "C" int hn_get_conv_math(void) { return g_conv_math; }

@@ -15,6 +15,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define HN_CHECK_LAUNCH() \
     do { if (hipGetLastError() != hipSuccess) return HN_ELAUNCH; } while (0)
 
+// bf16x3 weight planes: plane stride in elements for a matrix of n elements (HN_X3_PLANE in the header)
+static inline long long hn_x3_plane(long long n) { return HN_X3_PLANE(n); }
+
 static inline bool hn_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Blocks are dealt round-robin over the 8 XCDs (each with a private L2).  Remap the linear block id so

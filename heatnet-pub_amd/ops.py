@@ -146,8 +146,49 @@ if AUTOTUNE:
     atexit.register(_save_tune_cache)
 
 
-def _variant(bk=0, tm=0, tn=0):
-    return bk + 4 * tm + 16 * tn
+# ---- arithmetic of the convolution kernels --------------------------------------------------------------------------
+# "f32":    v_mfma_f32_32x32x2_f32 on the fp32 operands.
+# "bf16x3": every fp32 operand split exactly into three bf16 terms in the kernel, six bf16 MFMAs per product, fp32
+#           accumulate: the same fp32 result quality (see conv_igemm.hip, profiles/r01_bf16x3_probe.txt) at the bf16
+#           matrix-core rate / 6 instead of the fp32 one.  Shapes the bf16x3 kernels do not cover (Cin % 32 != 0) run
+#           on the f32 kernels either way.
+_MATH_CODES = {"f32": 1, "bf16x3": 2}
+CONV_MATH = os.environ.get("HEATNET_CONV_MATH", "f32")
+if CONV_MATH not in _MATH_CODES:
+    raise RuntimeError("HEATNET_CONV_MATH must be one of %s" % sorted(_MATH_CODES))
+
+
+def set_conv_math(name):
+    """Select the conv arithmetic ("f32" | "bf16x3") for subsequent launches; returns the previous setting."""
+    global CONV_MATH
+    if name not in _MATH_CODES:
+        raise ValueError("conv math must be one of %s" % sorted(_MATH_CODES))
+    prev, CONV_MATH = CONV_MATH, name
+    return prev
+
+
+def _variant(bk=0, tm=0, tn=0, math=0):
+    return bk + 4 * tm + 16 * tn + 64 * math
+
+
+def x3_plane(n):
+    """HN_X3_PLANE: elements per bf16 plane of a pre-split matrix of n elements."""
+    return (n + 7) & ~7
+
+
+def split_weight(w):
+    """The three bf16 planes (hi, mid, lo) of a dense fp32 weight, for the bf16x3 kernels; None under "f32"."""
+    if CONV_MATH != "bf16x3":
+        return None
+    n = w.numel()
+    out = torch.empty(3 * x3_plane(n), device=w.device, dtype=torch.int16)
+    check(_lib.load().hn_split_bf16x3(_ptr(w), _ptr(out), n, _stream()), "hn_split_bf16x3")
+    return out
+
+
+def _kind(kind):
+    """Tune-cache key of a launch kind under the current arithmetic."""
+    return kind if CONV_MATH == "f32" else kind + "." + CONV_MATH
 
 
 def _pick(kind, d, candidates, launch):
@@ -180,7 +221,9 @@ def _pick(kind, d, candidates, launch):
 
 def _igemm_candidates(cout):
     tiles = [(0, 0), (1, 2), (2, 1)] if cout > 64 else [(0, 0), (1, 1)]
-    return [_variant(bk, tm, tn) for tm, tn in tiles for bk in (1, 2)]
+    math = _MATH_CODES[CONV_MATH]
+    bks = (1, 2) if CONV_MATH == "f32" else (1,)  # the bf16x3 kernels have one K step
+    return [_variant(bk, tm, tn, math) for tm, tn in tiles for bk in bks]
 
 
 def _wgrad_candidates(cout, cin):
@@ -263,11 +306,13 @@ class _Conv2d(torch.autograd.Function):
             stats = None
         d = _desc(n, h, wd, cin, ldx, ho, wo, cout, cout, kh, kw, stride, pad, dil)
         s = _stream()
-        var = _pick("fwd", d, _igemm_candidates(cout), lambda v: check(
-            lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), None, ctypes.byref(d), act, slope, v, s), "hn_conv2d_fwd"))
+        wx3 = split_weight(w)
+        var = _pick(_kind("fwd"), d, _igemm_candidates(cout), lambda v: check(
+            lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), None, ctypes.byref(d), act, slope, v, s),
+            "hn_conv2d_fwd"))
         with _ConvTimer("fwd", d):
-            check(lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(stats), ctypes.byref(d), act, slope, var, s),
-                  "hn_conv2d_fwd")
+            check(lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), _ptr(stats), ctypes.byref(d), act, slope,
+                                    var, s), "hn_conv2d_fwd")
         ctx.geom = (stride, pad, dil, act, slope)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
@@ -306,17 +351,20 @@ class _Conv2d(torch.autograd.Function):
             fork = torch.cuda.Event()
             fork.record()  # dy (and the activation backward that produced it) is complete up to here
         if ctx.needs_input_grad[0]:
-            wt = torch.empty(cin * kh * kw * cout, device=x.device, dtype=torch.float32)
-            check(lib.hn_weight_flip_transpose(_ptr(w), _ptr(wt), cout, kh, kw, cin, stride, pad, dil, s),
+            nw = cin * kh * kw * cout
+            wt = torch.empty(nw, device=x.device, dtype=torch.float32)
+            wtx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16) if CONV_MATH == "bf16x3" else None
+            check(lib.hn_weight_flip_transpose(_ptr(w), _ptr(wt), _ptr(wtx3), cout, kh, kw, cin, stride, pad, dil, s),
                   "hn_weight_flip_transpose")
             dx = new_nhwc(n, cin, h, wd, x.device)
             dd = _desc(n, h, wd, cin, cin, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
-            var = _pick("dgrad", dd, _igemm_candidates(cin), lambda v: check(
-                lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(dx), None, 0, ctypes.byref(dd), v, s), "hn_conv2d_dgrad"))
+            var = _pick(_kind("dgrad"), dd, _igemm_candidates(cin), lambda v: check(
+                lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(wtx3), _ptr(dx), None, 0, ctypes.byref(dd), v, s),
+                "hn_conv2d_dgrad"))
             add, ldadd = (None, 0) if dskip is None else as_nhwc(dskip)
             with _ConvTimer("dgrad", dd):
-                check(lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(dx), _ptr(add), ldadd, ctypes.byref(dd), var, s),
-                      "hn_conv2d_dgrad")
+                check(lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(wtx3), _ptr(dx), _ptr(add), ldadd, ctypes.byref(dd), var,
+                                          s), "hn_conv2d_dgrad")
         elif dskip is not None:
             dx = dskip
         if ctx.needs_input_grad[1]:

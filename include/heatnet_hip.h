@@ -61,30 +61,51 @@ int hn_version(void);
 /* ---- convolution: nn.Conv2d in cm/models/extractors.py:71-77,111-146, cm/models/pspnet.py:13,18,32,57,
  *      cm/discriminator_model.py:40-44.  Implicit GEMM on v_mfma_f32_32x32x2_f32. ------------------------- */
 
-/* `variant` selects the kernel tiling: 0 = built-in heuristics, else bk + 4*tm + 16*tn with bk 1/2 = K step 32/16
- * (2 or 3 resident workgroups per CU) and tm/tn 1/2 = 64/128-row/-column block tile (0 = heuristic for that field).
- * Results are bitwise identical across variants; callers may time them per shape (heatnet-pub_amd/ops.py does).
+/* `variant` selects the kernel: 0 = built-in heuristics, else bk + 4*tm + 16*tn + 64*math with bk 1/2 = K step 32/16
+ * (2 or 3 resident workgroups per CU), tm/tn 1/2 = 64/128-row/-column block tile and math 1/2 = fp32 MFMA / bf16x3
+ * (see hn_set_conv_math); 0 = heuristic / library default for that field.  Within one math mode results are bitwise
+ * identical across variants; callers may time them per shape (heatnet-pub_amd/ops.py does).
  *
  * y = act(conv(x, w) + bias).  `bias` may be NULL.  If `stats` is non-NULL it must hold
  * HN_STAT_REPLICAS*2*Cout DOUBLES, zero on entry; the kernel adds per-channel sum and sum of squares of the PRE-activation output
  * (the batch statistics nn.BatchNorm2d needs, cm/models/extractors.py:72,75,77).  Statistics are accumulated
  * in double (global_atomic_add_f64), as the reference's CPU BatchNorm does. */
-int hn_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, double* stats,
+int hn_conv2d_fwd(const float* x, const float* w, const void* w_x3, const float* bias, float* y, double* stats,
                   const HnConvDesc* d, int act, float slope, int variant, void* stream);
+
+/* Arithmetic of hn_conv2d_fwd / hn_conv2d_dgrad for variant codes whose math field is 0 (see `variant` above):
+ * HN_MATH_F32 (0, the initial setting): v_mfma_f32_32x32x2_f32 on the fp32 operands.
+ * HN_MATH_BF16X3 (1): each fp32 operand is split exactly into three bf16 terms inside the kernel and the six products of
+ * weight >= 2^-24 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16 -- fp32-equivalent results (measured against fp64)
+ * at 16/6 of the fp32 matrix-core rate.  Geometries the bf16x3 kernels do not cover (Cin % 32 != 0, unaligned
+ * tensors, zero-dilated gathers) run on the fp32 kernels.  Process-wide; not synchronised with in-flight launches. */
+#define HN_MATH_F32 0
+#define HN_MATH_BF16X3 1
+int hn_set_conv_math(int math);
+int hn_get_conv_math(void);
+
+/* bf16x3 takes the WEIGHT operand pre-split (the activations / gradients are split inside the kernel): `w_x3` of
+ * hn_conv2d_fwd and `wt_x3` of hn_conv2d_dgrad are three consecutive planes (hi, mid, lo) of HN_X3_PLANE(n) bf16 elements
+ * each, n = Cout*KH*KW*Cin, every plane in the element order of the fp32 matrix (`w`, resp. `wt`).  hn_split_bf16x3 makes
+ * them from any fp32 array; hn_weight_flip_transpose writes them directly.  They may be NULL: the launch then runs on the
+ * fp32 MFMA.  The fp32 matrix must always be given (geometries bf16x3 does not cover use it). */
+#define HN_X3_PLANE(n) ((((long long)(n)) + 7) & ~7ll)
+int hn_split_bf16x3(const float* src, void* dst, int64_t n, void* stream);
 
 /* Operand of hn_conv2d_dgrad for a convolution with this stride / pad / dilation (same element count as w).
  * Stride 1: wt[Cin][KH][KW][Cout] = w[Cout][KH-1-kh][KW-1-kw][Cin].  Stride 2 with odd dilation: four consecutive blocks,
  * one per parity class (ph, pw) of the input pixels, each [Cin][Th*Tw][Cout] with only the taps that reach the class --
- * the data gradient then runs as four small stride-1 convolutions with no arithmetic on inserted zeros. */
-int hn_weight_flip_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, int stride, int pad, int dil,
-                             void* stream);
+ * the data gradient then runs as four small stride-1 convolutions with no arithmetic on inserted zeros.
+ * `wt` (fp32) and `wt_x3` (the bf16x3 planes of the same matrix, see above) are each optional, not both NULL. */
+int hn_weight_flip_transpose(const float* w, float* wt, void* wt_x3, int Cout, int KH, int KW, int Cin, int stride, int pad,
+                             int dil, void* stream);
 
 /* dx = conv_transpose(dy, w) [+ addend] for the forward geometry `d` (dy is N x Hout x Wout x Cout with pixel stride
  * d->ldy, dx is N x Hin x Win x Cin with pixel stride d->ldx); `wt` from hn_weight_flip_transpose.  `addend`
  * (optional, pixel stride ldadd, must not overlap dx) is a gradient that reached the same tensor through another branch --
  * the residual skip of cm/models/extractors.py:96-99 -- and is added in the epilogue instead of by a separate pass.
  * Overwrites dx. */
-int hn_conv2d_dgrad(const float* dy, const float* wt, float* dx, const float* addend, int ldadd,
+int hn_conv2d_dgrad(const float* dy, const float* wt, const void* wt_x3, float* dx, const float* addend, int ldadd,
                     const HnConvDesc* d, int variant, void* stream);
 
 /* dw[Cout][KH][KW][Cin] = sum over pixels of dy (x) x.  Overwrites dw.  split_k > 0: that many reduction splits;

@@ -58,8 +58,18 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture
+def conv_math(request):
+    """Run a test under the requested conv arithmetic (ops.CONV_MATH) and restore the previous one."""
+    ops = _ops()
+    prev = ops.set_conv_math(request.param)
+    yield request.param
+    ops.set_conv_math(prev)
+
+
+@pytest.mark.parametrize("conv_math", ["f32", "bf16x3"], indirect=True)
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
-def test_conv2d_forward_backward(dev, case):
+def test_conv2d_forward_backward(dev, case, conv_math):
     ops = _ops()
     n, cin, h, w, cout, k, stride, pad, dil, bias = case
     x = rnd(n, cin, h, w, seed=1)
@@ -87,6 +97,35 @@ def test_conv2d_forward_backward(dev, case):
     close(wd.grad, wr.grad, atol=2e-5 * np.sqrt(npix) + 1e-5, rtol=1e-4, what="dw")
     if bias:
         close(bd.grad, br.grad, atol=1e-5 * np.sqrt(npix) + 1e-5, rtol=1e-5, what="db")
+
+
+@pytest.mark.parametrize("case", [(2, 256, 24, 40, 256, 3, 1, 2, 2), (2, 1024, 20, 24, 256, 1, 1, 0, 1),
+                                  (2, 128, 32, 48, 128, 3, 2, 1, 1)], ids=str)
+def test_conv2d_bf16x3_is_fp32_accurate(dev, case):
+    """The bf16x3 kernels (exact 3-way bf16 split, 6 MFMAs, fp32 accumulate) against an fp64 convolution: their error
+    must not exceed the fp32-MFMA kernels' (both are dominated by fp32 accumulation rounding)."""
+    ops = _ops()
+    n, cin, h, w, cout, k, stride, pad, dil = case
+    x = F.relu(rnd(n, cin, h, w, seed=31))                      # post-ReLU activations, as in the network
+    wt = rnd(cout, cin, k, k, seed=32, scale=1.0 / np.sqrt(cin * k * k))
+    xr, wr = x.double().requires_grad_(), wt.double().requires_grad_()
+    yr = F.conv2d(xr, wr, None, stride=stride, padding=pad, dilation=dil)
+    gy = rnd(*yr.shape, seed=33)
+    yr.backward(gy.double())
+    errs = {}
+    for math in ("f32", "bf16x3"):
+        prev = ops.set_conv_math(math)
+        try:
+            xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+            wd = wt.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+            y = ops.conv2d(xd, wd, None, stride, pad, dil)
+            y.backward(gy.to(dev))
+            errs[math] = tuple(float((a.detach().cpu().double() - b.detach()).pow(2).mean().sqrt())
+                               for a, b in ((y, yr), (xd.grad, xr.grad), (wd.grad, wr.grad)))
+        finally:
+            ops.set_conv_math(prev)
+    for what, e32, ex3 in zip(("y", "dx", "dw"), errs["f32"], errs["bf16x3"]):
+        assert ex3 <= 1.25 * e32 + 1e-9, "%s: rms error vs fp64 %.3e (bf16x3) > 1.25 x %.3e (fp32 MFMA)" % (what, ex3, e32)
 
 
 def test_conv2d_fused_leaky_and_channel_slice_input(dev):
@@ -402,14 +441,14 @@ def test_c_abi_rejects_bad_arguments(dev):
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     good = _lib.HnConvDesc(1, 8, 8, 64, 64, 8, 8, 64, 64, 1, 1, 1, 0, 1)
-    assert lib.hn_conv2d_fwd(P(x), P(w), None, P(y), None, ctypes.byref(good), 0, 0.0, 0, s) == 0
-    assert lib.hn_conv2d_fwd(None, P(w), None, P(y), None, ctypes.byref(good), 0, 0.0, 0, s) == -1      # HN_EINVAL
-    assert lib.hn_conv2d_fwd(P(x), P(w), None, P(y), None, ctypes.byref(good), 7, 0.0, 0, s) == -1      # bad activation
-    assert lib.hn_conv2d_fwd(P(x), P(w), None, P(y), None, ctypes.byref(good), 0, 0.0, 99, s) == -1     # bad variant
+    assert lib.hn_conv2d_fwd(P(x), P(w), None, None, P(y), None, ctypes.byref(good), 0, 0.0, 0, s) == 0
+    assert lib.hn_conv2d_fwd(None, P(w), None, None, P(y), None, ctypes.byref(good), 0, 0.0, 0, s) == -1      # HN_EINVAL
+    assert lib.hn_conv2d_fwd(P(x), P(w), None, None, P(y), None, ctypes.byref(good), 7, 0.0, 0, s) == -1      # bad activation
+    assert lib.hn_conv2d_fwd(P(x), P(w), None, None, P(y), None, ctypes.byref(good), 0, 0.0, 99, s) == -1     # bad variant
     bad_shape = _lib.HnConvDesc(1, 8, 8, 64, 64, 7, 8, 64, 64, 1, 1, 1, 0, 1)                           # Hout inconsistent
-    assert lib.hn_conv2d_fwd(P(x), P(w), None, P(y), None, ctypes.byref(bad_shape), 0, 0.0, 0, s) == -4  # HN_ESHAPE
+    assert lib.hn_conv2d_fwd(P(x), P(w), None, None, P(y), None, ctypes.byref(bad_shape), 0, 0.0, 0, s) == -4  # HN_ESHAPE
     bad_ld = _lib.HnConvDesc(1, 8, 8, 64, 32, 8, 8, 64, 64, 1, 1, 1, 0, 1)                              # ldx < Cin
-    assert lib.hn_conv2d_fwd(P(x), P(w), None, P(y), None, ctypes.byref(bad_ld), 0, 0.0, 0, s) == -1
+    assert lib.hn_conv2d_fwd(P(x), P(w), None, None, P(y), None, ctypes.byref(bad_ld), 0, 0.0, 0, s) == -1
     assert lib.hn_bn_act_fwd(P(x), 64, None, None, None, 0, P(y), 64, 64, 64, 1, None, 0.0, None, 0, s) == -1
     assert lib.hn_bn_act_fwd(P(x), 64, P(w), P(w), None, 0, P(y), 64, 64, 64, 1, None, 0.0, P(w), 48, s) == -1  # hw !| npix
     assert lib.hn_pyramid_pool_bwd(9, None, None, None, None, P(y), 64, 1, 8, 8, 64, s) == -1            # > 8 levels

@@ -50,21 +50,28 @@ def main():
         ho, wo = ops.conv_out_size(h, k, stride, pad, dil), ops.conv_out_size(w, k, stride, pad, dil)
         x = torch.randn(n, h, w, cin, device=dev)
         wt = torch.randn(cout, k, k, cin, device=dev) * 0.02
+        if os.environ.get("ZERO") == "1":  # data-dependent power: all-zero operands toggle no multiplier bits
+            x.zero_()
+            wt.zero_()
         y = torch.empty(n, ho, wo, cout, device=dev)
         dy = torch.randn(n, ho, wo, cout, device=dev)
         dx = torch.empty_like(x)
         dw = torch.empty_like(wt)
         wflip = torch.empty(cin * k * k * cout, device=dev)
+        nw = cin * k * k * cout
+        wx3 = torch.empty(3 * ops.x3_plane(nw), device=dev, dtype=torch.int16)
+        wflipx3 = torch.empty(3 * ops.x3_plane(nw), device=dev, dtype=torch.int16)
         d = _lib.HnConvDesc(n, h, w, cin, cin, ho, wo, cout, cout, k, k, stride, pad, dil)
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = lambda t: ctypes.c_void_p(t.data_ptr())
-        _lib.check(lib.hn_weight_flip_transpose(P(wt), P(wflip), cout, k, k, cin, stride, pad, dil, s), "flip")
+        _lib.check(lib.hn_weight_flip_transpose(P(wt), P(wflip), P(wflipx3), cout, k, k, cin, stride, pad, dil, s), "flip")
+        _lib.check(lib.hn_split_bf16x3(P(wt), P(wx3), nw, s), "split")
         flops = 2.0 * n * ho * wo * cout * k * k * cin
         res = {}
         if "fwd" in kinds:
-            res["fwd"] = timeit(lambda: _lib.check(lib.hn_conv2d_fwd(P(x), P(wt), None, P(y), None, ctypes.byref(d), 0, 0.0, VAR, s), "fwd"))
+            res["fwd"] = timeit(lambda: _lib.check(lib.hn_conv2d_fwd(P(x), P(wt), P(wx3), None, P(y), None, ctypes.byref(d), 0, 0.0, VAR, s), "fwd"))
         if "dgrad" in kinds:
-            res["dgrad"] = timeit(lambda: _lib.check(lib.hn_conv2d_dgrad(P(dy), P(wflip), P(dx), None, 0, ctypes.byref(d), VAR, s), "dgrad"))
+            res["dgrad"] = timeit(lambda: _lib.check(lib.hn_conv2d_dgrad(P(dy), P(wflip), P(wflipx3), P(dx), None, 0, ctypes.byref(d), VAR, s), "dgrad"))
         if "wgrad" in kinds:
             res["wgrad"] = timeit(lambda: _lib.check(lib.hn_conv2d_wgrad(P(x), P(dy), P(dw), ctypes.byref(d), SPLIT, VAR, s), "wgrad"))
         cols = ["%10.1f" % (flops / res[k2] / 1e9) if k2 in res else "%10s" % "-" for k2 in ("fwd", "dgrad", "wgrad")]
