@@ -417,15 +417,268 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     }
 }
 
-template <int TM, int TN, int MODE, int BKP>
+
+// ---- bf16x3 weight gradient ------------------------------------------------------------------------------------------
+// Same GEMM on the bf16 matrix cores with fp32-equivalent accuracy (see conv_igemm.hip, MATH_X3): both operands are
+// split exactly into three bf16 terms when they are staged, six v_mfma_f32_32x32x16_bf16 per product.  The reduction
+// index (pixel) is the slow one of both NHWC operands, so the LDS images stay [pixel][channel] (a thread writes the
+// 8 B of its 4 channels of one pixel) and the MFMA fragments -- 8 consecutive pixels of one channel per lane -- are
+// fetched with the transposing LDS read ds_read_b64_tr_b16 (16 lanes read a 4-pixel x 16-channel block and receive
+// one channel's 4 pixels each).  The 64-B column blocks of a pixel row are XOR-swizzled with the pixel index so that
+// the 4 rows of a transposed read fall into 4 different bank groups.
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 hh = (__bf16)v[e];
+        const float r = v[e] - (float)hh;  // exact
+        const __bf16 mm = (__bf16)r;
+        const float r2 = r - (float)mm;    // exact
+        h[e] = hh;
+        m[e] = mm;
+        l[e] = (__bf16)r2;
+    }
+}
+
+__device__ __forceinline__ bf16x4 lds_read_tr(const char* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+#else
+    return bf16x4{};
+#endif
+}
+
+// byte offset of (pixel k, channel c) in a [32][B] bf16 image: 64-B column blocks swizzled by the pixel index
+template <int B>
+__device__ __forceinline__ int x3_off(int k, int c) {
+    const int swz = B >= 128 ? (k & 3) : ((k >> 1) & 1);
+    return k * (2 * B) + ((((c >> 5) ^ swz) << 6) | ((c & 31) * 2));
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p) {
+    constexpr int BKP = 32;
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int PLANE_A = BKP * BM * 2, PLANE_B = BKP * BN * 2;  // bytes per bf16 plane
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* As = reinterpret_cast<char*>(smem);  // [3][32][BM] bf16   dY tile
+    char* Bs = As + 3 * PLANE_A;               // [3][32][BN] bf16   gathered X tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles = p.ntm * p.ntn;
+    const int logical = hn_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / tiles, tile = logical - split * tiles;
+    const int tile_m = tile % p.ntm, tile_n = tile / p.ntm;
+    const int co0 = tile_m * BM, n0 = tile_n * BN;
+    const int total_chunks = (p.M + BKP - 1) / BKP;
+    const int c_begin = split * p.chunks_per_split;
+    const int c_end = min(total_chunks, c_begin + p.chunks_per_split);
+    const int hw = p.Ho * p.Wo;
+
+    constexpr int CA = BM / 4, CB = BN / 4;               // 16-B pieces per pixel row
+    constexpr int RA = (BKP * CA) / 256, RB = (BKP * CB) / 256;
+    constexpr int ROWS_A = 256 / CA, ROWS_B = 256 / CB;   // pixel rows covered by one pass of the 256 threads
+    f32x4 va[2][RA], vb[2][RB];                           // two staging sets: two reduction steps of loads in flight
+
+    const int tap = n0 / p.C, ci0 = n0 - tap * p.C;       // a tile's column range lies inside one tap (C % BN == 0)
+    const int vkh = tap / p.KW, vkw = tap - vkh * p.KW;
+    const int a_c4 = tid % CA, a_r0 = tid / CA;
+    const int b_c4 = tid % CB, b_r0 = tid / CB;
+    const bool a_col_ok = co0 + a_c4 * 4 < p.K;
+    int hq[RB], wq[RB], wo_[RB], ho_[RB];
+    long long xoff[RB];
+    unsigned a_voff[RA];
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+        const int pix = c_begin * BKP + b_r0 + ROWS_B * q;
+        const int n = pix / hw, rem = pix - n * hw;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        ho_[q] = ho;
+        wo_[q] = wo;
+        hq[q] = ho * p.stride - p.pad + vkh * p.dil;
+        wq[q] = wo * p.stride - p.pad + vkw * p.dil;
+        xoff[q] = ((long long)(n * p.H + hq[q]) * p.W + wq[q]) * p.ldx + ci0 + b_c4 * 4;
+    }
+    const unsigned x_records = (unsigned)p.x_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, x_records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_dy =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (unsigned)p.dy_bytes, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < RA; ++q)
+        a_voff[q] = a_col_ok ? (unsigned)(((a_r0 + ROWS_A * q) * p.ldy + co0 + a_c4 * 4) * 4) : (unsigned)p.dy_bytes;
+    const long long step_w = (long long)p.stride * p.ldx;
+    const long long step_h = (long long)p.stride * p.W * p.ldx;
+    const long long wrap_w = step_h - (long long)p.Wo * step_w;
+    const long long wrap_h = (long long)p.H * p.W * p.ldx - (long long)p.Ho * step_h;
+
+    int fetch_chunk = c_begin;
+    auto load_chunk = [&](f32x4 (&da)[RA], f32x4 (&db)[RB]) {
+        const int p0 = fetch_chunk * BKP;
+        const unsigned adv = (unsigned)((long long)p0 * p.ldy * 4);
+#pragma unroll
+        for (int q = 0; q < RA; ++q) {
+            const unsigned off = a_voff[q] + adv;
+            da[q] = buffer_load16(rsrc_dy, off < a_voff[q] ? 0xFFFFFFFFu : off, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int pix = p0 + b_r0 + ROWS_B * q;
+            const bool ok = (pix < p.M) & ((unsigned)hq[q] < (unsigned)p.H) & ((unsigned)wq[q] < (unsigned)p.W);
+            db[q] = buffer_load16(rsrc_x, ok ? (unsigned)(xoff[q] * 4) : x_records, 0);
+            wo_[q] += BKP;
+            wq[q] += BKP * p.stride;
+            xoff[q] += BKP * step_w;
+            while (wo_[q] >= p.Wo) {
+                wo_[q] -= p.Wo;
+                wq[q] -= p.Wo * p.stride;
+                ho_[q] += 1;
+                hq[q] += p.stride;
+                xoff[q] += wrap_w;
+                if (ho_[q] >= p.Ho) {
+                    ho_[q] -= p.Ho;
+                    hq[q] -= p.Ho * p.stride;
+                    xoff[q] += wrap_h;
+                }
+            }
+        }
+        ++fetch_chunk;
+    };
+    auto store_chunk = [&](const f32x4 (&sa)[RA], const f32x4 (&sb)[RB]) {
+#pragma unroll
+        for (int q = 0; q < RA; ++q) {
+            bf16x4 h, m, l;
+            split3(sa[q], h, m, l);
+            char* dst = As + x3_off<BM>(a_r0 + ROWS_A * q, a_c4 * 4);
+            *reinterpret_cast<bf16x4*>(dst) = h;
+            *reinterpret_cast<bf16x4*>(dst + PLANE_A) = m;
+            *reinterpret_cast<bf16x4*>(dst + 2 * PLANE_A) = l;
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            bf16x4 h, m, l;
+            split3(sb[q], h, m, l);
+            char* dst = Bs + x3_off<BN>(b_r0 + ROWS_B * q, b_c4 * 4);
+            *reinterpret_cast<bf16x4*>(dst) = h;
+            *reinterpret_cast<bf16x4*>(dst + PLANE_B) = m;
+            *reinterpret_cast<bf16x4*>(dst + 2 * PLANE_B) = l;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed-read duty of this lane (see tools/probes/tr_read_probe.hip): within its 16-lane group, lane 4q+pp
+    // supplies the address of pixel row q, channels 4pp..4pp+3 of the group's 16-channel block; it receives the 4
+    // pixels of channel (lane & 15) of that block.  Lane halves take pixels 0..7 / 8..15 of the 16-pixel group.
+    const int lh = lane >> 5, g1 = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int krow = 8 * lh + tq;
+    int offA[TM], offB[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) offA[i] = x3_off<BM>(krow, (wm * TM + i) * 32 + 16 * g1 + 4 * tp);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) offB[j] = x3_off<BN>(krow, (wn * TN + j) * 32 + 16 * g1 + 4 * tp);
+
+    auto x3_group = [&](int g) {
+        bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const char* a = As + s3 * PLANE_A + g * 16 * (2 * BM) + offA[i];
+                const bf16x4 lo = lds_read_tr(a), hi = lds_read_tr(a + 4 * (2 * BM));
+                fa[i][s3] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const char* b = Bs + s3 * PLANE_B + g * 16 * (2 * BN) + offB[j];
+                const bf16x4 lo = lds_read_tr(b), hi = lds_read_tr(b + 4 * (2 * BN));
+                fb[j][s3] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);  // mid*mid
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);  // hi*lo
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);  // lo*hi
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);  // hi*mid
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);  // mid*hi
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);  // hi*hi
+                acc[i][j] = c;
+            }
+    };
+    // every lane takes part in every transposed read (EXEC all ones): the loop below has no lane-dependent control flow
+    auto x3_step = [&](bool more, int cur) {
+        if (more) load_chunk(va[cur ^ 1], vb[cur ^ 1]);
+        store_chunk(va[cur], vb[cur]);
+        __syncthreads();
+        x3_group(0);
+        x3_group(1);
+        __syncthreads();
+    };
+    const int nch = c_end - c_begin;
+    if (nch > 0) {
+        load_chunk(va[0], vb[0]);
+        int kc = 0;
+        for (; kc + 1 < nch; kc += 2) {
+            x3_step(true, 0);
+            x3_step(kc + 2 < nch, 1);
+        }
+        if (kc < nch) x3_step(false, 0);
+    }
+
+    const int lr = lane & 31;
+    const bool full = (co0 + BM <= p.K) && (n0 + BN <= p.Kdim);
+    auto finish = [&](auto full_tag, auto atomic_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        constexpr bool ATOMIC = decltype(atomic_tag)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + lr;
+            const bool nok = FULL || n < p.Kdim;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rbase = co0 + (wm * TM + i) * 32 + 4 * lh;
+                float* dst = p.dw + (size_t)rbase * p.Kdim + n;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    if (FULL || (nok && rbase + ro < p.K)) {
+                        if constexpr (ATOMIC) atomicAdd(dst + (size_t)ro * p.Kdim, acc[i][j][r]);
+                        else dst[(size_t)ro * p.Kdim] = acc[i][j][r];
+                    }
+                }
+            }
+        }
+    };
+    if (p.atomic) {
+        if (full) finish(std::true_type{}, std::true_type{});
+        else finish(std::false_type{}, std::true_type{});
+    } else {
+        if (full) finish(std::true_type{}, std::false_type{});
+        else finish(std::false_type{}, std::false_type{});
+    }
+}
+
+template <int TM, int TN, int MODE, int BKP, bool X3 = false>
 int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int lds = 2 * BKP * (BM + BN) * (int)sizeof(float);
+    constexpr int lds = X3 ? 3 * BKP * (BM + BN) * 2 : 2 * BKP * (BM + BN) * (int)sizeof(float);
+    const void* kern = X3 ? reinterpret_cast<const void*>(conv_wgrad_x3_kernel<TM, TN>)
+                          : reinterpret_cast<const void*>(conv_wgrad_kernel<TM, TN, MODE, BKP>);
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<TM, TN, MODE, BKP>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return HN_ELAUNCH;
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return HN_ELAUNCH;
         configured = true;
     }
     a.ntm = (a.K + BM - 1) / BM;
@@ -449,15 +702,17 @@ int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     if (a.atomic) {
         if (hipMemsetAsync(a.dw, 0, (size_t)a.K * a.Kdim * sizeof(float), stream) != hipSuccess) return HN_ELAUNCH;
     }
-    HN_LAUNCH((conv_wgrad_kernel<TM, TN, MODE, BKP>), dim3(tiles * split_k), dim3(256), lds, stream, a);
+    if constexpr (X3) HN_LAUNCH((conv_wgrad_x3_kernel<TM, TN>), dim3(tiles * split_k), dim3(256), lds, stream, a);
+    else HN_LAUNCH((conv_wgrad_kernel<TM, TN, MODE, BKP>), dim3(tiles * split_k), dim3(256), lds, stream, a);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
 
-template <int MODE, int BKP>
+template <int MODE, int BKP, bool X3 = false>
 int dispatch_wgrad(const WgradArgs& a, bool wide_m, bool wide_n, int split_k, hipStream_t s) {
-    if (wide_m) return wide_n ? launch_wgrad<2, 2, MODE, BKP>(a, split_k, s) : launch_wgrad<2, 1, MODE, BKP>(a, split_k, s);
-    return wide_n ? launch_wgrad<1, 2, MODE, BKP>(a, split_k, s) : launch_wgrad<1, 1, MODE, BKP>(a, split_k, s);
+    if (wide_m)
+        return wide_n ? launch_wgrad<2, 2, MODE, BKP, X3>(a, split_k, s) : launch_wgrad<2, 1, MODE, BKP, X3>(a, split_k, s);
+    return wide_n ? launch_wgrad<1, 2, MODE, BKP, X3>(a, split_k, s) : launch_wgrad<1, 1, MODE, BKP, X3>(a, split_k, s);
 }
 
 }  // namespace
@@ -468,9 +723,9 @@ extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const
     if (d->N <= 0 || d->Hin <= 0 || d->Win <= 0 || d->Cin <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0 ||
         d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->dil <= 0 || d->pad < 0 || d->ldx < d->Cin || d->ldy < d->Cout)
         return HN_EINVAL;
-    if (variant < 0 || variant >= 48) return HN_EINVAL;
+    if (variant < 0 || variant >= 192) return HN_EINVAL;
     // same encoding as hn_conv2d_fwd; the K-step field selects the pixel step (1 -> 32, 2 -> 16)
-    const int bk_sel = variant & 3, tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3;
+    const int bk_sel = variant & 3, tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3, math_sel = variant >> 6;
     if (bk_sel == 3 || tm_sel == 3 || tn_sel == 3) return HN_EINVAL;
     WgradArgs a;
     a.x = x; a.dy = dy; a.dw = dw;
@@ -491,6 +746,12 @@ extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const
         if (tn_sel == 1) wide_n = false;  // a 128-wide column tile needs Cin % 128 == 0; 64 is always allowed here
         const bool buf_ok = a.x_bytes < 0xFFFF0000ll && a.dy_bytes + 64ll * d->ldy * 4 < 0xFFFF0000ll;
         const bool p16 = bk_sel == 2;
+        // bf16x3: tiles are whole 64-channel blocks of dY as well (no partial column pieces in the transposed reads)
+        const bool x3 = (math_sel ? math_sel == 2 : hn_get_conv_math() == HN_MATH_BF16X3) && buf_ok && d->Cout % 64 == 0;
+        if (x3) {
+            if (d->Cout % 128 != 0) wide_m = false;
+            return dispatch_wgrad<WG_VEC_BUF, 32, true>(a, wide_m, wide_n, split_k, s);
+        }
 #ifdef HN_WG_DMA
         if (buf_ok) return dispatch_wgrad<WG_VEC_DMA, 32>(a, wide_m, wide_n, split_k, s);  // experiment: LDS-DMA staging
 #endif

@@ -156,6 +156,12 @@ _MATH_CODES = {"f32": 1, "bf16x3": 2}
 CONV_MATH = os.environ.get("HEATNET_CONV_MATH", "f32")
 if CONV_MATH not in _MATH_CODES:
     raise RuntimeError("HEATNET_CONV_MATH must be one of %s" % sorted(_MATH_CODES))
+# diagnostics only: comma-separated launch kinds (fwd, dgrad, wgrad) kept on the fp32 MFMA while CONV_MATH is bf16x3
+_MATH_F32_KINDS = set(filter(None, os.environ.get("HEATNET_CONV_MATH_F32_KINDS", "").split(",")))
+
+
+def _math(kind):
+    return "f32" if kind in _MATH_F32_KINDS else CONV_MATH
 
 
 def set_conv_math(name):
@@ -178,7 +184,7 @@ def x3_plane(n):
 
 def split_weight(w):
     """The three bf16 planes (hi, mid, lo) of a dense fp32 weight, for the bf16x3 kernels; None under "f32"."""
-    if CONV_MATH != "bf16x3":
+    if _math("fwd") != "bf16x3":
         return None
     n = w.numel()
     out = torch.empty(3 * x3_plane(n), device=w.device, dtype=torch.int16)
@@ -188,7 +194,7 @@ def split_weight(w):
 
 def _kind(kind):
     """Tune-cache key of a launch kind under the current arithmetic."""
-    return kind if CONV_MATH == "f32" else kind + "." + CONV_MATH
+    return kind if _math(kind) == "f32" else kind + "." + _math(kind)
 
 
 def _pick(kind, d, candidates, launch):
@@ -219,17 +225,19 @@ def _pick(kind, d, candidates, launch):
     return best
 
 
-def _igemm_candidates(cout):
+def _igemm_candidates(cout, kind):
     tiles = [(0, 0), (1, 2), (2, 1)] if cout > 64 else [(0, 0), (1, 1)]
-    math = _MATH_CODES[CONV_MATH]
-    bks = (1, 2) if CONV_MATH == "f32" else (1,)  # the bf16x3 kernels have one K step
+    math = _MATH_CODES[_math(kind)]
+    bks = (1, 2) if _math(kind) == "f32" else (1,)  # the bf16x3 kernels have one K step
     return [_variant(bk, tm, tn, math) for tm, tn in tiles for bk in bks]
 
 
 def _wgrad_candidates(cout, cin):
     tms = (0, 1) if cout > 64 else (0,)
     tns = (0, 1) if cin % 128 == 0 else (0,)
-    return [(split, _variant(bk, tm, tn)) for tm in tms for tn in tns for bk in (1, 2) for split in (0, -2, -3, -4)]
+    math = _MATH_CODES[_math("wgrad")]
+    bks = (1, 2) if _math("wgrad") == "f32" else (1,)
+    return [(split, _variant(bk, tm, tn, math)) for tm in tms for tn in tns for bk in bks for split in (0, -2, -3, -4)]
 
 
 # ---- dgrad || wgrad overlap ----------------------------------------------------------------------------------------
@@ -307,7 +315,7 @@ class _Conv2d(torch.autograd.Function):
         d = _desc(n, h, wd, cin, ldx, ho, wo, cout, cout, kh, kw, stride, pad, dil)
         s = _stream()
         wx3 = split_weight(w)
-        var = _pick(_kind("fwd"), d, _igemm_candidates(cout), lambda v: check(
+        var = _pick(_kind("fwd"), d, _igemm_candidates(cout, "fwd"), lambda v: check(
             lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), None, ctypes.byref(d), act, slope, v, s),
             "hn_conv2d_fwd"))
         with _ConvTimer("fwd", d):
@@ -353,12 +361,12 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             nw = cin * kh * kw * cout
             wt = torch.empty(nw, device=x.device, dtype=torch.float32)
-            wtx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16) if CONV_MATH == "bf16x3" else None
+            wtx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16) if _math("dgrad") == "bf16x3" else None
             check(lib.hn_weight_flip_transpose(_ptr(w), _ptr(wt), _ptr(wtx3), cout, kh, kw, cin, stride, pad, dil, s),
                   "hn_weight_flip_transpose")
             dx = new_nhwc(n, cin, h, wd, x.device)
             dd = _desc(n, h, wd, cin, cin, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
-            var = _pick(_kind("dgrad"), dd, _igemm_candidates(cin), lambda v: check(
+            var = _pick(_kind("dgrad"), dd, _igemm_candidates(cin, "dgrad"), lambda v: check(
                 lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(wtx3), _ptr(dx), None, 0, ctypes.byref(dd), v, s),
                 "hn_conv2d_dgrad"))
             add, ldadd = (None, 0) if dskip is None else as_nhwc(dskip)
@@ -369,7 +377,7 @@ class _Conv2d(torch.autograd.Function):
             dx = dskip
         if ctx.needs_input_grad[1]:
             dw = torch.empty((cout, kh, kw, cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
-            split, var = _pick("wgrad", d, _wgrad_candidates(cout, cin), lambda sv: check(
+            split, var = _pick(_kind("wgrad"), d, _wgrad_candidates(cout, cin), lambda sv: check(
                 lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), sv[0], sv[1], s), "hn_conv2d_wgrad"))
             if OVERLAP and _conv_prof is None and ctx.needs_input_grad[0]:
                 # the dgrad above is already queued on the main stream; wgrad runs beside it on the side stream

