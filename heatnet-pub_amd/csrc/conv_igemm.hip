@@ -19,7 +19,7 @@
 // MATH_X3 ("bf16x3"): the same fp32 product computed on the bf16 matrix cores.  Every fp32 operand is split exactly into
 // three bf16 terms (x = hi + mid + lo, round-to-nearest at each level) when it is staged into LDS, and the six products
 // whose weight is >= 2^-24 of the result (mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi; each exact in fp32) are
-// accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest terms first.  Measured against fp64 this is as accurate as
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16, smallest terms first.  Measured against fp64 this is as accurate as
 // the fp32 MFMA (profiles/r01_bf16x3_probe.txt: rms error 0.38-0.57 x 2^-24 of sum|products| vs 0.44-0.50) at 16/6
 // of its matrix-core rate.  Not a reduced-precision mode: nothing of the fp32 operands is dropped above 2^-24.
 #include <type_traits>
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     constexpr bool STRIDED = MODE == MODE_SCALAR_STRIDED || MODE == MODE_VEC_STRIDED;
     constexpr bool BUF = MODE == MODE_VEC_BUF;
     constexpr bool X3 = MATH == MATH_X3;
+    constexpr bool S16 = X3;  // bf16x3 runs on v_mfma_f32_16x16x32_bf16: accumulators hold 16x16 sub-blocks (acc_row / acc_col)
     static_assert(!X3 || (BUF && BK == 32), "bf16x3 math is built for the buffer loaders at K step 32");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -342,18 +343,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     // Accumulators start at zero -- or at the addend (a gradient that reached this tensor through another branch): its
     // loads are issued here, ahead of the operand prologue, and their latency disappears behind the first K steps, so
     // the epilogue stays a pure store loop.  The addend never overlaps the output (header contract).
+    // Accumulator element r of acc[i][j] (a 32x32 block of the tile):
+    //   32x32 MFMA:  column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    //   16x16 MFMA:  registers 4s..4s+3 hold sub-block s = 2 * (row half) + (column half):
+    //                column = 16 * ((r >> 2) & 1) + (lane & 15), row = 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3)
+    // NC = distinct columns a lane holds per 32-column block; c2_of(r) = which of them element r belongs to.
+    constexpr int NC = S16 ? 2 : 1;
+    auto c2_of = [](int r) { return S16 ? (r >> 2) & 1 : 0; };
+    auto acc_row = [&](int i, int r) {  // row inside the block tile
+        return (wm * TM + i) * 32 + (S16 ? 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * lh);
+    };
+    auto acc_col = [&](int j, int c2) {  // global output channel
+        return n0 + (wn * TN + j) * 32 + (S16 ? 16 * c2 + (lane & 15) : lr);
+    };
     f32x16 acc[TM][TN];
     if (p.addend != nullptr && p.cps == 0) {
         const float* __restrict__ add = p.addend;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + lr;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int rloc = (wm * TM + i) * 32 + 4 * lh;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = rloc + (r & 3) + 8 * (r >> 2);
+                    const int row = acc_row(i, r), col = acc_col(j, c2_of(r));
                     float v = 0.f;
                     if (m0 + row < p.M && col < p.K) v = add[(size_t)rowinfo[row * 4 + 3] * p.ldadd + col];
                     acc[i][j][r] = v;
@@ -429,33 +441,42 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     };
 
     if constexpr (X3) {
-        // One LDS stage, register prefetch one K step ahead: split+store chunk kc | barrier | fetch chunk kc+1 |
-        // 2 x (fragments, 6*TM*TN MFMAs) | barrier.  The two workgroups of a CU run out of phase, so one wave's
+        // One LDS stage, register prefetch: fetch chunk kc+1 | split+store chunk kc | barrier | fragments and
+        // 6 * 4*TM*TN MFMAs | barrier.  The two workgroups of a CU run out of phase, so one wave's
         // split/store (VALU, LDS) overlaps the other's MFMAs on the same SIMD.
-        auto x3_group = [&](int g) {
-            const char* a = reinterpret_cast<const char*>(As) + ((wm * TM * 32 + lr) * X3_ROW + g * 32 + lh * 16);
-            const char* b = reinterpret_cast<const char*>(Bs) + ((wn * TN * 32 + lr) * X3_ROW + g * 32 + lh * 16);
-            bf16x8 fa[TM][3], fb[TN][3];
+        // v_mfma_f32_16x16x32_bf16 (measured 2-5 % faster than the 32x32x16 form of the same loop on random data: the chip
+        // holds a higher clock on it): one instruction spans the whole K step; the B fragments of the wave's 2*TN column
+        // blocks stay in registers while the 2*TM row blocks stream through
+        auto x3_k32 = [&]() {
+            const char* a = reinterpret_cast<const char*>(As) + ((wm * TM * 32 + (lane & 15)) * X3_ROW + (lane >> 4) * 16);
+            const char* b = reinterpret_cast<const char*>(Bs) + ((wn * TN * 32 + (lane & 15)) * X3_ROW + (lane >> 4) * 16);
+            bf16x8 fb[2 * TN][3];
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
+            for (int bj = 0; bj < 2 * TN; ++bj)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i][s3] = *reinterpret_cast<const bf16x8*>(a + (s3 * BM + i * 32) * X3_ROW);
+                for (int s3 = 0; s3 < 3; ++s3) fb[bj][s3] = *reinterpret_cast<const bf16x8*>(b + (s3 * BN + bj * 16) * X3_ROW);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j][s3] = *reinterpret_cast<const bf16x8*>(b + (s3 * BN + j * 32) * X3_ROW);
-            }
+            for (int bi = 0; bi < 2 * TM; ++bi) {
+                bf16x8 fa[3];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int s3 = 0; s3 < 3; ++s3) fa[s3] = *reinterpret_cast<const bf16x8*>(a + (s3 * BM + bi * 16) * X3_ROW);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);  // mid*mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);  // hi*lo
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);  // lo*hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);  // hi*mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);  // mid*hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);  // hi*hi
-                    acc[i][j] = c;
+                for (int bj = 0; bj < 2 * TN; ++bj) {
+                    const int sb = 4 * (2 * (bi & 1) + (bj & 1));
+                    f32x16& blk = acc[bi >> 1][bj >> 1];
+                    f32x4 c = {blk[sb], blk[sb + 1], blk[sb + 2], blk[sb + 3]};
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][1], c, 0, 0, 0);  // mid*mid
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][2], c, 0, 0, 0);  // hi*lo
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[bj][0], c, 0, 0, 0);  // lo*hi
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][1], c, 0, 0, 0);  // hi*mid
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][0], c, 0, 0, 0);  // mid*hi
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][0], c, 0, 0, 0);  // hi*hi
+                    blk[sb] = c[0];
+                    blk[sb + 1] = c[1];
+                    blk[sb + 2] = c[2];
+                    blk[sb + 3] = c[3];
                 }
+            }
         };
         // chunk kc+1 is fetched into the other staging set BEFORE chunk kc is split and stored, so a fetch has the
         // split/store phase plus the whole MFMA phase to land
@@ -470,8 +491,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
             store_lds(0, cur_a, cur_b);
 #endif
             __syncthreads();
-            x3_group(0);
-            x3_group(1);
+            x3_k32();
             __syncthreads();
         };
         load_a(va);
@@ -508,13 +528,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     if (p.cps > 0) {  // split-K partial: accumulate into the pre-initialised output
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + lr;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    const int row = m0 + acc_row(i, r), col = acc_col(j, c2_of(r));
                     if (row < p.M && col < p.K) {
                         const size_t opix = p.omap ? (size_t)rowinfo[(row - m0) * 4 + 3] : (size_t)row;
                         atomicAdd(p.y + opix * p.ldy + col, acc[i][j][r]);
@@ -525,18 +543,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         return;
     }
     const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.K);
-    float bias_v[TN];
+    float bias_v[TN][NC];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = min(n0 + (wn * TN + j) * 32 + lr, p.K - 1);
-        bias_v[j] = p.bias != nullptr ? p.bias[col] : 0.f;
-    }
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int c2 = 0; c2 < NC; ++c2) bias_v[j][c2] = p.bias != nullptr ? p.bias[min(acc_col(j, c2), p.K - 1)] : 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] += bias_v[j];
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += bias_v[j][c2_of(r)];
 
     // branch-free activation: out = v > 0 ? v : v * neg_slope  (none: 1, relu: 0, leaky/prelu: slope)
     const float neg_slope = p.act == HN_ACT_NONE ? 1.f : (p.act == HN_ACT_RELU ? 0.f : p.slope);
@@ -545,39 +562,45 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         constexpr bool OMAP = decltype(map_tag)::value;  // rows land on interleaved pixels (rowinfo[.][3])
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + lr;
-            const bool cok = FULL || col < p.K;
-            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
-                float* __restrict__ dst = p.y + (size_t)rbase * p.ldy + col;
+            for (int c2 = 0; c2 < NC; ++c2) {
+                const int col = acc_col(j, c2);
+                const bool cok = FULL || col < p.K;
+                float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ro = (r & 3) + 8 * (r >> 2);
-                    const float v = acc[i][j][r];
-                    if (FULL || (rbase + ro < p.M && cok)) {
-                        if constexpr (OMAP) {
-                            const size_t opix = (size_t)rowinfo[(rbase + ro - m0) * 4 + 3];
-                            p.y[opix * p.ldy + col] = v;
-                        } else {
-                            s1 += v;
-                            s2 += v * v;
-                            dst[(size_t)ro * p.ldy] = v > 0.f ? v : v * neg_slope;
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (c2_of(r) != c2) continue;
+                        const int row = m0 + acc_row(i, r);
+                        const float v = acc[i][j][r];
+                        if (FULL || (row < p.M && cok)) {
+                            if constexpr (OMAP) {
+                                const size_t opix = (size_t)rowinfo[(row - m0) * 4 + 3];
+                                p.y[opix * p.ldy + col] = v;
+                            } else {
+                                s1 += v;
+                                s2 += v * v;
+                                p.y[(size_t)row * p.ldy + col] = v > 0.f ? v : v * neg_slope;
+                            }
                         }
                     }
                 }
-            }
-            if (p.stats != nullptr) {
-                // <= 64 rows per lane were summed in fp32; everything across tiles is accumulated in double
-                // (global_atomic_add_f64), like the double accumulators of the CPU reference's BatchNorm.
-                double d1 = (double)s1, d2 = (double)s2;
-                d1 += __shfl_xor(d1, 32);
-                d2 += __shfl_xor(d2, 32);
-                if (lh == 0 && cok) {
-                    double* rep = p.stats + (size_t)(tile_m % HN_STAT_REPLICAS) * 2 * p.K;  // spread same-address atomics
-                    unsafeAtomicAdd(rep + col, d1);
-                    unsafeAtomicAdd(rep + p.K + col, d2);
+                if (p.stats != nullptr) {
+                    // <= 64 rows per lane were summed in fp32; everything across tiles is accumulated in double
+                    // (global_atomic_add_f64), like the double accumulators of the CPU reference's BatchNorm.
+                    double d1 = (double)s1, d2 = (double)s2;
+                    d1 += __shfl_xor(d1, 32);
+                    d2 += __shfl_xor(d2, 32);
+                    if constexpr (S16) {
+                        d1 += __shfl_xor(d1, 16);
+                        d2 += __shfl_xor(d2, 16);
+                    }
+                    if ((S16 ? (lane >> 4) : lh) == 0 && cok) {
+                        double* rep = p.stats + (size_t)(tile_m % HN_STAT_REPLICAS) * 2 * p.K;  // spread same-address atomics
+                        unsafeAtomicAdd(rep + col, d1);
+                        unsafeAtomicAdd(rep + p.K + col, d2);
+                    }
                 }
             }
         }
@@ -594,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 template <int TM, int TN, int MODE, int BK, int MATH = MATH_F32>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int lds = MATH == MATH_X3 ? 3 * (BM + BN) * X3_ROW + BM * 16
+    constexpr int lds = MATH != MATH_F32 ? 3 * (BM + BN) * X3_ROW + BM * 16
                                         : (2 * (BM + BN) * KStep<BK>::LDK + BM * 4) * (int)sizeof(float);
     static bool configured = false;  // raising the dynamic-LDS cap is idempotent; the flag only saves calls
     if (!configured) {

@@ -420,12 +420,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
 
 // ---- bf16x3 weight gradient ------------------------------------------------------------------------------------------
 // Same GEMM on the bf16 matrix cores with fp32-equivalent accuracy (see conv_igemm.hip, MATH_X3): both operands are
-// split exactly into three bf16 terms when they are staged, six v_mfma_f32_32x32x16_bf16 per product.  The reduction
+// split exactly into three bf16 terms when they are staged, six v_mfma_f32_16x16x32_bf16 per product.  The reduction
 // index (pixel) is the slow one of both NHWC operands, so the LDS images stay [pixel][channel] (a thread writes the
 // 8 B of its 4 channels of one pixel) and the MFMA fragments -- 8 consecutive pixels of one channel per lane -- are
 // fetched with the transposing LDS read ds_read_b64_tr_b16 (16 lanes read a 4-pixel x 16-channel block and receive
-// one channel's 4 pixels each).  The 64-B column blocks of a pixel row are XOR-swizzled with the pixel index so that
-// the 4 rows of a transposed read fall into 4 different bank groups.
+// one channel's 4 pixels each).
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
 
@@ -450,11 +449,13 @@ __device__ __forceinline__ bf16x4 lds_read_tr(const char* p) {
 #endif
 }
 
-// byte offset of (pixel k, channel c) in a [32][B] bf16 image: 64-B column blocks swizzled by the pixel index
+// byte offset of (pixel k, channel c) in a [32][B] bf16 image.  A transposed read of one 32-lane half fetches 32 B (16
+// channels) from each of pixel rows q..q+3 and 8+q..8+q+3: the 64-B column blocks are XOR-swizzled with the low pixel
+// bits and the 32-B halves inside a block with pixel bit 3, so those 8 pieces fall into 8 different bank groups.
 template <int B>
 __device__ __forceinline__ int x3_off(int k, int c) {
     const int swz = B >= 128 ? (k & 3) : ((k >> 1) & 1);
-    return k * (2 * B) + ((((c >> 5) ^ swz) << 6) | ((c & 31) * 2));
+    return k * (2 * B) + ((((c >> 5) ^ swz) << 6) | (((c & 31) ^ (((k >> 3) & 1) << 4)) * 2));
 }
 
 template <int TM, int TN>
@@ -575,55 +576,62 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // transposed-read duty of this lane (see tools/probes/tr_read_probe.hip): within its 16-lane group, lane 4q+pp
-    // supplies the address of pixel row q, channels 4pp..4pp+3 of the group's 16-channel block; it receives the 4
-    // pixels of channel (lane & 15) of that block.  Lane halves take pixels 0..7 / 8..15 of the 16-pixel group.
-    const int lh = lane >> 5, g1 = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
-    const int krow = 8 * lh + tq;
-    int offA[TM], offB[TN];
+    // transposed-read duty of this lane (tools/probes/tr_read_probe.hip): the 16-lane group g = lane >> 4 fetches pixels
+    // 8g .. 8g+7 (the k range of its lanes in the 16x16x32 operand) of one 16-channel block; lane 4q+pp of the group
+    // supplies the address of pixel row 8g+q (then +4), channels 4pp..4pp+3, and receives the pixels of channel lane & 15.
+    const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int krow = 8 * tg + tq;
+    int offA[2 * TM], offB[2 * TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) offA[i] = x3_off<BM>(krow, (wm * TM + i) * 32 + 16 * g1 + 4 * tp);
+    for (int i = 0; i < 2 * TM; ++i) offA[i] = x3_off<BM>(krow, (wm * TM * 2 + i) * 16 + 4 * tp);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) offB[j] = x3_off<BN>(krow, (wn * TN + j) * 32 + 16 * g1 + 4 * tp);
+    for (int j = 0; j < 2 * TN; ++j) offB[j] = x3_off<BN>(krow, (wn * TN * 2 + j) * 16 + 4 * tp);
 
-    auto x3_group = [&](int g) {
-        bf16x8 fa[TM][3], fb[TN][3];
+    // accumulator element r of acc[i][j]: registers 4s..4s+3 hold the 16x16 sub-block s = 2 * (row half) + (column half);
+    // column = 16 * ((r >> 2) & 1) + (lane & 15), row = 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3)
+    auto x3_k32 = [&]() {
+        bf16x8 fb[2 * TN][3];
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) {
+        for (int bj = 0; bj < 2 * TN; ++bj)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const char* a = As + s3 * PLANE_A + g * 16 * (2 * BM) + offA[i];
-                const bf16x4 lo = lds_read_tr(a), hi = lds_read_tr(a + 4 * (2 * BM));
-                fa[i][s3] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const char* b = Bs + s3 * PLANE_B + offB[bj];
+                const bf16x4 lo = lds_read_tr(b), hi = lds_read_tr(b + 4 * (2 * BN));
+                fb[bj][s3] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const char* b = Bs + s3 * PLANE_B + g * 16 * (2 * BN) + offB[j];
-                const bf16x4 lo = lds_read_tr(b), hi = lds_read_tr(b + 4 * (2 * BN));
-                fb[j][s3] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        for (int bi = 0; bi < 2 * TM; ++bi) {
+            bf16x8 fa[3];
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const char* a = As + s3 * PLANE_A + offA[bi];
+                const bf16x4 lo = lds_read_tr(a), hi = lds_read_tr(a + 4 * (2 * BM));
+                fa[s3] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int bj = 0; bj < 2 * TN; ++bj) {
+                const int sb = 4 * (2 * (bi & 1) + (bj & 1));
+                f32x16& blk = acc[bi >> 1][bj >> 1];
+                f32x4 c = {blk[sb], blk[sb + 1], blk[sb + 2], blk[sb + 3]};
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][1], c, 0, 0, 0);  // mid*mid
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][2], c, 0, 0, 0);  // hi*lo
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[bj][0], c, 0, 0, 0);  // lo*hi
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][1], c, 0, 0, 0);  // hi*mid
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][0], c, 0, 0, 0);  // mid*hi
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][0], c, 0, 0, 0);  // hi*hi
+                blk[sb] = c[0];
+                blk[sb + 1] = c[1];
+                blk[sb + 2] = c[2];
+                blk[sb + 3] = c[3];
             }
         }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                f32x16 c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);  // mid*mid
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);  // hi*lo
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);  // lo*hi
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);  // hi*mid
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);  // mid*hi
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);  // hi*hi
-                acc[i][j] = c;
-            }
     };
     // every lane takes part in every transposed read (EXEC all ones): the loop below has no lane-dependent control flow
     auto x3_step = [&](bool more, int cur) {
         if (more) load_chunk(va[cur ^ 1], vb[cur ^ 1]);
         store_chunk(va[cur], vb[cur]);
         __syncthreads();
-        x3_group(0);
-        x3_group(1);
+        x3_k32();
         __syncthreads();
     };
     const int nch = c_end - c_begin;
@@ -637,25 +645,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
         if (kc < nch) x3_step(false, 0);
     }
 
-    const int lr = lane & 31;
     const bool full = (co0 + BM <= p.K) && (n0 + BN <= p.Kdim);
     auto finish = [&](auto full_tag, auto atomic_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr bool ATOMIC = decltype(atomic_tag)::value;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + lr;
-            const bool nok = FULL || n < p.Kdim;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int rbase = co0 + (wm * TM + i) * 32 + 4 * lh;
-                float* dst = p.dw + (size_t)rbase * p.Kdim + n;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ro = (r & 3) + 8 * (r >> 2);
-                    if (FULL || (nok && rbase + ro < p.K)) {
-                        if constexpr (ATOMIC) atomicAdd(dst + (size_t)ro * p.Kdim, acc[i][j][r]);
-                        else dst[(size_t)ro * p.Kdim] = acc[i][j][r];
+                    const int row = co0 + (wm * TM + i) * 32 + 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3);
+                    const int n = n0 + (wn * TN + j) * 32 + 16 * ((r >> 2) & 1) + (lane & 15);
+                    if (FULL || (n < p.Kdim && row < p.K)) {
+                        float* dst = p.dw + (size_t)row * p.Kdim + n;
+                        if constexpr (ATOMIC) atomicAdd(dst, acc[i][j][r]);
+                        else *dst = acc[i][j][r];
                     }
                 }
             }
