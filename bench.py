@@ -11,10 +11,17 @@ A step = one pass of the hot path over one synthetic batch resident in HBM:
 N>1 is launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: one process per GPU,
 full replica each, gradients all-reduced by RCCL in flat buckets overlapped with backward (weak scaling).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernels -- the fp32-MFMA implicit-GEMM convolutions --
-as algorithmic conv FLOPs (2*M*N*K of every conv forward / data-gradient / weight-gradient launch) over the
-HIP-event time of exactly those launches, measured in an instrumented pass after the timed region.
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernels -- the implicit-GEMM convolutions -- as
+algorithmic conv FLOPs (2*M*N*K of every conv forward / data-gradient / weight-gradient launch) over the HIP-event time
+of exactly those launches, measured in an instrumented pass after the timed region.
 `cpu_baseline` times the CPU oracle (oracle/heatnet_ref.py, a port) on this host, on a bounded sample.
+
+Conv arithmetic (HEATNET_CONV_MATH): the default "bf16x3" computes the fp32 convolution on the
+bf16 matrix cores -- every fp32 operand split EXACTLY into three bf16 terms inside the kernel, the six products of weight
+>= 2^-24 accumulated in fp32 -- with the accuracy of the fp32 MFMA (tests/test_gpu_kernels.py::
+test_conv2d_bf16x3_is_fp32_accurate, profiles/r01_bf16x3_probe.txt); its roofline peak is the dense bf16 MFMA peak / 6.
+"f32" runs the same step on v_mfma_f32_32x32x2_f32.  At N=1 the other arithmetic is timed too, in the same process, and
+reported as `alt_conv_math` (same workload, same step, K steps), so both numbers come from one run.
 """
 import argparse
 import json
@@ -29,7 +36,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# MI355X_MICROARCH.md, dense peaks: v_mfma_f32_32x32x2_f32 157.3 TFLOP/s; bf16 MFMA ~2500 TFLOP/s, of which one fp32
+# product costs six MFMAs under bf16x3
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 6.0}
+KERNEL_LABEL = {"f32": "conv_igemm_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32)",
+                "bf16x3": "conv_igemm_kernel<..,MATH_X3> / conv_wgrad_x3_kernel (6 x v_mfma_f32_16x16x32_bf16 per fp32 "
+                          "product; peak = dense bf16 MFMA peak / 6)"}
+CONV_MATH_NOTE = {"f32": "f32: v_mfma_f32_32x32x2_f32 on the fp32 operands",
+                  "bf16x3": "bf16x3: fp32 operands split exactly into 3 bf16 terms in-kernel, 6 bf16 MFMAs per product, fp32 "
+                            "accumulate; error vs fp64 equal to the fp32 MFMA's (profiles/r01_bf16x3_probe.txt)"}
 H, W, BS = 320, 704, 8
 # conv FLOPs of one step in the REFERENCE's op graph (per image/pair x 8)
 REFERENCE_CONV_TFLOP = {"seg": 8 * 1.0738, "confmax_seg": 8 * 2.2532, "confmax_critic": 8 * 0.8484}
@@ -110,11 +125,13 @@ def measure_conv_roofline(step_fn, steps, workload, scale=1.0):
               for k, v in per_kind.items()}
     achieved = flops / ms / 1e9 if ms > 0 else 0.0
     ref_tflop = REFERENCE_CONV_TFLOP.get(workload) if scale == 1.0 else None
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": pmc_traffic(),
+    math = ops.CONV_MATH
+    peak = round(PEAK_TFLOPS[math], 1)
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4),
+            "traffic": pmc_traffic(math),
             "algorithmic_bytes_per_launch": round(nbytes / max(launches, 1)),
-            "kernel": "conv_igemm_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32)",
+            "kernel": KERNEL_LABEL[math], "conv_math": math,
             "launches_per_step": launches // steps,
             # executed = 2*M*N*K of the launches actually made (the pyramid bottleneck is applied per level at the
             # pooled resolution); reference = the same step in the reference's op graph
@@ -126,14 +143,15 @@ def measure_conv_roofline(step_fn, steps, workload, scale=1.0):
             "by_kind": detail}
 
 
-def pmc_traffic():
+def pmc_traffic(math):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE, separate runs of this same benchmark, FETCH_SIZE doubled per MI355X_MICROARCH.md): counters
     cannot be collected from inside this process, so the figure is read from profiles/ and is null if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    name, kernel = {"f32": ("r01_pmc_hbm_traffic.json", "conv_igemm_kernel<2, 2, 4, 32>"),
+                    "bf16x3": ("r01_pmc_hbm_traffic_bf16x3.json", "conv_igemm_kernel<2, 2, 4, 32, 1>")}[math]
     try:
-        with open(path) as f:
-            return round(json.load(f)["conv_igemm_kernel<2, 2, 4, 32>"]["hbm_bytes_per_launch"])
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return round(json.load(f)[kernel]["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
 
@@ -184,6 +202,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BS, help="images per GPU (default 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second timing under the other conv arithmetic")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -235,12 +254,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    from heatnet_amd import ops
+    scale = (args.height * args.width * args.batch) / float(H * W * BS)
     roof = None
     if rank == 0 and not args.no_roofline:
-        roof = measure_conv_roofline(step, max(1, min(3, args.steps)), args.workload,
-                                     scale=(args.height * args.width * args.batch) / float(H * W * BS))
+        roof = measure_conv_roofline(step, max(1, min(3, args.steps)), args.workload, scale=scale)
     if world > 1:
         dist.barrier()
+    alt = None
+    if world == 1 and not args.no_alt:
+        # the same step under the other conv arithmetic, timed the same way (N=1 only: like cpu_baseline, it is a
+        # reference figure printed beside the headline, not part of it)
+        main_math = ops.CONV_MATH
+        other = "f32" if main_math == "bf16x3" else "bf16x3"
+        ops.set_conv_math(other)
+        try:
+            for _ in range(max(2, args.warmup)):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            alt_elapsed = time.perf_counter() - t1
+            alt_roof = None
+            if not args.no_roofline:
+                r = measure_conv_roofline(step, max(1, min(3, args.steps)), args.workload, scale=scale)
+                alt_roof = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "conv_ms_per_step", "kernel")}
+            alt = {"conv_math": other, "value": round(args.batch * args.steps / alt_elapsed, 3), "unit": "images/s",
+                   "ms_per_step": round(1e3 * alt_elapsed / args.steps, 3), "steps": args.steps, "roofline": alt_roof}
+        finally:
+            ops.set_conv_math(main_math)
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline(args.workload)
@@ -256,8 +300,9 @@ def main():
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": names[args.workload], "global_batch": world * args.batch, "height": args.height,
                           "width": args.width,
-                          "parallelism": "dp%d" % world, "optimizer": "RMSprop lr=1e-4 (fused, flat arena)", "weights": "random init"},
-               "roofline": roof, "cpu_baseline": base}
+                          "parallelism": "dp%d" % world, "optimizer": "RMSprop lr=1e-4 (fused, flat arena)", "weights": "random init",
+                          "conv_math": CONV_MATH_NOTE[ops.CONV_MATH]},
+               "roofline": roof, "cpu_baseline": base, "alt_conv_math": alt}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

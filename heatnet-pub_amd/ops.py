@@ -153,7 +153,7 @@ if AUTOTUNE:
 #           matrix-core rate / 6 instead of the fp32 one.  Shapes the bf16x3 kernels do not cover (Cin % 32 != 0) run
 #           on the f32 kernels either way.
 _MATH_CODES = {"f32": 1, "bf16x3": 2}
-CONV_MATH = os.environ.get("HEATNET_CONV_MATH", "f32")
+CONV_MATH = os.environ.get("HEATNET_CONV_MATH", "bf16x3")
 if CONV_MATH not in _MATH_CODES:
     raise RuntimeError("HEATNET_CONV_MATH must be one of %s" % sorted(_MATH_CODES))
 # diagnostics only: comma-separated launch kinds (fwd, dgrad, wgrad) kept on the fp32 MFMA while CONV_MATH is bf16x3

@@ -18,3 +18,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def conv_math(request):
+    """Run a test under the requested conv arithmetic (heatnet_amd.ops.CONV_MATH: "f32" | "bf16x3"), then restore."""
+    from heatnet_amd import ops
+    prev = ops.set_conv_math(request.param)
+    yield request.param
+    ops.set_conv_math(prev)
+
+
+BOTH_MATHS = pytest.mark.parametrize("conv_math", ["f32", "bf16x3"], indirect=True)

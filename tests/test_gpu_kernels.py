@@ -58,15 +58,6 @@ CONV_CASES = [
 ]
 
 
-@pytest.fixture
-def conv_math(request):
-    """Run a test under the requested conv arithmetic (ops.CONV_MATH) and restore the previous one."""
-    ops = _ops()
-    prev = ops.set_conv_math(request.param)
-    yield request.param
-    ops.set_conv_math(prev)
-
-
 @pytest.mark.parametrize("conv_math", ["f32", "bf16x3"], indirect=True)
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
 def test_conv2d_forward_backward(dev, case, conv_math):

@@ -29,8 +29,9 @@ def _build(late, state_seed, dev):
     return net.to(dev)
 
 
+@pytest.mark.parametrize("conv_math", ["f32", "bf16x3"], indirect=True)
 @pytest.mark.parametrize("tag,late", [("late", True), ("early", False)])
-def test_segnet_forward_matches_reference_fixture(dev, golden_dir, tag, late):
+def test_segnet_forward_matches_reference_fixture(dev, golden_dir, tag, late, conv_math):
     """Train-mode and eval-mode logits + the five feature maps vs. fixtures produced by the reference (tol 1e-3)."""
     g = _load(golden_dir, "segnet_%s_2x64x96" % tag)
     net = _build(late, 1, dev)
@@ -110,7 +111,8 @@ def test_segnet_backward_matches_oracle(dev):
     assert float(np.exp(np.mean(np.log(ratios)))) < 2.0, ratios
 
 
-def test_fullres_minibatch_logits_and_miou(dev, golden_dir):
+@pytest.mark.parametrize("conv_math", ["f32", "bf16x3"], indirect=True)
+def test_fullres_minibatch_logits_and_miou(dev, golden_dir, conv_math):
     """BASELINE criterion: logits within 1e-3 and |d mIoU| < 1e-3 on the fixed 2x320x704 mini-batch."""
     from heatnet_amd import miou, train_step
     from oracle import heatnet_ref as R
@@ -152,8 +154,9 @@ def test_rgb18_config1(dev, golden_dir):
     np.testing.assert_allclose(net.final[0].weight.grad.cpu().numpy(), g["grad_final_w"], rtol=2e-3, atol=2e-5)
 
 
+@pytest.mark.parametrize("conv_math", ["f32", "bf16x3"], indirect=True)
 @pytest.mark.parametrize("adv", ["MSE", "BCE"])
-def test_confusion_maximisation_steps(dev, golden_dir, adv):
+def test_confusion_maximisation_steps(dev, golden_dir, adv, conv_math):
     """conv_segnet forward, one train_critic and one train_seg iteration (RMSprop) vs. the reference fixture."""
     from heatnet_amd import conf_segnet, train_step
     g = _load(golden_dir, "confstep_%s_2x256x256" % adv.lower())
