@@ -27,14 +27,14 @@ SIGNATURES = {
     "hn_conv2d_fwd": [P, P, P, P, P, P, DP, c_int, c_float, c_int, P],
     "hn_weight_flip_transpose": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_conv2d_dgrad": [P, P, P, P, P, c_int, DP, c_int, P],
-    "hn_conv2d_wgrad": [P, P, P, DP, c_int, c_int, P],
+    "hn_conv2d_wgrad": [P, P, P, DP, c_int, c_int, c_int, P],
     "hn_channel_sum": [P, c_int, c_i64, c_int, P, P],
     "hn_channel_stats": [P, c_int, c_i64, c_int, P, P],
     "hn_bn_finalize": [P, c_i64, P, P, P, P, c_float, c_float, P, P, P, P, c_int, P],
     "hn_bn_eval_params": [P, P, P, P, c_float, P, P, P, P, c_int, P],
     "hn_bn_act_fwd": [P, c_int, P, P, P, c_int, P, c_int, c_i64, c_int, c_int, P, c_float, P, c_i64, P],
-    "hn_bn_act_bwd_reduce": [P, c_int, P, c_int, P, c_int, P, P, P, P, c_i64, c_int, c_int, P, c_float, P, P, P, c_i64,
-                             P],
+    "hn_bn_act_bwd_reduce": [P, c_int, P, c_int, P, c_int, P, P, P, P, c_i64, c_int, c_int, P, c_float, P, P, P, P, P, P,
+                             c_i64, P],
     "hn_bn_act_bwd_apply": [P, c_int, P, c_int, P, c_int, P, P, P, P, P, P, c_i64, c_int, P, c_int, P, c_int,
                             c_i64, c_int, c_int, P, c_float, P, c_i64, P],
     "hn_act_bwd": [P, c_int, P, c_int, P, c_int, c_i64, c_int, c_int, c_float, P],

@@ -22,6 +22,7 @@
 // accumulated in fp32 by v_mfma_f32_16x16x32_bf16, smallest terms first.  Measured against fp64 this is as accurate as
 // the fp32 MFMA (profiles/r01_bf16x3_probe.txt: rms error 0.38-0.57 x 2^-24 of sum|products| vs 0.44-0.50) at 16/6
 // of its matrix-core rate.  Not a reduced-precision mode: nothing of the fp32 operands is dropped above 2^-24.
+#include <cstdlib>
 #include <type_traits>
 
 #include "hn_common.h"
@@ -67,6 +68,7 @@ struct ConvArgs {
     // follow-up pass.
     int cps;
     int M, Kdim, ntm, ntn;
+    int gm;  // row tiles per group of the tile order (see the kernel)
     int act;
     float slope;
     long long x_bytes;  // extent of the gathered tensor from p.x, for the buffer descriptors
@@ -125,7 +127,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     const int logical = hn_xcd_remap(blockIdx.x, gridDim.x);
     const int ntiles = p.ntm * p.ntn;
     const int split = logical / ntiles, tile = logical - split * ntiles;
-    const int tile_n = tile % p.ntn, tile_m = tile / p.ntn;
+    // Tile order inside an XCD's contiguous range: groups of `gm` row tiles are walked column by column, so the ~64
+    // workgroups an XCD runs at a time cover a gm x (64/gm) patch -- each A panel and each B panel in its L2 is shared
+    // by several of them -- instead of a few rows across every column.  gm = 1: row-major.
+    int tile_m, tile_n;
+    {
+        const int gm = p.gm, per_group = gm * p.ntn;
+        const int g = tile / per_group, in_g = tile - g * per_group;
+        const int first = g * gm, rows = min(gm, p.ntm - first);
+        tile_n = in_g / rows;
+        tile_m = first + (in_g - tile_n * rows);
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     for (int r = tid; r < BM; r += 256) {
@@ -629,6 +641,11 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     ConvArgs p = a;
     p.ntm = (a.M + BM - 1) / BM;
     p.ntn = (a.K + BN - 1) / BN;
+    // measured (profiles/r01_tile_order.txt): 8-row groups gain 4-6 % once there are >= 8 column tiles (the B panels
+    // of one group then outgrow an XCD's L2 in row-major order), and lose 1-2 % below that
+    static const int gm_env = getenv("HN_GROUP_M") ? atoi(getenv("HN_GROUP_M")) : 0;  // experiment knob
+    p.gm = gm_env > 0 ? gm_env : (p.ntn >= 8 ? 8 : 1);
+    if (p.gm > p.ntm) p.gm = p.ntm;
     int splits = 1;
     if (a.cps > 0) {  // a.cps is expressed in 32-wide K steps; rescale to this instantiation's step
         const int total = (a.Kdim + BK - 1) / BK;

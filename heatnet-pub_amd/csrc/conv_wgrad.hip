@@ -41,6 +41,7 @@ struct WgradArgs {
     int ntm, ntn; // tiles over Cout and over (tap, ci)
     int chunks_per_split;
     int atomic;
+    int dw_zeroed;  // the caller guarantees dW is all zero on entry: accumulate without a fill
     long long x_bytes, dy_bytes;
 };
 
@@ -704,7 +705,7 @@ int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     a.chunks_per_split = (total_chunks + split_k - 1) / split_k;
     split_k = (total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
     a.atomic = split_k > 1;
-    if (a.atomic) {
+    if (a.atomic && !a.dw_zeroed) {
         if (hipMemsetAsync(a.dw, 0, (size_t)a.K * a.Kdim * sizeof(float), stream) != hipSuccess) return HN_ELAUNCH;
     }
     if constexpr (X3) HN_LAUNCH((conv_wgrad_x3_kernel<TM, TN>), dim3(tiles * split_k), dim3(256), lds, stream, a);
@@ -723,7 +724,7 @@ int dispatch_wgrad(const WgradArgs& a, bool wide_m, bool wide_n, int split_k, hi
 }  // namespace
 
 extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant,
-                               void* stream) {
+                               int flags, void* stream) {
     if (x == nullptr || dy == nullptr || dw == nullptr || d == nullptr) return HN_EINVAL;
     if (d->N <= 0 || d->Hin <= 0 || d->Win <= 0 || d->Cin <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0 ||
         d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->dil <= 0 || d->pad < 0 || d->ldx < d->Cin || d->ldy < d->Cout)
@@ -740,6 +741,7 @@ extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const
     a.M = d->N * d->Hout * d->Wout;
     a.Kdim = d->KH * d->KW * d->Cin;
     a.ntm = a.ntn = a.chunks_per_split = a.atomic = 0;
+    a.dw_zeroed = (flags & HN_WGRAD_DW_ZEROED) != 0;
     a.x_bytes = (((long long)d->N * d->Hin * d->Win - 1) * d->ldx + d->Cin) * 4;
     a.dy_bytes = (((long long)a.M - 1) * d->ldy + d->Cout) * 4;
     hipStream_t s = static_cast<hipStream_t>(stream);

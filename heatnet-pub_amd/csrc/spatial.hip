@@ -417,12 +417,17 @@ __global__ __launch_bounds__(256) void pyramid_merge_kernel(const float* __restr
 // dx = sum over pyramid levels of adaptive_avg_pool backward: every level's gradient is scattered back to the
 // full-resolution map in ONE pass (one write of dx instead of one per level plus the adds between them).  The bins
 // that contain row h at output size s are i in [floor(h*s/H), ceil((h+1)*s/H) - 1] (1 or 2 of them).
+// floor(a / b) for 0 <= a < 2^21 and the reciprocal rb = 1.0f / b: once a is shifted by +0.5 the exact quotient is at
+// least 0.5 / b away from an integer, and the computed product is within 2^-23 * a / b of it -- smaller for a < 2^22
+__device__ __forceinline__ int fdiv(int a, float rb) { return (int)(((float)a + 0.5f) * rb); }
+
 template <int V>
 __global__ __launch_bounds__(256) void pyramid_pool_bwd_kernel(PyramidArgs a, float* __restrict__ dx, int lddx, int N, int H,
                                                               int W, int C) {
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (c >= C) return;
     const int64_t npix = (int64_t)N * H * W;
+    const float rH = 1.0f / (float)H, rW = 1.0f / (float)W;
     HN_PIX_LOOP(npix) {
         const int w = (int)(pix % W);
         const int64_t t = pix / W;
@@ -432,13 +437,15 @@ __global__ __launch_bounds__(256) void pyramid_pool_bwd_kernel(PyramidArgs a, fl
         for (int e = 0; e < V; ++e) acc[e] = 0.f;
         for (int k = 0; k < a.count; ++k) {
             const int Ho = a.h[k], Wo = a.w[k], ld = a.ld[k];
-            const int i_lo = h * Ho / H, i_hi = ((h + 1) * Ho + H - 1) / H - 1;
-            const int j_lo = w * Wo / W, j_hi = ((w + 1) * Wo + W - 1) / W - 1;
+            const float rHo = 1.0f / (float)Ho, rWo = 1.0f / (float)Wo;
+            const int i_lo = fdiv(h * Ho, rH), i_hi = fdiv((h + 1) * Ho + H - 1, rH) - 1;
+            const int j_lo = fdiv(w * Wo, rW), j_hi = fdiv((w + 1) * Wo + W - 1, rW) - 1;
             const float* base = a.p[k] + (int64_t)n * Ho * Wo * ld + c;
             for (int i = i_lo; i <= i_hi; ++i) {
-                const int bh = bin_end(i, H, Ho) - bin_start(i, H, Ho);
+                const int bh = fdiv((i + 1) * H + Ho - 1, rHo) - fdiv(i * H, rHo);  // bin_end - bin_start
                 for (int j = j_lo; j <= j_hi; ++j) {
-                    const float inv = 1.f / (float)(bh * (bin_end(j, W, Wo) - bin_start(j, W, Wo)));
+                    const int bw = fdiv((j + 1) * W + Wo - 1, rWo) - fdiv(j * W, rWo);
+                    const float inv = 1.f / (float)(bh * bw);
                     float g[V];
                     ldv<V>(base + (int64_t)(i * Wo + j) * ld, g);
 #pragma unroll
@@ -569,6 +576,8 @@ extern "C" int hn_pyramid_pool_bwd(int n_levels, const float* const* dys, const 
     if (!dx || n_levels <= 0 || n_levels > 8 || !dys || !hos || !wos || !lds || N <= 0 || H <= 0 || W <= 0 || C <= 0 ||
         lddx < C)
         return HN_EINVAL;
+    for (int k = 0; k < n_levels; ++k)  // bin arithmetic of the kernel (fdiv) is exact below 2^21
+        if ((int64_t)(H + 1) * (hos[k] + 1) >= (1 << 21) || (int64_t)(W + 1) * (wos[k] + 1) >= (1 << 21)) return HN_ESHAPE;
     PyramidArgs a;
     a.count = n_levels;
     bool aligned = true;

@@ -86,6 +86,8 @@ class GradBuckets:
             b["pending"] = len(b["params"])
             b["work"] = None
             for p in b["params"]:
+                if p.grad is None and hasattr(p, "_hn_grad_slot"):
+                    continue  # arena parameter after zero_grad(): backward re-attaches a view of its slot
                 if p.grad is None or p.grad.data_ptr() < b["flat"].data_ptr() or \
                         p.grad.data_ptr() >= b["flat"].data_ptr() + b["flat"].numel() * 4:
                     raise RuntimeError("GradBuckets: a gradient left its bucket (use zero_grad(set_to_none=False))")

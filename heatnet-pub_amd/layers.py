@@ -79,8 +79,9 @@ def conv_bn_act(x, conv, bn, act=ops.ACT_NONE, residual=None, prelu_weight=None,
     then joins this conv's data gradient inside the dgrad kernel instead of in a separate elementwise add."""
     s, p, d = conv.geometry()
     stats = bn.workspace(x.device).stats if bn.training else None  # conv epilogue adds into it, hn_bn_finalize re-zeroes
+    batch_stats = bn.training or bn.running_mean is None
     out = ops.conv2d(x, conv.weight, conv.bias, s, p, d, want_stats=stats if stats is not None else False,
-                     passthrough=passthrough)
+                     passthrough=passthrough, zero_bias_grad=batch_stats and conv.bias is not None)
     y, skip = out if passthrough else (out, None)
     z = bn(y, residual=residual, act=act, stats=stats, prelu_weight=prelu_weight, drop_mask=drop_mask)
     return (z, skip) if passthrough else z

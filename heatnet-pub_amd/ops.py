@@ -225,6 +225,17 @@ def _pick(kind, d, candidates, launch):
     return best
 
 
+_scratch = {}
+
+
+def _tune_scratch(like):
+    """Same-size scratch for candidate timing: those launches must not leave anything in a gradient slot."""
+    buf = _scratch.get((like.device, like.numel()))
+    if buf is None:
+        buf = _scratch[(like.device, like.numel())] = torch.empty(like.numel(), device=like.device, dtype=like.dtype)
+    return buf
+
+
 def _igemm_candidates(cout, kind):
     tiles = [(0, 0), (1, 2), (2, 1)] if cout > 64 else [(0, 0), (1, 1)]
     math = _MATH_CODES[_math(kind)]
@@ -254,6 +265,26 @@ def _side_stream(device):
     if s is None:
         s = _side_streams[device] = torch.cuda.Stream(device=device)
     return s
+
+
+# ---- gradient slots -------------------------------------------------------------------------------------------------
+# optim.ParamArena gives every parameter a fixed slot in a flat gradient buffer that is cleared once per step and marks
+# the parameter with `_hn_grad_slot`.  A backward that is about to produce the FIRST gradient of such a parameter in this
+# step (param.grad is None) writes it straight into the slot and returns a fresh view of it; autograd's AccumulateGrad
+# then adopts that tensor as `.grad` without a copy or an add.  Any further contribution (a layer applied twice) goes the
+# ordinary way: a temporary that autograd adds in place.
+def grad_slot(param):
+    """A new view of `param`'s arena gradient slot, or None (no slot, or the slot already holds this step's gradient)."""
+    slot = getattr(param, "_hn_grad_slot", None)
+    if slot is None or param.grad is not None or getattr(param, "_hn_slot_used", False):
+        return None
+    flat, off = slot
+    param._hn_slot_used = True  # reset by the optimizer's zero_grad()
+    return flat[off:off + param.numel()].as_strided(param.size(), param.stride())
+
+
+def _leaf(t):
+    return t if isinstance(t, torch.nn.Parameter) else None
 
 
 _conv_prof = None  # bench.py: list receiving (kind, algorithmic flops, start event, end event) per conv launch
@@ -295,9 +326,9 @@ class _Conv2d(torch.autograd.Function):
     """y = act(conv(x, w) + b) [+ per-channel batch statistics of the pre-activation output]."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, dil, act, slope, want_stats, passthrough):
+    def forward(ctx, x, w, b, stride, pad, dil, act, slope, want_stats, passthrough, zero_bias_grad=False):
         lib = _lib.load()
-        x_in = x
+        x_in, w_in = x, w
         x, ldx = as_nhwc(x)
         w = weight_ohwi(w)
         n, cin, h, wd = x.shape
@@ -323,6 +354,8 @@ class _Conv2d(torch.autograd.Function):
                                     var, s), "hn_conv2d_fwd")
         ctx.geom = (stride, pad, dil, act, slope)
         ctx.has_bias = b is not None
+        ctx.w_leaf, ctx.b_leaf = _leaf(w_in), _leaf(b)
+        ctx.zero_bias_grad = zero_bias_grad
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.passthrough = passthrough
         if passthrough:
@@ -376,33 +409,49 @@ class _Conv2d(torch.autograd.Function):
         elif dskip is not None:
             dx = dskip
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((cout, kh, kw, cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
+            dw = grad_slot(ctx.w_leaf) if ctx.w_leaf is not None else None
+            flags = 0
+            if dw is not None and weight_ohwi(dw) is dw:
+                flags = 1  # HN_WGRAD_DW_ZEROED: the arena was cleared by zero_grad()
+            else:
+                dw = torch.empty((cout, kh, kw, cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
             split, var = _pick(_kind("wgrad"), d, _wgrad_candidates(cout, cin), lambda sv: check(
-                lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), sv[0], sv[1], s), "hn_conv2d_wgrad"))
+                lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(_tune_scratch(dw) if flags else dw), ctypes.byref(d), sv[0], sv[1], 0, s),
+                "hn_conv2d_wgrad"))
             if OVERLAP and _conv_prof is None and ctx.needs_input_grad[0]:
                 # the dgrad above is already queued on the main stream; wgrad runs beside it on the side stream
                 main, side = torch.cuda.current_stream(), _side_stream(x.device)
                 side.wait_event(fork)
-                check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), split, var,
+                check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), split, var, flags,
                                           ctypes.c_void_p(side.cuda_stream)), "hn_conv2d_wgrad")
                 main.wait_stream(side)
             else:
                 with _ConvTimer("wgrad", d):
-                    check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), split, var, s),
+                    check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), split, var, flags, s),
                           "hn_conv2d_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(cout, device=x.device, dtype=torch.float32)
+            db = grad_slot(ctx.b_leaf) if ctx.b_leaf is not None else None
+            if ctx.zero_bias_grad:
+                # the caller normalises this output with batch statistics: the bias cancels, its gradient is exactly 0
+                db = db if db is not None else torch.zeros(cout, device=x.device, dtype=torch.float32)
+                return dx, dw, db, None, None, None, None, None, None, None, None
+            if db is None:
+                db = torch.empty(cout, device=x.device, dtype=torch.float32)
             check(lib.hn_channel_sum(_ptr(dy), lddy, npix, cout, _ptr(db), s), "hn_channel_sum")
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, pad=0, dil=1, act=ACT_NONE, slope=0.0, want_stats=False, passthrough=False):
+def conv2d(x, w, b=None, stride=1, pad=0, dil=1, act=ACT_NONE, slope=0.0, want_stats=False, passthrough=False,
+           zero_bias_grad=False):
     """`want_stats`: False, True (fresh accumulator) or a zeroed float64 [STAT_REPLICAS*2*Cout] accumulator.
     `passthrough=True` returns (y, x) with x an alias of the input whose gradient is folded into this conv's dgrad
-    (needs a caller-owned accumulator or no statistics)."""
+    (needs a caller-owned accumulator or no statistics).  `zero_bias_grad=True`: the caller feeds y into a BatchNorm that
+    uses batch statistics, where a per-channel bias cancels exactly -- the bias gradient is returned as exact zeros
+    instead of the rounding noise a full reduction pass over dy would produce."""
     if passthrough and want_stats is True:
         raise ValueError("conv2d: passthrough cannot be combined with want_stats=True")
-    return _Conv2d.apply(x, w, b, int(stride), int(pad), int(dil), int(act), float(slope), want_stats, bool(passthrough))
+    return _Conv2d.apply(x, w, b, int(stride), int(pad), int(dil), int(act), float(slope), want_stats, bool(passthrough),
+                         bool(zero_bias_grad))
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -446,6 +495,7 @@ class _BnAct(torch.autograd.Function):
         check(lib.hn_bn_act_fwd(_ptr(y), ldy, _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(z), c, npix, c, act,
                                 _ptr(prelu_w), leaky, _ptr(drop_mask), h * w, s), "hn_bn_act_fwd")
         ctx.drop_mask = drop_mask
+        ctx.leaves = (_leaf(gamma), _leaf(beta), _leaf(prelu_w))
         ctx.cfg = (training, act, leaky, residual is not None)
         ctx.ws = ws
         # the ReLU mask is recomputed from y in backward unless a residual entered u (then z is kept)
@@ -468,9 +518,15 @@ class _BnAct(torch.autograd.Function):
         sums = ws.bwd if ws is not None else torch.zeros(STAT_REPLICAS * (2 * c + 1), device=y.device,
                                                          dtype=torch.float64)
         dpar = torch.empty(2 * c + 1, device=y.device, dtype=torch.float32)   # dbeta | dgamma | dslope
+        # first gradient of a parameter in this step: written straight into its arena slot (see grad_slot)
+        lg, lb, lp = ctx.leaves
+        sg = grad_slot(lg) if (lg is not None and ctx.needs_input_grad[2]) else None
+        sb = grad_slot(lb) if (lb is not None and ctx.needs_input_grad[3]) else None
+        sp = grad_slot(lp) if (lp is not None and prelu_w is not None and ctx.needs_input_grad[7]) else None
         check(lib.hn_bn_act_bwd_reduce(_ptr(dz), lddz, _ptr(z), ldz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(scale),
                                        _ptr(shift), npix, c, act, _ptr(prelu_w), leaky, _ptr(sums), _ptr(dpar),
-                                       _ptr(ctx.drop_mask), h * w, s), "hn_bn_act_bwd_reduce")
+                                       _ptr(sg), _ptr(sb), _ptr(sp), _ptr(ctx.drop_mask), h * w, s),
+              "hn_bn_act_bwd_reduce")
         dy = new_nhwc(n, c, h, w, y.device) if ctx.needs_input_grad[0] else None
         dres = new_nhwc(n, c, h, w, y.device) if (has_res and ctx.needs_input_grad[6]) else None
         if dy is not None or dres is not None:
@@ -480,9 +536,10 @@ class _BnAct(torch.autograd.Function):
                                           _ptr(gamma), _ptr(scale), _ptr(shift), _ptr(dpar), npix, int(training),
                                           _ptr(dy), c, _ptr(dres), c, npix, c, act, _ptr(prelu_w), leaky,
                                           _ptr(ctx.drop_mask), h * w, s), "hn_bn_act_bwd_apply")
-        dgamma = dpar[c:2 * c] if ctx.needs_input_grad[2] else None
-        dbeta = dpar[0:c] if ctx.needs_input_grad[3] else None
-        dprelu = dpar[2 * c:2 * c + 1] if (prelu_w is not None and ctx.needs_input_grad[7]) else None
+        dgamma = (sg if sg is not None else dpar[c:2 * c]) if ctx.needs_input_grad[2] else None
+        dbeta = (sb if sb is not None else dpar[0:c]) if ctx.needs_input_grad[3] else None
+        dprelu = (sp if sp is not None else dpar[2 * c:2 * c + 1]) if (prelu_w is not None and ctx.needs_input_grad[7]) \
+            else None
         return dy, None, dgamma, dbeta, None, None, dres, dprelu, None, None, None, None, None, None, None
 
 

@@ -48,17 +48,50 @@ class ParamArena:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.grad[off:off + n].as_strided(p.size(), p.stride())
+                # ops.grad_slot(): after a zero_grad() the backward kernels write the parameter's first gradient of the
+                # step straight into this slot (no temporary, no accumulation add)
+                p._hn_grad_slot = (self.grad, off)
+                p._hn_slot_used = False
+                # gradients produced by anything else (a sliced weight's SliceBackward, stock torch ops) are adopted by
+                # autograd as free-standing tensors: move them into the slot as soon as they are accumulated (this hook
+                # is registered before any ddp.GradBuckets hook, so buckets only ever see slot-resident gradients)
+                p.register_post_accumulate_grad_hook(self._adopt)
 
     def active(self):
         """True when this arena's parameters take part in the current phase."""
         return self.params[0].requires_grad
 
-    def check(self):
-        base, end = self.grad.data_ptr(), self.grad.data_ptr() + 4 * self.numel
+    def grad_view(self, p):
+        """A view of `p`'s gradient slot (what `p.grad` is while the parameter holds a gradient)."""
+        flat, off = p._hn_grad_slot
+        return flat[off:off + p.numel()].as_strided(p.size(), p.stride())
+
+    def _adopt(self, p):
+        g = p.grad
+        flat, off = p._hn_grad_slot
+        if g is None or g.data_ptr() == flat.data_ptr() + 4 * off:
+            return
+        view = flat[off:off + p.numel()].as_strided(p.size(), p.stride())
+        view.copy_(g)
+        p.grad = view
+        p._hn_slot_used = True
+
+    def zero_grad(self):
+        """One memset; parameters drop their `.grad` (the next backward re-attaches views of the slots, see
+        ops.grad_slot) -- a parameter that receives no gradient in a step therefore reads as zero gradient."""
+        self.grad.zero_()
         for p in self.params:
+            p.grad = None
+            p._hn_slot_used = False
+
+    def check(self):
+        """Every gradient that exists must live in its arena slot."""
+        base = self.grad.data_ptr()
+        for p, off in zip(self.params, self.offsets):
             g = p.grad
-            if g is None or not (base <= g.data_ptr() < end):
-                raise RuntimeError("ParamArena: a gradient left the arena (zero_grad(set_to_none=True) was used?)")
+            if g is not None and g.data_ptr() != base + 4 * off:
+                raise RuntimeError("ParamArena: a gradient left the arena (a foreign zero_grad(set_to_none=True), or a "
+                                   "gradient tensor autograd could not adopt in place)")
 
 
 class _FlatOptimizer(torch.optim.Optimizer):
@@ -72,10 +105,11 @@ class _FlatOptimizer(torch.optim.Optimizer):
         super().__init__(groups, defaults)  # param_groups[i] <-> arenas[i]
 
     def zero_grad(self, set_to_none=False):
-        """Always in place (one memset per arena); `set_to_none` is accepted for API compatibility and ignored."""
+        """One memset per arena; `set_to_none` is accepted for API compatibility and ignored (gradients are detached
+        from the parameters either way and re-attached, in place, by the next backward)."""
         for a in self.arenas:
             if a.active():
-                a.grad.zero_()
+                a.zero_grad()
 
 
 class FlatRMSprop(_FlatOptimizer):
@@ -90,6 +124,7 @@ class FlatRMSprop(_FlatOptimizer):
         for g, a, sq in zip(self.param_groups, self.arenas, self.square_avg):
             if not a.active():
                 continue
+            a.check()
             ops.rmsprop_step_(a.flat, a.grad, sq, g["lr"], g["alpha"], g["eps"], g["weight_decay"])
 
 
@@ -107,6 +142,7 @@ class FlatAdam(_FlatOptimizer):
         for i, (g, a) in enumerate(zip(self.param_groups, self.arenas)):
             if not a.active():
                 continue
+            a.check()
             self.steps[i] += 1
             ops.adam_step_(a.flat, a.grad, self.exp_avg[i], self.exp_avg_sq[i], self.steps[i], g["lr"], g["betas"][0],
                            g["betas"][1], g["eps"], g["weight_decay"])

@@ -218,6 +218,7 @@ def test_flat_arena_rmsprop_matches_torch(dev):
             g = torch.Generator().manual_seed(step)
             for pa, pb in zip(a.parameters(), b.parameters()):
                 grad = torch.randn(pa.shape, generator=g).to(dev)
+                pa.grad = arena.grad_view(pa)  # zero_grad() detached it; a backward would re-attach it the same way
                 pa.grad.copy_(grad)
                 pb.grad = grad.clone()
             arena.check()
@@ -228,6 +229,49 @@ def test_flat_arena_rmsprop_matches_torch(dev):
         for p in a.parameters():  # detach from the arena before the next optimizer re-homes them
             p.data = p.data.clone()
             p.grad = None
+
+
+def test_gradient_slots_match_plain_autograd(dev):
+    """optim.ParamArena gradient slots: after zero_grad() the conv / BN backward kernels write a parameter's first
+    gradient straight into its arena slot (no temporary, no accumulation add).  Same gradients as without an arena,
+    every `.grad` resident in its slot, also for a layer applied twice and for a weight used through a slice."""
+    import copy
+    import torch.nn as nn
+    from heatnet_amd import ops, optim
+    from heatnet_amd.layers import HnBatchNorm2d, HnConv2d, conv_bn_act
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1, self.b1 = HnConv2d(32, 64, 3, padding=1, bias=True), HnBatchNorm2d(64)
+            self.c2, self.b2 = HnConv2d(64, 64, 1, bias=False), HnBatchNorm2d(64)
+            self.wide = HnConv2d(128, 32, 1, bias=True)     # used through two column slices of its weight
+
+        def forward(self, x):
+            z = conv_bn_act(x, self.c1, self.b1, ops.ACT_RELU)
+            z = conv_bn_act(z, self.c2, self.b2, ops.ACT_RELU)
+            z = conv_bn_act(z, self.c2, self.b2, ops.ACT_RELU)  # same layer twice: second gradient is accumulated
+            w = self.wide.weight
+            return ops.conv2d(z, w[:, :64], self.wide.bias) + ops.conv2d(z, w[:, 64:])
+
+    torch.manual_seed(3)
+    plain = Net().to(dev).train()
+    slotted = copy.deepcopy(plain)
+    x = torch.randn(2, 32, 12, 16, device=dev).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(2, 32, 12, 16, device=dev).contiguous(memory_format=torch.channels_last)
+    plain(x).backward(g)
+    arena = optim.ParamArena(list(slotted.parameters()))
+    opt = optim.FlatRMSprop([arena], lr=1e-4)
+    for _ in range(2):  # second round: slots are re-attached after a zero_grad()
+        opt.zero_grad()
+        assert all(p.grad is None for p in slotted.parameters())
+        slotted(x).backward(g)
+        arena.check()
+        for (k, a), b in zip(slotted.named_parameters(), plain.parameters()):
+            assert a.grad is not None and a.grad.data_ptr() == arena.grad_view(a).data_ptr(), k
+            scale = float(b.grad.abs().max()) + 1e-12
+            assert float((a.grad - b.grad).abs().max()) <= 2e-5 * scale + 1e-7, k
+    opt.step()  # runs ParamArena.check() on the way
 
 
 def test_validation_convention_matches_oracle(dev):
