@@ -257,8 +257,15 @@ def main():
     from heatnet_amd import ops
     scale = (args.height * args.width * args.batch) / float(H * W * BS)
     roof = None
-    if rank == 0 and not args.no_roofline:
-        roof = measure_conv_roofline(step, max(1, min(3, args.steps)), args.workload, scale=scale)
+    if not args.no_roofline:
+        # every rank runs the instrumented steps (a step contains the gradient all-reduce); only rank 0 records events
+        nprof = max(1, min(3, args.steps))
+        if rank == 0:
+            roof = measure_conv_roofline(step, nprof, args.workload, scale=scale)
+        else:
+            for _ in range(nprof):
+                step()
+            torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     alt = None
