@@ -5,6 +5,8 @@
 // (coalesced), threadIdx.y walks pixels; a block is bx x by = 256 threads with bx = the smallest power
 // of two covering the channel pieces (<= 64), so narrow tensors (C = 64) still fill their waves.
 // Column reductions finish through LDS across threadIdx.y and one global_atomic_add_f32 per channel.
+#include <cstdlib>
+
 #include "hn_common.h"
 
 namespace {
@@ -105,7 +107,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 }
 
 // sums[0:C] += sum du ; sums[C:2C] += sum du*xhat ; sums[2C] += dslope   (double accumulation throughout)
-template <int V>
+// ZMASK / MASK are compile-time so that the pixel loop is straight-line code the compiler can unroll and pipeline
+// (loads of the next pixels issued before the arithmetic of the current ones)
+template <int V, bool ZMASK, bool MASK>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ dz, int lddz,
                                                                const float* __restrict__ z, int ldz,
                                                                const float* __restrict__ y, int ldy,
@@ -129,27 +133,34 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
         ldv<V>(invstd + c, is);
     }
     const float slope = act == HN_ACT_PRELU ? *slope_p : leaky;
-    const bool zmask = act == HN_ACT_RELU && z != nullptr;
     if (live) {
-#pragma unroll 2
-        for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix;
-             pix += (int64_t)gridDim.y * blockDim.y) {
+        const int64_t first = (int64_t)blockIdx.y * blockDim.y + threadIdx.y, step = (int64_t)gridDim.y * blockDim.y;
+        const float* pg = dz + first * lddz + c;
+        const float* py = y + first * ldy + c;
+        const float* pz = ZMASK ? z + first * ldz + c : nullptr;
+        const int64_t sg = step * lddz, sy = step * ldy, sz = step * ldz;
+#pragma unroll 4
+        for (int64_t pix = first; pix < npix; pix += step) {
             float g[V], zz[V], yy[V], du[V];
             float ds = 0.f;
-            ldv<V>(dz + pix * lddz + c, g);
-            ldv<V>(y + pix * ldy + c, yy);
-            if (mask != nullptr) {
+            ldv<V>(pg, g);
+            ldv<V>(py, yy);
+            if constexpr (ZMASK) {
+                ldv<V>(pz, zz);
+                pz += sz;
+            } else {
+#pragma unroll
+                for (int i = 0; i < V; ++i) zz[i] = 0.f;
+            }
+            pg += sg;
+            py += sy;
+            if constexpr (MASK) {
                 float m[V];
                 ldv<V>(mask + (pix / hw) * C + c, m);
 #pragma unroll
                 for (int i = 0; i < V; ++i) g[i] *= m[i];
             }
-            if (zmask) ldv<V>(z + pix * ldz + c, zz);
-            else {
-#pragma unroll
-                for (int i = 0; i < V; ++i) zz[i] = 0.f;
-            }
-            act_grad<V>(g, zz, yy, sc, sh, act, slope, zmask, du, ds);
+            act_grad<V>(g, zz, yy, sc, sh, act, slope, ZMASK, du, ds);
             dslope += (double)ds;
 #pragma unroll
             for (int i = 0; i < V; ++i) {
@@ -493,10 +504,35 @@ extern "C" int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, i
     if (bad_rows(npix, C, {lddz, ldy}) || (z && ldz < C)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool zmask = act == HN_ACT_RELU && z != nullptr;
-    const RowLaunch pl = plan_rows(npix, C, {dz, y, zmask ? z : nullptr, mean, invstd, scale, shift},
-                                   {lddz, ldy, zmask ? ldz : 4}, 2048);
-    HN_LAUNCH_V(pl, bn_act_bwd_reduce_kernel, dz, lddz, z, ldz, y, ldy, mean, invstd, scale, shift, npix, C, act, slope,
-                leaky_slope, sums, mask, hw);
+    RowLaunch pl = plan_rows(npix, C, {dz, y, zmask ? z : nullptr, mean, invstd, scale, shift},
+                             {lddz, ldy, zmask ? ldz : 4}, 2048);
+    {
+        // every block ends with 2C double atomics: give each thread at least MINPIX pixels so that small tensors are not
+        // dominated by them (a [8x40x88, 256] tensor went from 2048 blocks / 1 M atomics to 440 / 225 k)
+        // (measured inside the training step, rocprofv3: tensors under ~48 MB 36.7 -> 27.0 us at 8 pixels per thread,
+        // the large residual-block tensors 75.2 -> 61.6 us at 32)
+        static const int minpix_env = getenv("HN_BN_MINPIX") ? atoi(getenv("HN_BN_MINPIX")) : 0;
+        const int minpix = minpix_env > 0 ? minpix_env : ((int64_t)npix * C * 4 >= (48ll << 20) ? 32 : 8);
+        const int64_t gy_cap = (npix + (int64_t)pl.block.y * minpix - 1) / ((int64_t)pl.block.y * minpix);
+        if ((int64_t)pl.grid.y > gy_cap) pl.grid.y = (unsigned)(gy_cap < 1 ? 1 : gy_cap);
+    }
+#define HN_LAUNCH_REDUCE(ZM, MK)                                                                                       \
+    do {                                                                                                                \
+        if (pl.V == 4)                                                                                                  \
+            HN_LAUNCH((bn_act_bwd_reduce_kernel<4, ZM, MK>), pl.grid, pl.block, 0, s, dz, lddz, z, ldz, y, ldy, mean, invstd, \
+                      scale, shift, npix, C, act, slope, leaky_slope, sums, mask, hw);                                  \
+        else                                                                                                            \
+            HN_LAUNCH((bn_act_bwd_reduce_kernel<1, ZM, MK>), pl.grid, pl.block, 0, s, dz, lddz, z, ldz, y, ldy, mean, invstd, \
+                      scale, shift, npix, C, act, slope, leaky_slope, sums, mask, hw);                                  \
+    } while (0)
+    if (zmask) {
+        if (mask != nullptr) HN_LAUNCH_REDUCE(true, true);
+        else HN_LAUNCH_REDUCE(true, false);
+    } else {
+        if (mask != nullptr) HN_LAUNCH_REDUCE(false, true);
+        else HN_LAUNCH_REDUCE(false, false);
+    }
+#undef HN_LAUNCH_REDUCE
     HN_CHECK_LAUNCH();
     HN_LAUNCH(f64_to_f32_reset_kernel, dim3((2 * C + 1 + 255) / 256), dim3(256), 0, s, sums, dparams, 2 * C + 1, C, dgamma_out,
               dbeta_out, dslope_out);
