@@ -55,7 +55,12 @@ class ParamArena:
                 # gradients produced by anything else (a sliced weight's SliceBackward, stock torch ops) are adopted by
                 # autograd as free-standing tensors: move them into the slot as soon as they are accumulated (this hook
                 # is registered before any ddp.GradBuckets hook, so buckets only ever see slot-resident gradients)
+                frozen = not p.requires_grad  # a phase switch (conv_segnet.setPhase) may enable it later
+                if frozen:
+                    p.requires_grad_(True)
                 p.register_post_accumulate_grad_hook(self._adopt)
+                if frozen:
+                    p.requires_grad_(False)
 
     def active(self):
         """True when this arena's parameters take part in the current phase."""

@@ -154,11 +154,14 @@ def test_rgb18_config1(dev, golden_dir):
     np.testing.assert_allclose(net.final[0].weight.grad.cpu().numpy(), g["grad_final_w"], rtol=2e-3, atol=2e-5)
 
 
-@pytest.mark.parametrize("conv_math", ["f32", "bf16x3"], indirect=True)
+@pytest.mark.parametrize("conv_math,optimizer", [("f32", "torch"), ("bf16x3", "torch"), ("bf16x3", "arena")],
+                         indirect=["conv_math"])
 @pytest.mark.parametrize("adv", ["MSE", "BCE"])
-def test_confusion_maximisation_steps(dev, golden_dir, adv, conv_math):
-    """conv_segnet forward, one train_critic and one train_seg iteration (RMSprop) vs. the reference fixture."""
-    from heatnet_amd import conf_segnet, train_step
+def test_confusion_maximisation_steps(dev, golden_dir, adv, conv_math, optimizer):
+    """conv_segnet forward, one train_critic and one train_seg iteration (RMSprop) vs. the reference fixture.
+    `optimizer="arena"`: the flat per-phase parameter arenas + fused RMSprop + gradient slots of optim.py (what bench.py
+    runs) instead of torch.optim.RMSprop."""
+    from heatnet_amd import conf_segnet, optim, train_step
     g = _load(golden_dir, "confstep_%s_2x256x256" % adv.lower())
     model = conf_segnet.conv_segnet(pretrained=False, disc_arch="cyclegan", num_critics=6, arch="pspnet",
                                     late_fusion=True)
@@ -166,7 +169,10 @@ def test_confusion_maximisation_steps(dev, golden_dir, adv, conv_math):
     model.load_state_dict(state)
     set_dropout(model, 0.0)
     model = model.to(dev).train()
-    opt = torch.optim.RMSprop(model.parameters(), lr=1e-4)
+    if optimizer == "arena":
+        opt = optim.FlatRMSprop(optim.arenas_for(model), lr=1e-4)
+    else:
+        opt = torch.optim.RMSprop(model.parameters(), lr=1e-4)
     rgb_d, ir_d, lab = [t.to(dev) for t in seeded_inputs(2, 256, 256, seed=11)]
     rgb_n, ir_n, _ = [t.to(dev) for t in seeded_inputs(2, 256, 256, seed=12)]
     for step, state_name in enumerate(("train_critic", "train_seg")):
@@ -193,7 +199,8 @@ def test_confusion_maximisation_steps(dev, golden_dir, adv, conv_math):
             assert abs(losses["conf"].item() - float(g["s1_conf"])) < tol * max(1.0, abs(float(g["s1_conf"])))
         names = [str(n) for n in g["s%d_grad_names" % step]]
         norms = dict(zip(names, g["s%d_grad_norms" % step]))
-        got = {k: float(p.grad.double().norm()) for k, p in model.named_parameters() if p.grad is not None}
+        got = {k: float(p.grad.double().norm()) for k, p in model.named_parameters()
+               if p.grad is not None and p.requires_grad}
         assert sorted(got) == sorted(names)
         floor = 1e-4 * max(norms.values())  # conv biases in front of a BatchNorm have a zero true gradient
         worst = max((abs(got[k] - norms[k]) / max(norms[k], floor), k) for k in names)
