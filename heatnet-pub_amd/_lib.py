@@ -25,7 +25,7 @@ DP = ctypes.POINTER(HnConvDesc)
 # name -> argtypes, exactly the prototypes of include/heatnet_hip.h
 SIGNATURES = {
     "hn_conv2d_fwd": [P, P, P, P, P, P, DP, c_int, c_float, c_int, P],
-    "hn_weight_flip_transpose": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "hn_weight_flip_transpose": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_conv2d_dgrad": [P, P, P, P, P, c_int, DP, c_int, P],
     "hn_conv2d_wgrad": [P, P, P, DP, c_int, c_int, c_int, P],
     "hn_channel_sum": [P, c_int, c_i64, c_int, P, P],

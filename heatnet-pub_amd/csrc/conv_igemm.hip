@@ -805,8 +805,10 @@ __device__ __forceinline__ void split3_scalar(float v, unsigned short& h, unsign
 }
 
 // one 32x32 (co, ci) tile of one tap per block, transposed through LDS; `wt` (fp32) and `wx3` (three bf16 planes of
-// `plane` elements each, same element order) are both optional
-__global__ __launch_bounds__(256) void weight_taps_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt,
+// `plane` elements each, same element order) are both optional; `w_x3` (optional) receives the bf16 planes of the
+// UNtransposed matrix -- every source element passes through exactly one block, so the forward operand comes for free
+__global__ __launch_bounds__(256) void weight_taps_transpose_kernel(const float* __restrict__ w,
+                                                                   unsigned short* __restrict__ w_x3, float* __restrict__ wt,
                                                                    unsigned short* __restrict__ wx3, long long plane,
                                                                    int Cout, int T, int Cin, TapTable t) {
     __shared__ float tile[32][33];
@@ -815,7 +817,13 @@ __global__ __launch_bounds__(256) void weight_taps_transpose_kernel(const float*
     const int src = t.src[z];
     for (int r = ty; r < 32; r += 8) {
         const int co = co0 + r, ci = ci0 + tx;
-        tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * T + src) * Cin + ci] : 0.f;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+            const size_t o = ((size_t)co * T + src) * Cin + ci;
+            v = w[o];
+            if (w_x3 != nullptr) split3_scalar(v, w_x3[o], w_x3[plane + o], w_x3[2 * plane + o]);
+        }
+        tile[r][tx] = v;
     }
     __syncthreads();
     const int rowstride = t.row[z];
@@ -974,8 +982,8 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, const void* wt_
     return HN_OK;
 }
 
-extern "C" int hn_weight_flip_transpose(const float* w, float* wt, void* wt_x3, int Cout, int KH, int KW, int Cin, int stride,
-                                        int pad, int dil, void* stream) {
+extern "C" int hn_weight_flip_transpose(const float* w, void* w_x3, float* wt, void* wt_x3, int Cout, int KH, int KW, int Cin,
+                                        int stride, int pad, int dil, void* stream) {
     if (w == nullptr || (wt == nullptr && wt_x3 == nullptr) || Cout <= 0 || KH <= 0 || KW <= 0 || Cin <= 0 || stride <= 0 ||
         pad < 0 || dil <= 0)
         return HN_EINVAL;
@@ -983,8 +991,9 @@ extern "C" int hn_weight_flip_transpose(const float* w, float* wt, void* wt_x3, 
     TapTable t;
     build_tap_table(t, Cout, KH, KW, Cin, stride, pad, dil);
     const dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, KH * KW);
-    HN_LAUNCH(weight_taps_transpose_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, wt,
-              static_cast<unsigned short*>(wt_x3), hn_x3_plane((long long)Cout * KH * KW * Cin), Cout, KH * KW, Cin, t);
+    HN_LAUNCH(weight_taps_transpose_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w,
+              static_cast<unsigned short*>(w_x3), wt, static_cast<unsigned short*>(wt_x3),
+              hn_x3_plane((long long)Cout * KH * KW * Cin), Cout, KH * KW, Cin, t);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

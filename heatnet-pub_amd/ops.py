@@ -345,7 +345,18 @@ class _Conv2d(torch.autograd.Function):
             stats = None
         d = _desc(n, h, wd, cin, ldx, ho, wo, cout, cout, kh, kw, stride, pad, dil)
         s = _stream()
-        wx3 = split_weight(w)
+        ctx.wt = ctx.wtx3 = None
+        if _math("fwd") == "bf16x3" and _math("dgrad") == "bf16x3" and ctx.needs_input_grad[0]:
+            # a data gradient will follow: ONE launch prepares the forward operand (bf16 planes of w) and the dgrad
+            # operands (flipped / transposed weights, fp32 and bf16 planes), instead of a split now and a transpose later
+            nw = w.numel()
+            wx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16)
+            ctx.wt = torch.empty(nw, device=x.device, dtype=torch.float32)
+            ctx.wtx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16)
+            check(lib.hn_weight_flip_transpose(_ptr(w), _ptr(wx3), _ptr(ctx.wt), _ptr(ctx.wtx3), cout, kh, kw, cin, stride,
+                                               pad, dil, s), "hn_weight_flip_transpose")
+        else:
+            wx3 = split_weight(w)
         var = _pick(_kind("fwd"), d, _igemm_candidates(cout, "fwd"), lambda v: check(
             lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), None, ctypes.byref(d), act, slope, v, s),
             "hn_conv2d_fwd"))
@@ -393,10 +404,13 @@ class _Conv2d(torch.autograd.Function):
             fork.record()  # dy (and the activation backward that produced it) is complete up to here
         if ctx.needs_input_grad[0]:
             nw = cin * kh * kw * cout
-            wt = torch.empty(nw, device=x.device, dtype=torch.float32)
-            wtx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16) if _math("dgrad") == "bf16x3" else None
-            check(lib.hn_weight_flip_transpose(_ptr(w), _ptr(wt), _ptr(wtx3), cout, kh, kw, cin, stride, pad, dil, s),
-                  "hn_weight_flip_transpose")
+            wt, wtx3 = ctx.wt, ctx.wtx3  # prepared by the forward (bf16x3), else made here
+            if wt is None:
+                wt = torch.empty(nw, device=x.device, dtype=torch.float32)
+                wtx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16) \
+                    if _math("dgrad") == "bf16x3" else None
+                check(lib.hn_weight_flip_transpose(_ptr(w), None, _ptr(wt), _ptr(wtx3), cout, kh, kw, cin, stride, pad, dil,
+                                                   s), "hn_weight_flip_transpose")
             dx = new_nhwc(n, cin, h, wd, x.device)
             dd = _desc(n, h, wd, cin, cin, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
             var = _pick(_kind("dgrad"), dd, _igemm_candidates(cin, "dgrad"), lambda v: check(

@@ -96,9 +96,11 @@ int hn_split_bf16x3(const float* src, void* dst, int64_t n, void* stream);
  * Stride 1: wt[Cin][KH][KW][Cout] = w[Cout][KH-1-kh][KW-1-kw][Cin].  Stride 2 with odd dilation: four consecutive blocks,
  * one per parity class (ph, pw) of the input pixels, each [Cin][Th*Tw][Cout] with only the taps that reach the class --
  * the data gradient then runs as four small stride-1 convolutions with no arithmetic on inserted zeros.
- * `wt` (fp32) and `wt_x3` (the bf16x3 planes of the same matrix, see above) are each optional, not both NULL. */
-int hn_weight_flip_transpose(const float* w, float* wt, void* wt_x3, int Cout, int KH, int KW, int Cin, int stride, int pad,
-                             int dil, void* stream);
+ * `wt` (fp32) and `wt_x3` (the bf16x3 planes of the same matrix, see above) are each optional, not both NULL.
+ * `w_x3` (optional): additionally receives the bf16x3 planes of `w` itself (what hn_split_bf16x3 would produce), so one
+ * launch at forward time prepares the weight operands of both the forward and the data-gradient kernels. */
+int hn_weight_flip_transpose(const float* w, void* w_x3, float* wt, void* wt_x3, int Cout, int KH, int KW, int Cin, int stride,
+                             int pad, int dil, void* stream);
 
 /* dx = conv_transpose(dy, w) [+ addend] for the forward geometry `d` (dy is N x Hout x Wout x Cout with pixel stride
  * d->ldy, dx is N x Hin x Win x Cin with pixel stride d->ldx); `wt` from hn_weight_flip_transpose.  `addend`

@@ -64,7 +64,7 @@ def main():
         d = _lib.HnConvDesc(n, h, w, cin, cin, ho, wo, cout, cout, k, k, stride, pad, dil)
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = lambda t: ctypes.c_void_p(t.data_ptr())
-        _lib.check(lib.hn_weight_flip_transpose(P(wt), P(wflip), P(wflipx3), cout, k, k, cin, stride, pad, dil, s), "flip")
+        _lib.check(lib.hn_weight_flip_transpose(P(wt), None, P(wflip), P(wflipx3), cout, k, k, cin, stride, pad, dil, s), "flip")
         _lib.check(lib.hn_split_bf16x3(P(wt), P(wx3), nw, s), "split")
         flops = 2.0 * n * ho * wo * cout * k * k * cin
         res = {}
