@@ -73,7 +73,7 @@ def main():
         if "dgrad" in kinds:
             res["dgrad"] = timeit(lambda: _lib.check(lib.hn_conv2d_dgrad(P(dy), P(wflip), P(wflipx3), P(dx), None, 0, ctypes.byref(d), VAR, s), "dgrad"))
         if "wgrad" in kinds:
-            res["wgrad"] = timeit(lambda: _lib.check(lib.hn_conv2d_wgrad(P(x), P(dy), P(dw), ctypes.byref(d), SPLIT, VAR, s), "wgrad"))
+            res["wgrad"] = timeit(lambda: _lib.check(lib.hn_conv2d_wgrad(P(x), P(dy), P(dw), ctypes.byref(d), SPLIT, VAR, 0, s), "wgrad"))
         cols = ["%10.1f" % (flops / res[k2] / 1e9) if k2 in res else "%10s" % "-" for k2 in ("fwd", "dgrad", "wgrad")]
         print("%-34s %8.1f %s" % (sh, flops / 1e9, " ".join(cols)))
 
