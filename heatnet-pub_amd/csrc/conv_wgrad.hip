@@ -42,6 +42,7 @@ struct WgradArgs {
     int chunks_per_split;
     int atomic;
     int dw_zeroed;  // the caller guarantees dW is all zero on entry: accumulate without a fill
+    int accumulate; // dW += (always through atomics, never filled)
     long long x_bytes, dy_bytes;
 };
 
@@ -704,8 +705,8 @@ int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     if (split_k > total_chunks) split_k = total_chunks;
     a.chunks_per_split = (total_chunks + split_k - 1) / split_k;
     split_k = (total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
-    a.atomic = split_k > 1;
-    if (a.atomic && !a.dw_zeroed) {
+    a.atomic = split_k > 1 || a.accumulate;
+    if (a.atomic && !a.dw_zeroed && !a.accumulate) {
         if (hipMemsetAsync(a.dw, 0, (size_t)a.K * a.Kdim * sizeof(float), stream) != hipSuccess) return HN_ELAUNCH;
     }
     if constexpr (X3) HN_LAUNCH((conv_wgrad_x3_kernel<TM, TN>), dim3(tiles * split_k), dim3(256), lds, stream, a);
@@ -742,6 +743,7 @@ extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const
     a.Kdim = d->KH * d->KW * d->Cin;
     a.ntm = a.ntn = a.chunks_per_split = a.atomic = 0;
     a.dw_zeroed = (flags & HN_WGRAD_DW_ZEROED) != 0;
+    a.accumulate = (flags & HN_WGRAD_ACCUMULATE) != 0;
     a.x_bytes = (((long long)d->N * d->Hin * d->Win - 1) * d->ldx + d->Cin) * 4;
     a.dy_bytes = (((long long)a.M - 1) * d->ldy + d->Cout) * 4;
     hipStream_t s = static_cast<hipStream_t>(stream);

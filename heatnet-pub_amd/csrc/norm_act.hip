@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
 // (bn backward: n = 2C+1 = dbeta | dgamma | dslope; the three optional pointers receive the same values where the
 // caller wants them -- the parameters' gradient slots -- so that no copy / accumulation kernel follows)
 __global__ void f64_to_f32_reset_kernel(double* __restrict__ in, float* __restrict__ out, int n, int C,
-                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dslope) {
+                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dslope,
+                                        int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         double a = 0.0;
@@ -219,13 +220,9 @@ __global__ void f64_to_f32_reset_kernel(double* __restrict__ in, float* __restri
         }
         const float v = (float)a;
         out[i] = v;
-        if (i < C) {
-            if (dbeta != nullptr) dbeta[i] = v;
-        } else if (i < 2 * C) {
-            if (dgamma != nullptr) dgamma[i - C] = v;
-        } else if (dslope != nullptr) {
-            dslope[0] = v;
-        }
+        float* dst = i < C ? (dbeta != nullptr ? dbeta + i : nullptr)
+                           : (i < 2 * C ? (dgamma != nullptr ? dgamma + (i - C) : nullptr) : dslope);
+        if (dst != nullptr) *dst = accumulate ? *dst + v : v;
     }
 }
 
@@ -497,7 +494,7 @@ extern "C" int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, i
                                     const float* mean, const float* invstd, const float* scale, const float* shift,
                                     int64_t npix, int C, int act, const float* slope, float leaky_slope, double* sums,
                                     float* dparams, float* dgamma_out, float* dbeta_out, float* dslope_out,
-                                    const float* mask, int64_t hw, void* stream) {
+                                    int out_accumulate, const float* mask, int64_t hw, void* stream) {
     if (!dz || !y || !mean || !invstd || !scale || !shift || !sums || !dparams || act < 0 || act > 3) return HN_EINVAL;
     if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
     if (act == HN_ACT_PRELU && !slope) return HN_EINVAL;
@@ -535,7 +532,7 @@ extern "C" int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, i
 #undef HN_LAUNCH_REDUCE
     HN_CHECK_LAUNCH();
     HN_LAUNCH(f64_to_f32_reset_kernel, dim3((2 * C + 1 + 255) / 256), dim3(256), 0, s, sums, dparams, 2 * C + 1, C, dgamma_out,
-              dbeta_out, dslope_out);
+              dbeta_out, dslope_out, out_accumulate);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

@@ -151,3 +151,5 @@ def broadcast_module_state(module, src=0, process_group=None):
                 tmp = t.contiguous()
                 dist.broadcast(tmp, src, group=process_group)
                 t.copy_(tmp)
+    from . import ops
+    ops.weights_changed()  # the collective wrote the parameters behind their version counters

@@ -177,6 +177,18 @@ def _variant(bk=0, tm=0, tn=0, math=0):
     return bk + 4 * tm + 16 * tn + 64 * math
 
 
+_weights_epoch = 0
+
+
+def weights_changed():
+    """Invalidate the cached bf16x3 weight operands.  Called by the flat optimizers after their update (it goes through
+    the arena, not through the parameters' version counters) and by anything else that writes parameters through
+    `.data` (ddp.broadcast_module_state); in-place updates through the Parameter itself (torch.optim, load_state_dict)
+    are seen through `Tensor._version`."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
 def x3_plane(n):
     """HN_X3_PLANE: elements per bf16 plane of a pre-split matrix of n elements."""
     return (n + 7) & ~7
@@ -269,18 +281,25 @@ def _side_stream(device):
 
 # ---- gradient slots -------------------------------------------------------------------------------------------------
 # optim.ParamArena gives every parameter a fixed slot in a flat gradient buffer that is cleared once per step and marks
-# the parameter with `_hn_grad_slot`.  A backward that is about to produce the FIRST gradient of such a parameter in this
-# step (param.grad is None) writes it straight into the slot and returns a fresh view of it; autograd's AccumulateGrad
-# then adopts that tensor as `.grad` without a copy or an add.  Any further contribution (a layer applied twice) goes the
-# ordinary way: a temporary that autograd adds in place.
-def grad_slot(param):
-    """A new view of `param`'s arena gradient slot, or None (no slot, or the slot already holds this step's gradient)."""
+# the parameter with `_hn_grad_slot`.  The backward that produces the FIRST gradient of such a parameter in a step
+# (param.grad is None) writes it straight into the slot and returns a fresh view of it; autograd's AccumulateGrad then
+# adopts that tensor as `.grad` without a copy or an add.  A further contribution in the same step (a layer applied
+# twice: day and night passes) is ADDED into the slot by the kernel itself and reported to autograd as "no gradient"
+# (None): the leaf's AccumulateGrad -- and any hook on it -- still runs once, after all of its uses.
+def grad_slot(param, accumulate_ok=True):
+    """(view, first) for `param`'s arena gradient slot -- `first`: the slot is empty (zero) and the caller's result
+    becomes the gradient; not first: the caller must add into it -- or None when there is no slot to use."""
     slot = getattr(param, "_hn_grad_slot", None)
-    if slot is None or param.grad is not None or getattr(param, "_hn_slot_used", False):
+    if slot is None:
         return None
     flat, off = slot
-    param._hn_slot_used = True  # reset by the optimizer's zero_grad()
-    return flat[off:off + param.numel()].as_strided(param.size(), param.stride())
+    view = flat[off:off + param.numel()].as_strided(param.size(), param.stride())
+    if not getattr(param, "_hn_slot_used", False) and param.grad is None:
+        param._hn_slot_used = True  # reset by the optimizer's zero_grad()
+        return view, True
+    if accumulate_ok and param._hn_slot_used and (param.grad is None or param.grad.data_ptr() == view.data_ptr()):
+        return view, False
+    return None
 
 
 def _leaf(t):
@@ -346,17 +365,31 @@ class _Conv2d(torch.autograd.Function):
         d = _desc(n, h, wd, cin, ldx, ho, wo, cout, cout, kh, kw, stride, pad, dil)
         s = _stream()
         ctx.wt = ctx.wtx3 = None
-        if _math("fwd") == "bf16x3" and _math("dgrad") == "bf16x3" and ctx.needs_input_grad[0]:
-            # a data gradient will follow: ONE launch prepares the forward operand (bf16 planes of w) and the dgrad
-            # operands (flipped / transposed weights, fp32 and bf16 planes), instead of a split now and a transpose later
-            nw = w.numel()
-            wx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16)
-            ctx.wt = torch.empty(nw, device=x.device, dtype=torch.float32)
-            ctx.wtx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16)
-            check(lib.hn_weight_flip_transpose(_ptr(w), _ptr(wx3), _ptr(ctx.wt), _ptr(ctx.wtx3), cout, kh, kw, cin, stride,
-                                               pad, dil, s), "hn_weight_flip_transpose")
-        else:
-            wx3 = split_weight(w)
+        wx3 = None
+        if _math("fwd") == "bf16x3":
+            # Weight operands of the bf16x3 kernels: the bf16 planes of w for the forward and -- when a data gradient
+            # will follow -- the flipped / transposed weights (fp32 and planes) for dgrad, all made by ONE launch.  They
+            # are kept on the parameter and reused while the weights are unchanged (second pass of a confusion-
+            # maximisation step, evaluation loops): see weights_changed().
+            want_t = _math("dgrad") == "bf16x3" and ctx.needs_input_grad[0]
+            leaf = _leaf(w_in) if w is w_in else None
+            key = (w.data_ptr(), w._version, _weights_epoch, stride, pad, dil)
+            prep = getattr(leaf, "_hn_prep", None) if leaf is not None else None
+            if prep is None or prep[0] != key or (want_t and prep[2] is None):
+                nw = w.numel()
+                wx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16)
+                if want_t:
+                    wt = torch.empty(nw, device=x.device, dtype=torch.float32)
+                    wtx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16)
+                    check(lib.hn_weight_flip_transpose(_ptr(w), _ptr(wx3), _ptr(wt), _ptr(wtx3), cout, kh, kw, cin, stride,
+                                                       pad, dil, s), "hn_weight_flip_transpose")
+                else:
+                    wt = wtx3 = None
+                    check(lib.hn_split_bf16x3(_ptr(w), _ptr(wx3), nw, s), "hn_split_bf16x3")
+                prep = (key, wx3, wt, wtx3)
+                if leaf is not None:
+                    leaf._hn_prep = prep
+            _, wx3, ctx.wt, ctx.wtx3 = prep
         var = _pick(_kind("fwd"), d, _igemm_candidates(cout, "fwd"), lambda v: check(
             lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), None, ctypes.byref(d), act, slope, v, s),
             "hn_conv2d_fwd"))
@@ -422,13 +455,16 @@ class _Conv2d(torch.autograd.Function):
                                           s), "hn_conv2d_dgrad")
         elif dskip is not None:
             dx = dskip
+        dw_out = None
         if ctx.needs_input_grad[1]:
-            dw = grad_slot(ctx.w_leaf) if ctx.w_leaf is not None else None
+            slot = grad_slot(ctx.w_leaf) if ctx.w_leaf is not None else None
             flags = 0
-            if dw is not None and weight_ohwi(dw) is dw:
-                flags = 1  # HN_WGRAD_DW_ZEROED: the arena was cleared by zero_grad()
+            if slot is not None and weight_ohwi(slot[0]) is slot[0]:
+                dw = slot[0]
+                flags = 1 if slot[1] else 2  # HN_WGRAD_DW_ZEROED (arena cleared by zero_grad) | HN_WGRAD_ACCUMULATE
+                dw_out = dw if slot[1] else None  # a later use adds in place and reports no gradient of its own
             else:
-                dw = torch.empty((cout, kh, kw, cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
+                dw_out = dw = torch.empty((cout, kh, kw, cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
             split, var = _pick(_kind("wgrad"), d, _wgrad_candidates(cout, cin), lambda sv: check(
                 lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(_tune_scratch(dw) if flags else dw), ctypes.byref(d), sv[0], sv[1], 0, s),
                 "hn_conv2d_wgrad"))
@@ -444,15 +480,16 @@ class _Conv2d(torch.autograd.Function):
                     check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), split, var, flags, s),
                           "hn_conv2d_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = grad_slot(ctx.b_leaf) if ctx.b_leaf is not None else None
+            slot = grad_slot(ctx.b_leaf, accumulate_ok=False) if ctx.b_leaf is not None else None
+            db = slot[0] if slot is not None else None
             if ctx.zero_bias_grad:
                 # the caller normalises this output with batch statistics: the bias cancels, its gradient is exactly 0
                 db = db if db is not None else torch.zeros(cout, device=x.device, dtype=torch.float32)
-                return dx, dw, db, None, None, None, None, None, None, None, None
+                return dx, dw_out, db, None, None, None, None, None, None, None, None
             if db is None:
                 db = torch.empty(cout, device=x.device, dtype=torch.float32)
             check(lib.hn_channel_sum(_ptr(dy), lddy, npix, cout, _ptr(db), s), "hn_channel_sum")
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw_out, db, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, w, b=None, stride=1, pad=0, dil=1, act=ACT_NONE, slope=0.0, want_stats=False, passthrough=False,
@@ -537,9 +574,15 @@ class _BnAct(torch.autograd.Function):
         sg = grad_slot(lg) if (lg is not None and ctx.needs_input_grad[2]) else None
         sb = grad_slot(lb) if (lb is not None and ctx.needs_input_grad[3]) else None
         sp = grad_slot(lp) if (lp is not None and prelu_w is not None and ctx.needs_input_grad[7]) else None
+        used = [t for t in (sg, sb, sp) if t is not None]
+        if len({first for _, first in used}) > 1:
+            sg = sb = sp = None  # the layer's parameters disagree on first / later use (not expected): plain outputs
+            used = []
+        accumulate = bool(used) and not used[0][1]  # a later use of the layer in this step: add into the slots
         check(lib.hn_bn_act_bwd_reduce(_ptr(dz), lddz, _ptr(z), ldz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(scale),
                                        _ptr(shift), npix, c, act, _ptr(prelu_w), leaky, _ptr(sums), _ptr(dpar),
-                                       _ptr(sg), _ptr(sb), _ptr(sp), _ptr(ctx.drop_mask), h * w, s),
+                                       _ptr(sg[0]) if sg else None, _ptr(sb[0]) if sb else None,
+                                       _ptr(sp[0]) if sp else None, int(accumulate), _ptr(ctx.drop_mask), h * w, s),
               "hn_bn_act_bwd_reduce")
         dy = new_nhwc(n, c, h, w, y.device) if ctx.needs_input_grad[0] else None
         dres = new_nhwc(n, c, h, w, y.device) if (has_res and ctx.needs_input_grad[6]) else None
@@ -550,10 +593,16 @@ class _BnAct(torch.autograd.Function):
                                           _ptr(gamma), _ptr(scale), _ptr(shift), _ptr(dpar), npix, int(training),
                                           _ptr(dy), c, _ptr(dres), c, npix, c, act, _ptr(prelu_w), leaky,
                                           _ptr(ctx.drop_mask), h * w, s), "hn_bn_act_bwd_apply")
-        dgamma = (sg if sg is not None else dpar[c:2 * c]) if ctx.needs_input_grad[2] else None
-        dbeta = (sb if sb is not None else dpar[0:c]) if ctx.needs_input_grad[3] else None
-        dprelu = (sp if sp is not None else dpar[2 * c:2 * c + 1]) if (prelu_w is not None and ctx.needs_input_grad[7]) \
-            else None
+        def out(slot, fallback, needed):  # first use: the slot view; later use: nothing (added in place); no slot: dpar
+            if not needed:
+                return None
+            if slot is None:
+                return fallback
+            return slot[0] if slot[1] else None
+
+        dgamma = out(sg, dpar[c:2 * c], ctx.needs_input_grad[2])
+        dbeta = out(sb, dpar[0:c], ctx.needs_input_grad[3])
+        dprelu = out(sp, dpar[2 * c:2 * c + 1], prelu_w is not None and ctx.needs_input_grad[7])
         return dy, None, dgamma, dbeta, None, None, dres, dprelu, None, None, None, None, None, None, None
 
 

@@ -131,6 +131,7 @@ class FlatRMSprop(_FlatOptimizer):
                 continue
             a.check()
             ops.rmsprop_step_(a.flat, a.grad, sq, g["lr"], g["alpha"], g["eps"], g["weight_decay"])
+        ops.weights_changed()
 
 
 class FlatAdam(_FlatOptimizer):
@@ -151,6 +152,7 @@ class FlatAdam(_FlatOptimizer):
             self.steps[i] += 1
             ops.adam_step_(a.flat, a.grad, self.exp_avg[i], self.exp_avg_sq[i], self.steps[i], g["lr"], g["betas"][0],
                            g["betas"][1], g["eps"], g["weight_decay"])
+        ops.weights_changed()
 
 
 def arenas_for(model):

@@ -114,8 +114,10 @@ int hn_conv2d_dgrad(const float* dy, const float* wt, const void* wt_x3, float* 
  * 0 / -1: fill two rounds of the chip's 512 resident workgroups; -2 / -3 / -4 / -5: one / three / four / six rounds.
  * `variant`: encoded as for hn_conv2d_fwd (the K-step field selects 32 or 16 pixels per reduction step).
  * `flags`: HN_WGRAD_DW_ZEROED = the caller guarantees dw is all zero on entry (e.g. a slice of a gradient arena cleared
- * once per step), so split launches accumulate into it without a fill of their own. */
+ * once per step), so split launches accumulate into it without a fill of their own; HN_WGRAD_ACCUMULATE = dw += the
+ * result (a second use of the same weights in one step adds to the gradient already there). */
 #define HN_WGRAD_DW_ZEROED 1
+#define HN_WGRAD_ACCUMULATE 2
 int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant,
                     int flags, void* stream);
 
@@ -156,12 +158,12 @@ int hn_bn_act_fwd(const float* y, int ldy, const float* scale, const float* shif
  * HN_ACT_RELU takes its mask from z > 0, or -- when z is NULL (allowed only if the forward had no residual) -- from
  * u recomputed from y; PRELU/LEAKY always recompute u from y (residual must have been NULL).
  * dgamma_out / dbeta_out / dslope_out (each optional): the same three results written where the caller keeps the
- * parameters' gradients, so that no copy or accumulation pass follows. */
+ * parameters' gradients (added to what is there when out_accumulate != 0), so that no copy or accumulation pass follows. */
 int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                          const float* mean, const float* invstd, const float* scale, const float* shift,
                          int64_t npix, int C, int act, const float* slope, float leaky_slope,
                          double* sums, float* dparams, float* dgamma_out, float* dbeta_out, float* dslope_out,
-                         const float* mask, int64_t hw, void* stream);
+                         int out_accumulate, const float* mask, int64_t hw, void* stream);
 
 /* Second backward pass: dy = gamma*invstd*(du - dbeta/count - xhat*dgamma/count) when `training`,
  * dy = gamma*invstd*du otherwise; dres = du when dres != NULL (gradient of the residual input).
