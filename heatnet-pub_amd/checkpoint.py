@@ -48,3 +48,21 @@ def save_checkpoint(state, is_best, filename="checkpoint.pth.tar"):
     torch.save(state, filename)
     if is_best:
         shutil.copyfile(filename, filename + "_best.pth.tar")
+
+
+def resume(path, model, optimizer=None, lr_scheduler=None):
+    """The resume block of cm/train_trgb_segnet_conf.py:276-283: model weights, optimizer and LR-scheduler state, epoch
+    and best mIoU from a `save_checkpoint` file of either implementation.  Returns (epoch, best_iou).  `optimizer` may be
+    a torch.optim optimizer or one of optim.FlatRMSprop / FlatAdam (state is matched by parameter order)."""
+    ckpt = torch.load(path, map_location="cpu")
+    state = ckpt["state_dict"]
+    own = model.state_dict()
+    if not any(k in own for k in state) and all(k.startswith("module.") for k in state):
+        state = {k[len("module."):]: v for k, v in state.items()}  # written through nn.DataParallel
+    model.load_state_dict(state)
+    ensure_channels_last_(model)
+    if optimizer is not None and "optimizer" in ckpt:
+        optimizer.load_state_dict(ckpt["optimizer"])
+    if lr_scheduler is not None and "lr_scheduler" in ckpt:
+        lr_scheduler.load_state_dict(ckpt["lr_scheduler"])
+    return ckpt.get("epoch", 0), ckpt.get("best_iou", 0.0)

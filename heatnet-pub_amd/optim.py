@@ -100,7 +100,14 @@ class ParamArena:
 
 
 class _FlatOptimizer(torch.optim.Optimizer):
-    """Common part: one param group per arena (so LR schedulers and state_dict-style access keep working)."""
+    """Common part: one param group per arena (so LR schedulers and state_dict-style access keep working).
+
+    `state_dict()` / `load_state_dict()` speak torch.optim's format -- per-parameter entries `step` plus the buffers
+    named in `_BUFFERS` -- so that optimizer states move both ways between this class and the reference's
+    `torch.optim.RMSprop` / `Adam` checkpoints (cm/train_trgb_segnet_conf.py:276-283,648-654).  Parameters are matched by
+    their position in the concatenation of all param groups, whatever the grouping of the file."""
+
+    _BUFFERS = ()
 
     def __init__(self, arenas, defaults):
         if isinstance(arenas, ParamArena):
@@ -108,6 +115,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self.arenas = list(arenas)
         groups = [{"params": a.params} for a in self.arenas]
         super().__init__(groups, defaults)  # param_groups[i] <-> arenas[i]
+        self.steps = [0 for _ in self.arenas]
 
     def zero_grad(self, set_to_none=False):
         """One memset per arena; `set_to_none` is accepted for API compatibility and ignored (gradients are detached
@@ -116,19 +124,72 @@ class _FlatOptimizer(torch.optim.Optimizer):
             if a.active():
                 a.zero_grad()
 
+    def _flat_buffers(self, name):
+        return getattr(self, name)  # list of flat tensors, one per arena
+
+    def state_dict(self):
+        state, groups, idx = {}, [], 0
+        for gi, (g, a) in enumerate(zip(self.param_groups, self.arenas)):
+            ids = []
+            for p, off in zip(a.params, a.offsets):
+                if self.steps[gi] > 0:  # torch creates a parameter's state at its first step
+                    entry = {"step": torch.tensor(float(self.steps[gi]))}
+                    for name in self._BUFFERS:
+                        flat = self._flat_buffers(name)[gi]
+                        entry[name] = flat[off:off + p.numel()].as_strided(p.size(), p.stride()).clone()
+                    state[idx] = entry
+                ids.append(idx)
+                idx += 1
+            groups.append(dict({k: v for k, v in g.items() if k != "params"}, params=ids))
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, state_dict):
+        saved_ids = [i for g in state_dict["param_groups"] for i in g["params"]]
+        own = [(gi, p, off) for gi, a in enumerate(self.arenas) for p, off in zip(a.params, a.offsets)]
+        if len(saved_ids) != len(own):
+            raise ValueError("optimizer state has %d parameters, this optimizer %d" % (len(saved_ids), len(own)))
+        steps = [0 for _ in self.arenas]
+        with torch.no_grad():
+            for name in self._BUFFERS:
+                for flat in self._flat_buffers(name):
+                    flat.zero_()
+            for sid, (gi, p, off) in zip(saved_ids, own):
+                entry = state_dict["state"].get(sid)
+                if entry is None:
+                    continue
+                steps[gi] = max(steps[gi], int(float(entry.get("step", 0))))
+                for name in self._BUFFERS:
+                    t = entry[name]
+                    if tuple(t.shape) != tuple(p.shape):
+                        raise ValueError("optimizer state %s of parameter %d has shape %s, expected %s"
+                                         % (name, sid, tuple(t.shape), tuple(p.shape)))
+                    flat = self._flat_buffers(name)[gi]
+                    flat[off:off + p.numel()].as_strided(p.size(), p.stride()).copy_(t)
+        self.steps = steps
+        # hyper-parameters: a single saved group (the reference's optimizer) applies to every arena
+        saved_groups = state_dict["param_groups"]
+        for gi, g in enumerate(self.param_groups):
+            src = saved_groups[gi] if len(saved_groups) == len(self.param_groups) else saved_groups[0]
+            for k, v in src.items():
+                if k != "params" and k in g:
+                    g[k] = v
+
 
 class FlatRMSprop(_FlatOptimizer):
     """torch.optim.RMSprop(lr, alpha=0.99, eps=1e-8, weight_decay=0, momentum=0, centered=False) on arenas."""
 
+    _BUFFERS = ("square_avg",)
+
     def __init__(self, arenas, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0):
-        super().__init__(arenas, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay))
+        super().__init__(arenas, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay, momentum=0, centered=False))
         self.square_avg = [torch.zeros_like(a.flat) for a in self.arenas]
 
     @torch.no_grad()
     def step(self, closure=None):
-        for g, a, sq in zip(self.param_groups, self.arenas, self.square_avg):
+        for i, (g, a, sq) in enumerate(zip(self.param_groups, self.arenas, self.square_avg)):
             if not a.active():
                 continue
+            self.steps[i] += 1
             a.check()
             ops.rmsprop_step_(a.flat, a.grad, sq, g["lr"], g["alpha"], g["eps"], g["weight_decay"])
         ops.weights_changed()
@@ -137,11 +198,12 @@ class FlatRMSprop(_FlatOptimizer):
 class FlatAdam(_FlatOptimizer):
     """torch.optim.Adam(lr, betas, eps, weight_decay) on arenas (no amsgrad)."""
 
+    _BUFFERS = ("exp_avg", "exp_avg_sq")
+
     def __init__(self, arenas, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        super().__init__(arenas, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        super().__init__(arenas, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
         self.exp_avg = [torch.zeros_like(a.flat) for a in self.arenas]
         self.exp_avg_sq = [torch.zeros_like(a.flat) for a in self.arenas]
-        self.steps = [0 for _ in self.arenas]
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -179,3 +179,54 @@ def test_flat_arena_layout_on_cpu():
     assert float(arena.grad.sum()) == net.conv1.weight.numel()
     groups = optim.arenas_for(net)
     assert len(groups) == 1
+
+
+def test_flat_optimizer_state_interchange(tmp_path):
+    """optim.FlatRMSprop / FlatAdam state_dict() <-> torch.optim.RMSprop / Adam (the reference's checkpoints keep
+    `optimizer.state_dict()`, cm/train_trgb_segnet_conf.py:648-654), and checkpoint.resume() end to end."""
+    import copy
+    import torch.nn as nn
+    from heatnet_amd import checkpoint, optim
+
+    def make():
+        torch.manual_seed(0)
+        net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.PReLU(), nn.Conv2d(8, 4, 1))
+        net[0].weight.data = net[0].weight.data.contiguous(memory_format=torch.channels_last)  # as HnConv2d keeps them
+        return net
+
+    for flat_cls, ref_cls, bufs, kw in ((optim.FlatRMSprop, torch.optim.RMSprop, ("square_avg",), dict(lr=1e-4)),
+                                        (optim.FlatAdam, torch.optim.Adam, ("exp_avg", "exp_avg_sq"), dict(lr=1e-3))):
+        ref_net = make()
+        ref_opt = ref_cls(ref_net.parameters(), **kw)
+        for _ in range(2):  # two real torch steps -> a reference-format optimizer state
+            ref_opt.zero_grad()
+            ref_net(torch.randn(2, 3, 8, 8)).sum().backward()
+            ref_opt.step()
+        net = copy.deepcopy(ref_net)
+        flat = flat_cls(optim.arenas_for(net), **kw)
+        flat.load_state_dict(ref_opt.state_dict())                       # torch -> flat
+        assert flat.steps == [2]
+        arena = flat.arenas[0]
+        for p_ref, p, off in zip(ref_net.parameters(), arena.params, arena.offsets):
+            for name in bufs:
+                got = getattr(flat, name)[0][off:off + p.numel()].as_strided(p.size(), p.stride())
+                assert torch.equal(got, ref_opt.state[p_ref][name]), name
+        back = ref_cls(copy.deepcopy(ref_net).parameters(), **kw)
+        back.load_state_dict(flat.state_dict())                           # flat -> torch
+        for pa, pb in zip(back.param_groups[0]["params"], ref_opt.param_groups[0]["params"]):
+            for name in bufs:
+                assert torch.equal(back.state[pa][name], ref_opt.state[pb][name]), name
+            assert float(back.state[pa]["step"]) == 2.0
+        # a checkpoint file written the reference's way (DataParallel prefix) resumes into the flat optimizer
+        sched = torch.optim.lr_scheduler.StepLR(ref_opt, step_size=30, gamma=0.5)
+        path = str(tmp_path / ("ckpt_%s.pth.tar" % flat_cls.__name__))
+        checkpoint.save_checkpoint({"epoch": 7, "state_dict": {"module." + k: v for k, v in ref_net.state_dict().items()},
+                                    "best_iou": 0.42, "optimizer": ref_opt.state_dict(),
+                                    "lr_scheduler": sched.state_dict()}, False, filename=path)
+        net2 = make()
+        flat2 = flat_cls(optim.arenas_for(net2), **kw)
+        sched2 = torch.optim.lr_scheduler.StepLR(flat2, step_size=30, gamma=0.5)
+        epoch, best = checkpoint.resume(path, net2, flat2, sched2)
+        assert (epoch, best) == (7, 0.42) and flat2.steps == [2]
+        assert all(torch.equal(a, b) for a, b in zip(net2.state_dict().values(), ref_net.state_dict().values()))
+        assert torch.equal(getattr(flat2, bufs[0])[0], getattr(flat, bufs[0])[0])
