@@ -1,0 +1,38 @@
+"""GPU: bench.py's one-line JSON contract (the driver parses it), on a reduced geometry so the test stays short."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_contract_line():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2",
+                          "--height", "128", "--width", "256", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "alt_conv_math"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True
+    assert j["scaling"] == "weak" and j["unit"] == "images/s" and j["data"] == "synthetic" and j["vs_baseline"] is None
+    assert j["value"] > 0 and abs(j["value"] - 2 * 1e3 / j["ms_per_step"]) < 1e-2 * j["value"]
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert j["cpu_baseline"] is None  # --no-cpu-baseline
+    alt = j["alt_conv_math"]
+    assert alt["conv_math"] in ("f32", "bf16x3") and alt["conv_math"] != r["conv_math"] and alt["value"] > 0
