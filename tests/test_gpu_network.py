@@ -115,6 +115,34 @@ def test_segnet_backward_matches_oracle(dev):
 
 
 @pytest.mark.parametrize("conv_math", ["f32", "bf16x3"], indirect=True)
+def test_segnet_batch1_odd_geometry_with_ignored_labels(dev, conv_math):
+    """Edge geometry: a single image (BatchNorm statistics over one sample) of 72x104 pixels (9x13 feature maps: bins of
+    the 2/3/6 pyramid levels overlap, tiles are ragged everywhere) and labels containing the ignore index 13 of
+    scripts/main.py:223 -- logits, loss and parameter gradients against the CPU oracle."""
+    from heatnet_amd import train_step
+    from oracle import heatnet_ref as R
+    rgb, ir, lab = seeded_inputs(1, 72, 104, seed=17, n_classes=13, ignore_frac=0.2, ignore_index=13)
+    ref = R.RefPSPNet(backend="resnet50", late_fusion=True, in_channels=4)
+    ref.load_state_dict(seeded_state(ref, seed=5))
+    set_dropout(ref, 0.0)
+    ref.train()
+    rlogits = ref(rgb, ir)[0]
+    rloss = torch.nn.functional.cross_entropy(rlogits, lab, ignore_index=13)
+    rloss.backward()
+    net = _build(True, 5, dev)
+    net.train()
+    logits = net(rgb.to(dev), ir.to(dev))[0]
+    loss = train_step.segmentation_loss(logits, lab.to(dev), ignore_index=13)
+    loss.backward()
+    assert float((logits.detach().cpu() - rlogits.detach()).abs().max()) < 1e-3
+    assert abs(loss.item() - rloss.item()) < 1e-4
+    # gradients: the final classifier sees the loss directly (no ReLU decisions in between)
+    for k in ("final.0.weight", "final.0.bias"):
+        a, b = dict(net.named_parameters())[k].grad.detach().cpu(), dict(ref.named_parameters())[k].grad
+        assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max())), k
+
+
+@pytest.mark.parametrize("conv_math", ["f32", "bf16x3"], indirect=True)
 def test_fullres_minibatch_logits_and_miou(dev, golden_dir, conv_math):
     """BASELINE criterion: logits within 1e-3 and |d mIoU| < 1e-3 on the fixed 2x320x704 mini-batch."""
     from heatnet_amd import miou, train_step
