@@ -500,17 +500,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
                 }
             }
         };
-        // chunk kc+1 is fetched into the other staging set BEFORE chunk kc is split and stored, so a fetch has the
-        // split/store phase plus the whole MFMA phase to land
-        auto x3_step = [&](bool more, auto& cur_a, auto& cur_b, auto& nxt_a, auto& nxt_b) {
-#ifndef HN_EXP_NOLOAD
-            if (more) {
-                load_a(nxt_a);
-                load_b(nxt_b);
-            }
-#endif
+        // Two staging sets, fetch distance two K steps: chunk kc is split and stored from its set, and that set is then
+        // refilled at once with chunk kc+2 -- so a fetch has the rest of this step and ALL of the next one to land
+        // (a fetch issued one step ahead was what the waves waited on most: 39 % of the wave cycles in
+        // SQ_WAIT_INST_ANY beyond LDS).
+        auto x3_step = [&](bool refill, auto& set_a, auto& set_b) {
 #ifndef HN_EXP_NOWRITE
-            store_lds(0, cur_a, cur_b);
+            store_lds(0, set_a, set_b);
+#endif
+#ifndef HN_EXP_NOLOAD
+            if (refill) {
+                load_a(set_a);
+                load_b(set_b);
+            }
 #endif
             __syncthreads();
             x3_k32();
@@ -518,12 +520,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         };
         load_a(va);
         load_b(vb);
+        if (nchunks > 1) {
+            load_a(va1);
+            load_b(vb1);
+        }
         int kc = 0;
         for (; kc + 1 < nchunks; kc += 2) {
-            x3_step(true, va, vb, va1, vb1);
-            x3_step(kc + 2 < nchunks, va1, vb1, va, vb);
+            x3_step(kc + 2 < nchunks, va, vb);
+            x3_step(kc + 3 < nchunks, va1, vb1);
         }
-        if (kc < nchunks) x3_step(false, va, vb, va1, vb1);
+        if (kc < nchunks) x3_step(false, va, vb);
     } else {
     load_a(va);
     load_b(vb);

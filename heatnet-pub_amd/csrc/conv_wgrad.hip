@@ -629,9 +629,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
         }
     };
     // every lane takes part in every transposed read (EXEC all ones): the loop below has no lane-dependent control flow
-    auto x3_step = [&](bool more, int cur) {
-        if (more) load_chunk(va[cur ^ 1], vb[cur ^ 1]);
+    // two staging sets, fetch distance two reduction steps: a set is refilled (chunk kc+2) right after it has been
+    // split and stored (chunk kc)
+    auto x3_step = [&](bool refill, int cur) {
         store_chunk(va[cur], vb[cur]);
+        if (refill) load_chunk(va[cur], vb[cur]);
         __syncthreads();
         x3_k32();
         __syncthreads();
@@ -639,10 +641,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
     const int nch = c_end - c_begin;
     if (nch > 0) {
         load_chunk(va[0], vb[0]);
+        if (nch > 1) load_chunk(va[1], vb[1]);
         int kc = 0;
         for (; kc + 1 < nch; kc += 2) {
-            x3_step(true, 0);
-            x3_step(kc + 2 < nch, 1);
+            x3_step(kc + 2 < nch, 0);
+            x3_step(kc + 3 < nch, 1);
         }
         if (kc < nch) x3_step(false, 0);
     }
