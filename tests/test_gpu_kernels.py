@@ -300,7 +300,7 @@ def test_adaptive_avgpool(dev, size, hw):
     close(xd.grad, xr.grad, atol=1e-6, rtol=1e-5, what="dx")
 
 
-BILINEAR_CASES = [((2, 64, 10, 14), (20, 28)), ((1, 64, 1, 1), (40, 88)), ((2, 64, 2, 2), (40, 88)),
+BILINEAR_CASES = [((2, 64, 10, 14), (20, 28)), ((1, 12, 5, 7), (10, 14)), ((2, 3, 1, 4), (2, 8)), ((1, 8, 9, 1), (18, 2)), ((1, 64, 1, 1), (40, 88)), ((2, 64, 2, 2), (40, 88)),
                   ((2, 64, 3, 3), (40, 88)), ((2, 64, 6, 6), (40, 88)), ((2, 64, 6, 6), (8, 12)),
                   ((2, 1, 2, 5), (64, 160)), ((2, 1, 1, 2), (32, 64)), ((1, 13, 7, 9), (14, 18))]
 
