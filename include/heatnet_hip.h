@@ -249,6 +249,29 @@ int hn_rmsprop_step(float* param, const float* grad, float* square_avg, int64_t 
 int hn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 
+/* ---- data path: per-sample augmentation of cm/thermal_loader.py:642-735 on the device ----
+ * One entry of `params` (device memory, N of them) describes what the loader draws for a sample:
+ *   crop_i, crop_j   top-left corner of the random crop (transforms.RandomCrop.get_params, :642)
+ *   flip             horizontal flip (F.hflip, :690-699)
+ *   mode             0 = no rotation, 1 = rotation by the affine matrix below, 2 = Pillow's exact 180-degree fast path
+ *   m[6]             PIL.Image.rotate's inverse matrix (a, b, c, d, e, f), double
+ *   fx[6]            the same matrix in Pillow's 16.16 fixed point (nearest-neighbour path of the labels):
+ *                    FLOOR(v * 65536 + 0.5) of a, b, c + a/2 + b/2, d, e, f + d/2 + e/2
+ *   drop_*           modality block drop rectangle (train_trgb_segnet_conf.py:82-86); drop_target 0 none, 1 RGB, 2 IR
+ * heatnet-pub_amd/augment.py fills it exactly as oracle/thermal_aug_ref.py does. */
+typedef struct HnAugSample {
+    int32_t crop_i, crop_j, flip, mode;
+    double m[6];
+    long long fx[6];
+    int32_t drop_i, drop_j, drop_h, drop_w, drop_target, reserved;
+} HnAugSample;
+
+/* rgb [N][H0][W0][3] uint8, ir [N][H0][W0] uint16 (raw thermal counts), label [N][H0][W0] uint8 or NULL ->
+ * rgb_out [N][h][w][3], ir_out [N][h][w] fp32 in [-1, 1] (NHWC), label_out [N][h][w] int64 (NULL iff label is NULL). */
+int hn_thermal_augment(const uint8_t* rgb, const uint16_t* ir, const uint8_t* label, int N, int H0, int W0,
+                       const HnAugSample* params, int h, int w, float* rgb_out, float* ir_out, int64_t* label_out,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

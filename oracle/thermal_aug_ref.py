@@ -1,0 +1,161 @@
+"""CPU oracle for the per-sample augmentation path of the thermal data loader -- TEST
+INFRASTRUCTURE, not product code: only tests/, __graft_entry__.smoke() and bench tooling may import it.
+
+It restates, in numpy, what models/confusion_maximization/thermal_loader.py:642-745 does to one already resized and
+column-cropped sample:
+    random crop (i, j, h, w)                                    thermal_loader.py:642-648
+    IR clip to [21800, 25000] and scale to [0, 1]               :650-660  (uint16 arithmetic, then true division)
+    horizontal flip                                             :690-699  (torchvision F.hflip = PIL FLIP_LEFT_RIGHT)
+    rotation by a random angle, bilinear (images) / nearest (labels), zero fill   :701-712  (F.rotate = PIL Image.rotate)
+    to_tensor + normalize to [-1, 1]                            :717-735
+    modality block drop                                         train_trgb_segnet_conf.py:82-86 (rectDropTensor)
+
+The arithmetic of flip / rotate lives in a third-party dependency, Pillow (torchvision.transforms.functional forwards to
+PIL.Image.transpose / PIL.Image.rotate for PIL inputs).  Pillow IS installed in the build container, so this restatement
+is PINNED against it: tests/golden/make_golden_aug.py runs Pillow itself on seeded images and commits inputs + outputs
+(tests/golden/aug_*.npz); tests/test_oracle_aug.py checks this file against them bit for bit (uint8, labels) / to 1 ulp
+(float32).  cv2.resize (thermal_loader.py:621-626) is NOT restated: cv2 is not installed, its fixed-point INTER_LINEAR
+could not be pinned, and resizing stays on the host side of the boundary (parity unpinned for that step, by omission).
+
+Pillow algorithm restated (Pillow 12.2: Image.rotate in Image.py; affine_fixed / ImagingGenericTransform, nearest and
+bilinear filters in src/libImaging/Geometry.c, restated from their published behaviour and verified empirically):
+  * matrix: a = cos(-t), b = sin(-t), d = -sin(-t), e = cos(-t), each rounded to 15 decimals; c, f so that the centre
+    (w/2, h/2) is fixed.
+  * bilinear ('F' and 'RGB'): source = matrix * (x + 0.5, y + 0.5); outside [0, size) -> 0; then minus 0.5, floor,
+    two clamped taps per axis in double; the lower row is dropped (v2 = v1) when y + 1 is outside; uint8 results are
+    truncated, float32 results rounded by the cast.
+  * nearest ('L'): 16.16 fixed point -- every coefficient FLOOR(v * 65536 + 0.5), the row start includes the half-pixel
+    offsets, one add of `a` per pixel, arithmetic shift right by 16, zero outside.
+"""
+import math
+
+import numpy as np
+
+IR_MIN, IR_MAX = 21800, 25000
+
+
+def ir_clip_normalize(ir_u16):
+    """thermal_loader.py:650-660: clip the raw 16-bit thermal counts and map them to [0, 1] (float64 there, cast to
+    float32 at :676)."""
+    ir = np.clip(ir_u16, IR_MIN, IR_MAX)
+    return ((ir - IR_MIN) / (IR_MAX - IR_MIN)).astype(np.float32)
+
+
+def rotate_matrix(w, h, angle_deg):
+    """PIL.Image.rotate's inverse affine matrix (a, b, c, d, e, f) for expand=False, center=None."""
+    angle = -math.radians(angle_deg % 360.0)
+    a, b = round(math.cos(angle), 15), round(math.sin(angle), 15)
+    d, e = round(-math.sin(angle), 15), round(math.cos(angle), 15)
+    cx, cy = w / 2, h / 2
+    c = a * -cx + b * -cy + 0.0 + cx
+    f = d * -cx + e * -cy + 0.0 + cy
+    return a, b, c, d, e, f
+
+
+def affine_bilinear(img, matrix):
+    """Pillow's bilinear affine transform of a (H, W) float32 or (H, W, C) uint8 image, zero fill."""
+    h, w = img.shape[:2]
+    a, b, c, d, e, f = matrix
+    ys, xs = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    xin = a * (xs + 0.5) + b * (ys + 0.5) + c
+    yin = d * (xs + 0.5) + e * (ys + 0.5) + f
+    inside = (xin >= 0.0) & (xin < w) & (yin >= 0.0) & (yin < h)
+    xin, yin = xin - 0.5, yin - 0.5
+    x, y = np.floor(xin), np.floor(yin)
+    dx, dy = xin - x, yin - y
+    x, y = x.astype(np.int64), y.astype(np.int64)
+    x0, x1 = np.clip(x, 0, w - 1), np.clip(x + 1, 0, w - 1)
+    y0 = np.clip(y, 0, h - 1)
+    has_y1 = (y + 1 >= 0) & (y + 1 < h)
+    y1 = np.clip(y + 1, 0, h - 1)
+    src = img.astype(np.float64)
+    if src.ndim == 3:
+        dx, dy, has_y1_b = dx[..., None], dy[..., None], has_y1[..., None]
+    else:
+        has_y1_b = has_y1
+    v1 = src[y0, x0] + (src[y0, x1] - src[y0, x0]) * dx
+    v2 = src[y1, x0] + (src[y1, x1] - src[y1, x0]) * dx
+    v2 = np.where(has_y1_b, v2, v1)
+    v = v1 + (v2 - v1) * dy
+    v = np.where(inside[..., None] if src.ndim == 3 else inside, v, 0.0)
+    if img.dtype == np.uint8:
+        return v.astype(np.uint8)  # C cast: truncation
+    return v.astype(np.float32)
+
+
+def affine_nearest_u8(img, matrix):
+    """Pillow's nearest-neighbour affine transform of a (H, W) uint8 image (16.16 fixed point path), zero fill."""
+    h, w = img.shape
+    fix = lambda v: int(math.floor(v * 65536.0 + 0.5))
+    a, b, c, d, e, f = matrix
+    a0, a1, a3, a4 = fix(a), fix(b), fix(d), fix(e)
+    a2 = fix(c + a * 0.5 + b * 0.5)
+    a5 = fix(f + d * 0.5 + e * 0.5)
+    out = np.zeros_like(img)
+    xs = np.arange(w, dtype=np.int64)
+    for y in range(h):
+        xx = a2 + a1 * y + a0 * xs
+        yy = a5 + a4 * y + a3 * xs
+        xi, yi = xx >> 16, yy >> 16
+        ok = (xi >= 0) & (xi < w) & (yi >= 0) & (yi < h)
+        out[y, ok] = img[yi[ok], xi[ok]]
+    return out
+
+
+def rotate(img, angle_deg, nearest=False):
+    """F.rotate(PIL image, angle, resample=BILINEAR | NEAREST) including Pillow's exact fast paths."""
+    angle = angle_deg % 360.0
+    h, w = img.shape[:2]
+    if angle == 0:
+        return img.copy()
+    if angle == 180:
+        return img[::-1, ::-1].copy()
+    if angle in (90, 270) and w == h:
+        return np.rot90(img, 1 if angle == 90 else 3).copy()
+    m = rotate_matrix(w, h, angle_deg)
+    return affine_nearest_u8(img, m) if nearest else affine_bilinear(img, m)
+
+
+def hflip(img):
+    return img[:, ::-1].copy()
+
+
+def to_tensor_normalize(img, mean=0.5, std=0.5):
+    """F.to_tensor + F.normalize: (H, W, 3) uint8 -> (3, H, W) float32 in [0,1] -> (x - mean) / std; (H, W) float32 ->
+    (1, H, W), same normalisation (thermal_loader.py:717-735)."""
+    if img.dtype == np.uint8:
+        t = img.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0)
+    else:
+        t = img.astype(np.float32)[None]
+    return ((t - np.float32(mean)) / np.float32(std)).astype(np.float32)
+
+
+def rect_drop(t, params):
+    """rectDropTensor (train_trgb_segnet_conf.py:82-86) for ONE sample: t is (C, H, W), params = (i, j, h, w)."""
+    i, j, h, w = (int(v) for v in params)
+    t = t.copy()
+    t[:, i:i + h, j:j + w] = 0
+    return t
+
+
+def augment_sample(rgb_u8, ir_u16, label_u8, crop, flip, angle, drop=None, drop_rgb=True):
+    """One sample through thermal_loader.py:642-735 (+ the trainer's rectangle drop): `crop` = (i, j, h, w), `flip` bool,
+    `angle` in degrees or None, `drop` = (i, j, h, w) or None applied to the RGB (drop_rgb) or to the IR tensor.
+    Returns rgb (3, h, w) float32, ir (1, h, w) float32, label (h, w) uint8."""
+    i, j, h, w = crop
+    rgb = rgb_u8[i:i + h, j:j + w]
+    ir = ir_clip_normalize(ir_u16[i:i + h, j:j + w])
+    lab = label_u8[i:i + h, j:j + w] if label_u8 is not None else None
+    if flip:
+        rgb, ir = hflip(rgb), hflip(ir)
+        lab = hflip(lab) if lab is not None else None
+    if angle is not None:
+        rgb, ir = rotate(rgb, angle), rotate(ir, angle)
+        lab = rotate(lab, angle, nearest=True) if lab is not None else None
+    rgb_t, ir_t = to_tensor_normalize(rgb), to_tensor_normalize(ir)
+    if drop is not None:
+        if drop_rgb:
+            rgb_t = rect_drop(rgb_t, drop)
+        else:
+            ir_t = rect_drop(ir_t, drop)
+    return rgb_t, ir_t, lab
