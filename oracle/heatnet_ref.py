@@ -3,7 +3,9 @@
 A from-scratch restatement, in stock fp32 `torch` CPU ops, of the arithmetic the
 reference performs on its training hot path.  Only `tests/`,
 `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import
-this file; the shipped package (`heatnet-pub_amd/`) never does.
+this file (plus the diagnostic scripts under `tools/`, which use it the same
+way: as the checker / the timed CPU side); the shipped package
+(`heatnet-pub_amd/`) never does.
 
 Pinning: the reference has no tests or golden vectors of its own (SURVEY.md
 section 4), so this restatement is pinned by outputs of the reference's own

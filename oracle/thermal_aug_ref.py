@@ -1,5 +1,6 @@
 """CPU oracle for the per-sample augmentation path of the thermal data loader -- TEST
-INFRASTRUCTURE, not product code: only tests/, __graft_entry__.smoke() and bench tooling may import it.
+INFRASTRUCTURE, not product code: only tests/ and the diagnostic / bench scripts under tools/ import it (as the checker
+and as the timed CPU side); the shipped package (heatnet-pub_amd/) never does.
 
 It restates, in numpy, what models/confusion_maximization/thermal_loader.py:642-745 does to one already resized and
 column-cropped sample:
