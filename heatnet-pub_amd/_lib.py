@@ -49,7 +49,7 @@ SIGNATURES = {
     "hn_bilinear_bwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_pyramid_merge_fwd": [P, c_int, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_split_bf16x3": [P, P, c_i64, P],
-    "hn_thermal_augment": [P, P, P, c_int, c_int, c_int, P, c_int, c_int, P, P, P, P],
+    "hn_thermal_augment": [P, P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P, P],
     "hn_set_conv_math": [c_int],
     "hn_get_conv_math": [],
     "hn_pyramid_pool_bwd": [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],

@@ -21,7 +21,9 @@ class HnAugSample(ctypes.Structure):
     _fields_ = [("crop_i", ctypes.c_int32), ("crop_j", ctypes.c_int32), ("flip", ctypes.c_int32), ("mode", ctypes.c_int32),
                 ("m", ctypes.c_double * 6), ("fx", ctypes.c_longlong * 6),
                 ("drop_i", ctypes.c_int32), ("drop_j", ctypes.c_int32), ("drop_h", ctypes.c_int32),
-                ("drop_w", ctypes.c_int32), ("drop_target", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("drop_w", ctypes.c_int32), ("drop_target", ctypes.c_int32), ("ir_scale", ctypes.c_float)]
+
+AUG_CLASSES = 32  # HN_AUG_CLASSES
 
 
 def rotate_matrix(w, h, angle_deg):
@@ -56,10 +58,12 @@ def draw_params(n, src_hw, out_hw, rng=random):
     return out
 
 
-def augment_batch(rgb_u8, ir_u16, label_u8, out_hw, params, drop_target=None):
+def augment_batch(rgb_u8, ir_u16, label_u8, out_hw, params, drop_target=None, class_scale=None):
     """rgb_u8 [N,H0,W0,3] uint8, ir_u16 [N,H0,W0] uint16 (or int32 holding 16-bit counts), label_u8 [N,H0,W0] uint8 or
     None, all on the GPU; `params`: list of dicts(crop=(i,j), flip=bool, angle=deg|None, drop=(i,j,h,w)|None);
-    `drop_target`: None, "rgb" or "ir" (which tensor the block drop zeroes).  Returns (rgb [N,3,h,w], ir [N,1,h,w],
+    `drop_target`: None, "rgb" or "ir" (which tensor the block drop zeroes); a dict may carry `ir_scale` (the trainer's
+    `ir_day = scale * ir_day`, train_trgb_segnet_conf.py:402-405); `class_scale`: per-class factors on the thermal tensor
+    (smartAugment, :101-110; needs labels).  Returns (rgb [N,3,h,w], ir [N,1,h,w],
     label [N,h,w] int64 or None) -- logical NCHW over NHWC memory, what the network's first convolutions consume."""
     if not rgb_u8.is_cuda:
         raise RuntimeError("augment_batch runs on the MI355X only; there is no CPU fallback")
@@ -89,6 +93,7 @@ def augment_batch(rgb_u8, ir_u16, label_u8, out_hw, params, drop_target=None):
                 m = rotate_matrix(w, h, angle)
                 e.m[:] = m
                 e.fx[:] = _fixed(m)
+        e.ir_scale = float(p.get("ir_scale", 1.0))
         drop = p.get("drop") if drop_target else None
         if drop is not None:
             e.drop_i, e.drop_j, e.drop_h, e.drop_w = drop
@@ -100,8 +105,12 @@ def augment_batch(rgb_u8, ir_u16, label_u8, out_hw, params, drop_target=None):
     ir = torch.empty((n, h, w, 1), device=dev, dtype=torch.float32)
     lab = torch.empty((n, h, w), device=dev, dtype=torch.int64) if label_u8 is not None else None
     ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    cs = None
+    if class_scale is not None:
+        vals = list(class_scale) + [1.0] * (AUG_CLASSES - len(class_scale))
+        cs = torch.tensor(vals[:AUG_CLASSES], dtype=torch.float32).to(dev)
     check(_lib.load().hn_thermal_augment(ptr(rgb_u8.contiguous()), ptr(ir_u16.contiguous()),
                                          ptr(label_u8.contiguous()) if label_u8 is not None else None, n, h0, w0, ptr(pdev),
-                                         h, w, ptr(rgb), ptr(ir), ptr(lab),
+                                         ptr(cs), h, w, ptr(rgb), ptr(ir), ptr(lab),
                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "hn_thermal_augment")
     return rgb.permute(0, 3, 1, 2), ir.permute(0, 3, 1, 2), lab

@@ -33,7 +33,8 @@ __device__ __forceinline__ float ir_value(const Src& s, int64_t idx) {
     return (float)((v - IR_MIN) / IR_SPAN);
 }
 
-__global__ __launch_bounds__(256) void thermal_augment_kernel(Src s, const HnAugSample* __restrict__ params, int N, int h, int w,
+__global__ __launch_bounds__(256) void thermal_augment_kernel(Src s, const HnAugSample* __restrict__ params,
+                                                             const float* __restrict__ class_scale, int N, int h, int w,
                                                              float* __restrict__ rgb_out, float* __restrict__ ir_out,
                                                              int64_t* __restrict__ label_out) {
     // Pillow's blend is plain C double arithmetic (multiply, then add, each rounded): a fused multiply-add rounds once and
@@ -90,7 +91,11 @@ __global__ __launch_bounds__(256) void thermal_augment_kernel(Src s, const HnAug
         const bool in_rect = y >= a.drop_i && y < a.drop_i + a.drop_h && x >= a.drop_j && x < a.drop_j + a.drop_w;
         const bool drop_rgb = in_rect && a.drop_target == 1, drop_ir = in_rect && a.drop_target == 2;
         for (int c = 0; c < 3; ++c) rgb_out[p * 3 + c] = drop_rgb ? 0.f : (r[c] - 0.5f) / 0.5f;
-        ir_out[p] = drop_ir ? 0.f : (irv - 0.5f) / 0.5f;
+        // then the trainer's thermal intensity augmentations: whole-sample scale and per-class scale (smartAugment)
+        float iv = drop_ir ? 0.f : (irv - 0.5f) / 0.5f;
+        iv *= a.ir_scale;
+        if (class_scale != nullptr) iv *= class_scale[lab < HN_AUG_CLASSES ? lab : HN_AUG_CLASSES - 1];
+        ir_out[p] = iv;
         if (label_out != nullptr) label_out[p] = lab;
     }
 }
@@ -98,16 +103,17 @@ __global__ __launch_bounds__(256) void thermal_augment_kernel(Src s, const HnAug
 }  // namespace
 
 extern "C" int hn_thermal_augment(const uint8_t* rgb, const uint16_t* ir, const uint8_t* label, int N, int H0, int W0,
-                                  const HnAugSample* params, int h, int w, float* rgb_out, float* ir_out,
-                                  int64_t* label_out, void* stream) {
+                                  const HnAugSample* params, const float* class_scale, int h, int w, float* rgb_out,
+                                  float* ir_out, int64_t* label_out, void* stream) {
     if (!rgb || !ir || !params || !rgb_out || !ir_out || N <= 0 || H0 <= 0 || W0 <= 0 || h <= 0 || w <= 0 || h > H0 || w > W0)
         return HN_EINVAL;
     if ((label == nullptr) != (label_out == nullptr)) return HN_EINVAL;
+    if (class_scale != nullptr && label == nullptr) return HN_EINVAL;
     const int64_t total = (int64_t)N * h * w;
     const int64_t blocks = (total + 255) / 256;
     Src s{rgb, ir, label, H0, W0};
     HN_LAUNCH(thermal_augment_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0,
-              static_cast<hipStream_t>(stream), s, params, N, h, w, rgb_out, ir_out, label_out);
+              static_cast<hipStream_t>(stream), s, params, class_scale, N, h, w, rgb_out, ir_out, label_out);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

@@ -258,19 +258,24 @@ int hn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  *   fx[6]            the same matrix in Pillow's 16.16 fixed point (nearest-neighbour path of the labels):
  *                    FLOOR(v * 65536 + 0.5) of a, b, c + a/2 + b/2, d, e, f + d/2 + e/2
  *   drop_*           modality block drop rectangle (train_trgb_segnet_conf.py:82-86); drop_target 0 none, 1 RGB, 2 IR
+ *   ir_scale         factor applied to the normalised thermal tensor (`ir_day = scale * ir_day`, :402-405); 1 = off
  * heatnet-pub_amd/augment.py fills it exactly as oracle/thermal_aug_ref.py does. */
 typedef struct HnAugSample {
     int32_t crop_i, crop_j, flip, mode;
     double m[6];
     long long fx[6];
-    int32_t drop_i, drop_j, drop_h, drop_w, drop_target, reserved;
+    int32_t drop_i, drop_j, drop_h, drop_w, drop_target;
+    float ir_scale;
 } HnAugSample;
 
 /* rgb [N][H0][W0][3] uint8, ir [N][H0][W0] uint16 (raw thermal counts), label [N][H0][W0] uint8 or NULL ->
- * rgb_out [N][h][w][3], ir_out [N][h][w] fp32 in [-1, 1] (NHWC), label_out [N][h][w] int64 (NULL iff label is NULL). */
+ * rgb_out [N][h][w][3], ir_out [N][h][w] fp32 in [-1, 1] (NHWC), label_out [N][h][w] int64 (NULL iff label is NULL).
+ * class_scale (optional, HN_AUG_CLASSES floats, needs labels): per-class factor on the thermal tensor where the
+ * (augmented) label equals the class -- smartAugment, train_trgb_segnet_conf.py:101-110. */
+#define HN_AUG_CLASSES 32
 int hn_thermal_augment(const uint8_t* rgb, const uint16_t* ir, const uint8_t* label, int N, int H0, int W0,
-                       const HnAugSample* params, int h, int w, float* rgb_out, float* ir_out, int64_t* label_out,
-                       void* stream);
+                       const HnAugSample* params, const float* class_scale, int h, int w, float* rgb_out, float* ir_out,
+                       int64_t* label_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -160,3 +160,12 @@ def augment_sample(rgb_u8, ir_u16, label_u8, crop, flip, angle, drop=None, drop_
         else:
             ir_t = rect_drop(ir_t, drop)
     return rgb_t, ir_t, lab
+
+
+def smart_augment(ir_t, label, class_scale):
+    """smartAugment (train_trgb_segnet_conf.py:101-110) for one sample with given per-class factors: the normalised
+    thermal tensor (1, h, w) is multiplied by class_scale[l] wherever label == l."""
+    out = ir_t.copy()
+    for l, f in enumerate(class_scale):
+        out[0] = np.where(label == l, out[0] * np.float32(f), out[0])
+    return out

@@ -53,6 +53,23 @@ def test_augment_matches_oracle(dev, geom):
             assert np.abs(got_ir[k].cpu().numpy() - ei).max() <= 2.5e-7, (k, p)
 
 
+def test_thermal_intensity_augmentations(dev):
+    """`ir_day = scale * ir_day` and smartAugment (train_trgb_segnet_conf.py:101-110, 402-410) folded into the same pass."""
+    from heatnet_amd import augment
+    from oracle import thermal_aug_ref as A
+    rgb, ir, lab = _sample_batch(3, 24, 32, seed=9)
+    params = [dict(crop=(0, 0), flip=False, angle=None, ir_scale=0.37), dict(crop=(1, 2), flip=True, angle=5.0),
+              dict(crop=(0, 0), flip=False, angle=-11.0, ir_scale=0.9)]
+    cls = [0.1 + 0.07 * k for k in range(13)]
+    _, got_ir, got_lab = augment.augment_batch(torch.from_numpy(rgb).to(dev), torch.from_numpy(ir).to(dev),
+                                               torch.from_numpy(lab).to(dev), (20, 28), params, class_scale=cls)
+    for k, p in enumerate(params):
+        _, ei, el = A.augment_sample(rgb[k], ir[k], lab[k], p["crop"] + (20, 28), p["flip"], p["angle"])
+        want = A.smart_augment(ei * np.float32(p.get("ir_scale", 1.0)), el, cls)
+        assert np.array_equal(got_lab[k].cpu().numpy(), el.astype(np.int64))
+        assert np.abs(got_ir[k].cpu().numpy() - want).max() <= 3e-7, k
+
+
 def test_augment_without_labels_and_argument_checks(dev):
     from heatnet_amd import augment
     rgb, ir, _ = _sample_batch(2, 20, 24, seed=1)
