@@ -152,4 +152,4 @@ def broadcast_module_state(module, src=0, process_group=None):
                 dist.broadcast(tmp, src, group=process_group)
                 t.copy_(tmp)
     from . import ops
-    ops.weights_changed()  # the collective wrote the parameters behind their version counters
+    ops.weights_changed()  # in case the caller holds a frozen_weights() scope open

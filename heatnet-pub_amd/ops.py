@@ -177,16 +177,36 @@ def _variant(bk=0, tm=0, tn=0, math=0):
     return bk + 4 * tm + 16 * tn + 64 * math
 
 
-_weights_epoch = 0
+# Prepared weight operands (bf16 planes, flipped / transposed copies) are reused only inside a `frozen_weights()` scope:
+# the caller's promise that no parameter changes while it is open (the day and night passes of one training iteration,
+# an evaluation loop).  Outside a scope every forward prepares its operands afresh -- parameter writes through `.data`
+# (the reference's init functions) cannot be observed, so nothing is ever reused on a guess.
+_frozen_depth = 0
+_frozen_scope = 0
+
+
+class frozen_weights:
+    """`with ops.frozen_weights(): ...` -- parameters are constant inside: weight operands prepared by one forward are
+    reused by the following ones (keyed on the parameter's storage, version counter and conv geometry as well)."""
+
+    def __enter__(self):
+        global _frozen_depth, _frozen_scope
+        if _frozen_depth == 0:
+            _frozen_scope += 1
+        _frozen_depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _frozen_depth
+        _frozen_depth -= 1
+        return False
 
 
 def weights_changed():
-    """Invalidate the cached bf16x3 weight operands.  Called by the flat optimizers after their update (it goes through
-    the arena, not through the parameters' version counters) and by anything else that writes parameters through
-    `.data` (ddp.broadcast_module_state); in-place updates through the Parameter itself (torch.optim, load_state_dict)
-    are seen through `Tensor._version`."""
-    global _weights_epoch
-    _weights_epoch += 1
+    """Invalidate operands prepared so far (a new scope id); for code that updates parameters inside an open
+    `frozen_weights()` scope after all."""
+    global _frozen_scope
+    _frozen_scope += 1
 
 
 def x3_plane(n):
@@ -369,12 +389,12 @@ class _Conv2d(torch.autograd.Function):
         if _math("fwd") == "bf16x3":
             # Weight operands of the bf16x3 kernels: the bf16 planes of w for the forward and -- when a data gradient
             # will follow -- the flipped / transposed weights (fp32 and planes) for dgrad, all made by ONE launch.  They
-            # are kept on the parameter and reused while the weights are unchanged (second pass of a confusion-
-            # maximisation step, evaluation loops): see weights_changed().
+            # are kept on the parameter and reused inside a frozen_weights() scope (second pass of a confusion-
+            # maximisation step, evaluation loops).
             want_t = _math("dgrad") == "bf16x3" and ctx.needs_input_grad[0]
             leaf = _leaf(w_in) if w is w_in else None
-            key = (w.data_ptr(), w._version, _weights_epoch, stride, pad, dil)
-            prep = getattr(leaf, "_hn_prep", None) if leaf is not None else None
+            key = (w.data_ptr(), w._version, _frozen_scope, stride, pad, dil)
+            prep = getattr(leaf, "_hn_prep", None) if (leaf is not None and _frozen_depth > 0) else None
             if prep is None or prep[0] != key or (want_t and prep[2] is None):
                 nw = w.numel()
                 wx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16)
@@ -387,7 +407,7 @@ class _Conv2d(torch.autograd.Function):
                     wt = wtx3 = None
                     check(lib.hn_split_bf16x3(_ptr(w), _ptr(wx3), nw, s), "hn_split_bf16x3")
                 prep = (key, wx3, wt, wtx3)
-                if leaf is not None:
+                if leaf is not None and _frozen_depth > 0:
                     leaf._hn_prep = prep
             _, wx3, ctx.wt, ctx.wtx3 = prep
         var = _pick(_kind("fwd"), d, _igemm_candidates(cout, "fwd"), lambda v: check(

@@ -192,7 +192,6 @@ class FlatRMSprop(_FlatOptimizer):
             self.steps[i] += 1
             a.check()
             ops.rmsprop_step_(a.flat, a.grad, sq, g["lr"], g["alpha"], g["eps"], g["weight_decay"])
-        ops.weights_changed()
 
 
 class FlatAdam(_FlatOptimizer):
@@ -214,7 +213,6 @@ class FlatAdam(_FlatOptimizer):
             self.steps[i] += 1
             ops.adam_step_(a.flat, a.grad, self.exp_avg[i], self.exp_avg_sq[i], self.steps[i], g["lr"], g["betas"][0],
                            g["betas"][1], g["eps"], g["weight_decay"])
-        ops.weights_changed()
 
 
 def arenas_for(model):

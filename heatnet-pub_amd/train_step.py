@@ -72,7 +72,8 @@ def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_w
     optimizer.zero_grad(set_to_none=grad_sync is None)  # flat-arena optimizers always zero in place
     if grad_sync is not None:
         grad_sync.begin_step()
-    out = model(day, night)
+    with ops.frozen_weights():  # day and night passes share one preparation of every conv's weight operands
+        out = model(day, night)
     losses = {}
     if state == "train_seg":
         seg = segmentation_loss(out["pred_label_a"], label_day)

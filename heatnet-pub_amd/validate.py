@@ -31,7 +31,7 @@ def validate_model(model, samples, reference_mode=True, num_classes=14):
             model.train()  # the reference never leaves train mode during validation
         else:
             model.eval()
-        with torch.no_grad():
+        with torch.no_grad(), ops.frozen_weights():  # evaluation: weight operands prepared once for the whole loop
             for rgb, ir, label in samples:
                 if reference_mode:
                     for b in range(rgb.shape[0]):
