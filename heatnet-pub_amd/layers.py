@@ -78,7 +78,10 @@ def conv_bn_act(x, conv, bn, act=ops.ACT_NONE, residual=None, prelu_weight=None,
     `passthrough=True` additionally returns an alias of `x` to be used for the block's skip connection: its gradient
     then joins this conv's data gradient inside the dgrad kernel instead of in a separate elementwise add."""
     s, p, d = conv.geometry()
-    stats = bn.workspace(x.device).stats if bn.training else None  # conv epilogue adds into it, hn_bn_finalize re-zeroes
+    ws = bn.workspace(x.device)
+    stats = ws.stats if bn.training else None  # conv epilogue adds into it, hn_bn_finalize re-zeroes
+    if stats is not None:
+        ws.open_stats()
     batch_stats = bn.training or bn.running_mean is None
     out = ops.conv2d(x, conv.weight, conv.bias, s, p, d, want_stats=stats if stats is not None else False,
                      passthrough=passthrough, zero_bias_grad=batch_stats and conv.bias is not None)

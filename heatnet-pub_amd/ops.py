@@ -546,12 +546,16 @@ class _BnAct(torch.autograd.Function):
         mean, invstd, scale, shift = par[0:c], par[c:2 * c], par[2 * c:3 * c], par[3 * c:4 * c]
         if training:
             if stats is None:
+                if ws is not None:
+                    ws.open_stats()
                 stats = ws.stats if ws is not None else torch.zeros(STAT_REPLICAS * 2 * c, device=dev,
                                                                     dtype=torch.float64)
                 check(lib.hn_channel_stats(_ptr(y), ldy, npix, c, _ptr(stats), s), "hn_channel_stats")
             check(lib.hn_bn_finalize(_ptr(stats), npix, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                      momentum, eps, _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift), c, s),
                   "hn_bn_finalize")
+            if ws is not None:
+                ws.stats_open = False  # consumed and re-zeroed
         else:
             check(lib.hn_bn_eval_params(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), eps,
                                         _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift), c, s), "hn_bn_eval_params")
@@ -586,6 +590,8 @@ class _BnAct(torch.autograd.Function):
         mean, invstd, scale, shift = par[0:c], par[c:2 * c], par[2 * c:3 * c], par[3 * c:4 * c]
         ldz = c
         ws = ctx.ws
+        if ws is not None:
+            ws.open_bwd()
         sums = ws.bwd if ws is not None else torch.zeros(STAT_REPLICAS * (2 * c + 1), device=y.device,
                                                          dtype=torch.float64)
         dpar = torch.empty(2 * c + 1, device=y.device, dtype=torch.float32)   # dbeta | dgamma | dslope
@@ -604,6 +610,8 @@ class _BnAct(torch.autograd.Function):
                                        _ptr(sg[0]) if sg else None, _ptr(sb[0]) if sb else None,
                                        _ptr(sp[0]) if sp else None, int(accumulate), _ptr(ctx.drop_mask), h * w, s),
               "hn_bn_act_bwd_reduce")
+        if ws is not None:
+            ws.bwd_open = False  # hn_bn_act_bwd_reduce consumed and re-zeroed its accumulator
         dy = new_nhwc(n, c, h, w, y.device) if ctx.needs_input_grad[0] else None
         dres = new_nhwc(n, c, h, w, y.device) if (has_res and ctx.needs_input_grad[6]) else None
         if dy is not None or dres is not None:
@@ -633,6 +641,19 @@ class BnWorkspace:
         self.device = device
         buf = torch.zeros(STAT_REPLICAS * (4 * c + 1), device=device, dtype=torch.float64)
         self.stats, self.bwd = buf[:STAT_REPLICAS * 2 * c], buf[STAT_REPLICAS * 2 * c:]
+        # host-side guards: set while an accumulator may hold partial sums (between the kernel that adds into it and the
+        # kernel that consumes + re-zeroes it); if an exception interrupts that window, the next user clears it first
+        self.stats_open = self.bwd_open = False
+
+    def open_stats(self):
+        if self.stats_open:
+            self.stats.zero_()
+        self.stats_open = True
+
+    def open_bwd(self):
+        if self.bwd_open:
+            self.bwd.zero_()
+        self.bwd_open = True
 
 
 def bn_act(y, stats, gamma, beta, running_mean, running_var, residual=None, prelu_weight=None, training=True,

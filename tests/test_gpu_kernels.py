@@ -248,6 +248,33 @@ def test_pyramid_pool_fused_backward(dev, shape):
     close(xd2.grad, xr.grad, atol=1e-6, rtol=1e-5, what="dx(level 2 only)")
 
 
+def test_bn_accumulators_recover_from_an_interrupted_step(dev):
+    """The per-layer double accumulators must be zero when a kernel starts adding into them.  If an exception interrupts a
+    step between the producer (conv epilogue / backward reduction) and the consumer that re-zeroes them, the host-side
+    guards of ops.BnWorkspace clear the leftovers at the next use instead of silently folding them into the statistics."""
+    ops = _ops()
+    from heatnet_amd.layers import HnBatchNorm2d, HnConv2d, conv_bn_act
+    torch.manual_seed(1)
+    conv, bn = HnConv2d(32, 64, 3, padding=1, bias=False).to(dev), HnBatchNorm2d(64).to(dev)
+    x = torch.randn(2, 32, 10, 12, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    g = torch.randn(2, 64, 10, 12, device=dev).contiguous(memory_format=torch.channels_last)
+    z0 = conv_bn_act(x, conv, bn, ops.ACT_RELU)
+    z0.backward(g)
+    gx0, gg0 = x.grad.clone(), bn.weight.grad.clone()
+    ws = bn.workspace(dev)
+    ws.open_stats()          # an interrupted forward: producer ran, consumer did not
+    ws.stats.fill_(123.0)
+    ws.open_bwd()            # an interrupted backward
+    ws.bwd.fill_(-7.0)
+    x.grad = None
+    bn.weight.grad = None
+    z1 = conv_bn_act(x, conv, bn, ops.ACT_RELU)
+    z1.backward(g)
+    close(z1, z0, atol=1e-6, what="z after an interrupted forward")
+    close(x.grad, gx0, atol=1e-6, what="dx after an interrupted backward")
+    close(bn.weight.grad, gg0, atol=1e-5, rtol=1e-5, what="dgamma after an interrupted backward")
+
+
 def test_bn_stats_from_conv_epilogue_match_standalone(dev):
     """conv_bn_act (statistics from the conv epilogue) == conv then BatchNorm on CPU, incl. narrow C with ld tails."""
     from heatnet_amd.layers import HnBatchNorm2d, HnConv2d, conv_bn_act
