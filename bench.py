@@ -127,9 +127,10 @@ def measure_conv_roofline(step_fn, steps, workload, scale=1.0):
     ref_tflop = REFERENCE_CONV_TFLOP.get(workload) if scale == 1.0 else None
     math = ops.CONV_MATH
     peak = round(PEAK_TFLOPS[math], 1)
+    traffic_all, traffic_dominant = pmc_traffic(math)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
-            "traffic": pmc_traffic(math),
+            "traffic": traffic_all, "traffic_dominant_kernel": traffic_dominant,
             "algorithmic_bytes_per_launch": round(nbytes / max(launches, 1)),
             "kernel": KERNEL_LABEL[math], "conv_math": math,
             "launches_per_step": launches // steps,
@@ -144,16 +145,22 @@ def measure_conv_roofline(step_fn, steps, workload, scale=1.0):
 
 
 def pmc_traffic(math):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE, separate runs of this same benchmark, FETCH_SIZE doubled per MI355X_MICROARCH.md): counters
-    cannot be collected from inside this process, so the figure is read from profiles/ and is null if absent."""
+    """HBM bytes per conv-kernel launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE,
+    separate runs of this same benchmark, FETCH_SIZE doubled per MI355X_MICROARCH.md; tools/pmc_aggregate.py): counters
+    cannot be collected from inside this process, so the figures are read from profiles/ and are null if absent.
+    Returns (mean over ALL conv-kernel launches -- the set `achieved` and `algorithmic_bytes_per_launch` are taken
+    over --, bytes per launch of the dominant instantiation alone)."""
     name, kernel = {"f32": ("r01_pmc_hbm_traffic.json", "conv_igemm_kernel<2, 2, 4, 32>"),
                     "bf16x3": ("r01_pmc_hbm_traffic_bf16x3.json", "conv_igemm_kernel<2, 2, 4, 32, 1>")}[math]
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
-            return round(json.load(f)[kernel]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+            data = json.load(f)
+        conv = [v for k, v in data.items() if k.startswith("conv_igemm_kernel") or k.startswith("conv_wgrad")]
+        calls = sum(v["calls"] for v in conv)
+        mean = sum(v["calls"] * v["hbm_bytes_per_launch"] for v in conv) / calls
+        return round(mean), round(data[kernel]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None, None
 
 
 def cpu_baseline(workload):
