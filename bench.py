@@ -156,8 +156,9 @@ def pmc_traffic(math):
         with open(os.path.join(ROOT, "profiles", name)) as f:
             data = json.load(f)
         conv = [v for k, v in data.items() if k.startswith("conv_igemm_kernel") or k.startswith("conv_wgrad")]
-        calls = sum(v["calls"] for v in conv)
-        mean = sum(v["calls"] * v["hbm_bytes_per_launch"] for v in conv) / calls
+        ncalls = lambda v: v.get("calls", v.get("launches", 0))  # (the round-1 f32 file names the field "launches")
+        calls = sum(ncalls(v) for v in conv)
+        mean = sum(ncalls(v) * v["hbm_bytes_per_launch"] for v in conv) / calls
         return round(mean), round(data[kernel]["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None, None
