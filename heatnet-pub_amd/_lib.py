@@ -22,6 +22,12 @@ class HnConvDesc(ctypes.Structure):
 
 DP = ctypes.POINTER(HnConvDesc)
 
+
+class HnWeightPrepItem(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("w_x3", ctypes.c_void_p), ("wt", ctypes.c_void_p), ("wt_x3", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ("Cout", "KH", "KW", "Cin", "stride", "pad", "dil", "reserved")]
+
+
 # name -> argtypes, exactly the prototypes of include/heatnet_hip.h
 SIGNATURES = {
     "hn_conv2d_fwd": [P, P, P, P, P, P, DP, c_int, c_float, c_int, P],
@@ -49,6 +55,8 @@ SIGNATURES = {
     "hn_bilinear_bwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_pyramid_merge_fwd": [P, c_int, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_split_bf16x3": [P, P, c_i64, P],
+    "hn_weight_prep_table_fill": [P, c_int, P, P],
+    "hn_weight_prepare_batch": [P, c_int, c_int, P],
     "hn_thermal_augment": [P, P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P, P],
     "hn_set_conv_math": [c_int],
     "hn_get_conv_math": [],
@@ -85,6 +93,8 @@ def load():
         fn.restype = c_int
     lib.hn_strerror.argtypes = [c_int]
     lib.hn_strerror.restype = ctypes.c_char_p
+    lib.hn_weight_prep_table_bytes.argtypes = [c_int]
+    lib.hn_weight_prep_table_bytes.restype = ctypes.c_size_t
     lib.hn_version.argtypes = []
     lib.hn_version.restype = c_int
     _lib = lib

@@ -854,6 +854,60 @@ __global__ __launch_bounds__(256) void weight_taps_transpose_kernel(const float*
     }
 }
 
+// All layers of a model in ONE launch: the same tile body as weight_taps_transpose_kernel, with the layer looked up from
+// the block index (a step prepares ~90 weight matrices; as separate launches they cost ~7 us each, mostly latency).
+struct PrepLayer {
+    const float* w;
+    unsigned short* w_x3;
+    float* wt;
+    unsigned short* wt_x3;
+    long long plane;
+    int Cout, T, Cin;
+    int first_block, gx, gy;  // this layer's blocks are [first_block, first_block + gx * gy * T)
+    TapTable t;
+};
+
+__global__ __launch_bounds__(256) void weight_prepare_batch_kernel(const PrepLayer* __restrict__ layers, int n) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n - 1;  // last layer whose first_block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (layers[mid].first_block <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const PrepLayer& L = layers[lo];
+    const int local = blockIdx.x - L.first_block;
+    const int bx = local % L.gx, by = (local / L.gx) % L.gy, z = local / (L.gx * L.gy);
+    const float* __restrict__ w = L.w;
+    const int Cout = L.Cout, T = L.T, Cin = L.Cin;
+    const long long plane = L.plane;
+    const int ci0 = bx * 32, co0 = by * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int src = L.t.src[z];
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+            const size_t o = ((size_t)co * T + src) * Cin + ci;
+            v = w[o];
+            if (L.w_x3 != nullptr) split3_scalar(v, L.w_x3[o], L.w_x3[plane + o], L.w_x3[2 * plane + o]);
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    if (L.wt == nullptr && L.wt_x3 == nullptr) return;
+    const int rowstride = L.t.row[z];
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < Cin && co < Cout) {
+            const size_t o = (size_t)L.t.dst[z] + (size_t)ci * rowstride + co;
+            const float v = tile[tx][r];
+            if (L.wt != nullptr) L.wt[o] = v;
+            if (L.wt_x3 != nullptr) split3_scalar(v, L.wt_x3[o], L.wt_x3[plane + o], L.wt_x3[2 * plane + o]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
                                                           long long n, long long plane) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
@@ -1010,6 +1064,43 @@ extern "C" int hn_weight_flip_transpose(const float* w, void* w_x3, float* wt, v
     HN_LAUNCH(weight_taps_transpose_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w,
               static_cast<unsigned short*>(w_x3), wt, static_cast<unsigned short*>(wt_x3),
               hn_x3_plane((long long)Cout * KH * KW * Cin), Cout, KH * KW, Cin, t);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" size_t hn_weight_prep_table_bytes(int n) { return (size_t)(n > 0 ? n : 0) * sizeof(PrepLayer); }
+
+extern "C" int hn_weight_prep_table_fill(const HnWeightPrepItem* items, int n, void* table_host, int* total_blocks) {
+    if (items == nullptr || table_host == nullptr || total_blocks == nullptr || n <= 0) return HN_EINVAL;
+    PrepLayer* out = static_cast<PrepLayer*>(table_host);
+    long long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const HnWeightPrepItem& it = items[i];
+        if (it.w == nullptr || (it.w_x3 == nullptr && it.wt == nullptr && it.wt_x3 == nullptr) || it.Cout <= 0 || it.KH <= 0 ||
+            it.KW <= 0 || it.Cin <= 0 || it.stride <= 0 || it.pad < 0 || it.dil <= 0)
+            return HN_EINVAL;
+        if (it.KH * it.KW > 64) return HN_ESHAPE;
+        PrepLayer& L = out[i];
+        L.w = it.w;
+        L.w_x3 = static_cast<unsigned short*>(it.w_x3);
+        L.wt = it.wt;
+        L.wt_x3 = static_cast<unsigned short*>(it.wt_x3);
+        L.plane = hn_x3_plane((long long)it.Cout * it.KH * it.KW * it.Cin);
+        L.Cout = it.Cout; L.T = it.KH * it.KW; L.Cin = it.Cin;
+        L.gx = (it.Cin + 31) / 32; L.gy = (it.Cout + 31) / 32;
+        L.first_block = (int)blocks;
+        build_tap_table(L.t, it.Cout, it.KH, it.KW, it.Cin, it.stride, it.pad, it.dil);
+        blocks += (long long)L.gx * L.gy * L.T;
+        if (blocks > 0x7fffffffll) return HN_ESHAPE;
+    }
+    *total_blocks = (int)blocks;
+    return HN_OK;
+}
+
+extern "C" int hn_weight_prepare_batch(const void* table_dev, int n, int total_blocks, void* stream) {
+    if (table_dev == nullptr || n <= 0 || total_blocks <= 0) return HN_EINVAL;
+    HN_LAUNCH(weight_prepare_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+              static_cast<const PrepLayer*>(table_dev), n);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

@@ -8,11 +8,12 @@ allocation, autograd bookkeeping and streams only -- no arithmetic of the hot pa
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
 from . import _lib
-from ._lib import HnConvDesc, check
+from ._lib import HnConvDesc, HnWeightPrepItem, check
 
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY = 0, 1, 2, 3
 STAT_REPLICAS = 16  # HN_STAT_REPLICAS in include/heatnet_hip.h
@@ -207,6 +208,66 @@ def weights_changed():
     `frozen_weights()` scope after all."""
     global _frozen_scope
     _frozen_scope += 1
+
+
+class _WeightPrepRegistry:
+    """The convolutions seen inside frozen_weights() scopes (parameter, geometry, persistent operand buffers).  Once a
+    model's layers are known, `prepare_weights()` refreshes the operands of all layers used in the PREVIOUS scope with one
+    launch (hn_weight_prepare_batch) instead of one small launch per layer and step.  Parameters are held weakly."""
+
+    def __init__(self):
+        self.entries = {}      # (id(param), stride, pad, dil) -> dict(ref, geom, wx3, wt, wtx3, last_scope)
+        self.signature = None  # what the device table was built for
+        self.table = None
+        self.n = self.blocks = 0
+
+    def touch(self, leaf, geom, wx3, wt, wtx3):
+        key = (id(leaf),) + geom
+        e = self.entries.get(key)
+        if e is None or e["ref"]() is not leaf or e["wx3"] is not wx3:
+            e = self.entries[key] = dict(ref=weakref.ref(leaf), geom=geom, wx3=wx3, wt=wt, wtx3=wtx3)
+        e["last_scope"] = _frozen_scope
+
+    def run(self):
+        dead = [k for k, e in self.entries.items() if e["ref"]() is None]
+        for k in dead:
+            del self.entries[k]
+        live = [(e["ref"](), e) for e in self.entries.values() if e["last_scope"] == _frozen_scope - 1]
+        live = [(w, e) for w, e in live if w is not None and w.is_cuda]
+        if not live:
+            return
+        lib = _lib.load()
+        sig = tuple((w.data_ptr(), e["geom"], e["wx3"].data_ptr()) for w, e in live)
+        if sig != self.signature:  # first use, parameters re-homed (arena), or another set of layers (phase switch)
+            items = (HnWeightPrepItem * len(live))()
+            for it, (w, e) in zip(items, live):
+                cout, cin, kh, kw = w.shape
+                stride, pad, dil = e["geom"]
+                it.w, it.w_x3 = w.data_ptr(), e["wx3"].data_ptr()
+                it.wt, it.wt_x3 = e["wt"].data_ptr(), e["wtx3"].data_ptr()
+                it.Cout, it.KH, it.KW, it.Cin, it.stride, it.pad, it.dil = cout, kh, kw, cin, stride, pad, dil
+            host = torch.empty(lib.hn_weight_prep_table_bytes(len(live)), dtype=torch.uint8)
+            blocks = ctypes.c_int(0)
+            check(lib.hn_weight_prep_table_fill(items, len(live), ctypes.c_void_p(host.data_ptr()), ctypes.byref(blocks)),
+                  "hn_weight_prep_table_fill")
+            self.table = host.to(live[0][0].device)
+            self.n, self.blocks, self.signature = len(live), blocks.value, sig
+        check(lib.hn_weight_prepare_batch(_ptr(self.table), self.n, self.blocks, _stream()), "hn_weight_prepare_batch")
+        for w, e in live:
+            w._hn_prep = ((w.data_ptr(), w._version, _frozen_scope) + e["geom"], e["wx3"], e["wt"], e["wtx3"])
+            e["last_scope"] = _frozen_scope
+
+
+_prep_registry = _WeightPrepRegistry()
+BATCH_PREP = os.environ.get("HEATNET_BATCH_PREP", "1") != "0"  # A/B knob
+
+
+def prepare_weights():
+    """Inside a frozen_weights() scope, before the forward passes: refresh the weight operands of every convolution seen
+    in earlier scopes with ONE launch.  Layers not seen yet prepare themselves on first use (and are included next time).
+    A no-op under the "f32" arithmetic or outside a scope."""
+    if _frozen_depth > 0 and CONV_MATH == "bf16x3" and not _MATH_F32_KINDS and BATCH_PREP:
+        _prep_registry.run()
 
 
 def x3_plane(n):
@@ -409,6 +470,10 @@ class _Conv2d(torch.autograd.Function):
                 prep = (key, wx3, wt, wtx3)
                 if leaf is not None and _frozen_depth > 0:
                     leaf._hn_prep = prep
+                    if want_t:
+                        _prep_registry.touch(leaf, (stride, pad, dil), wx3, wt, wtx3)  # next scope: one batched launch
+            elif leaf is not None and want_t:
+                _prep_registry.touch(leaf, (stride, pad, dil), prep[1], prep[2], prep[3])
             _, wx3, ctx.wt, ctx.wtx3 = prep
         var = _pick(_kind("fwd"), d, _igemm_candidates(cout, "fwd"), lambda v: check(
             lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), None, ctypes.byref(d), act, slope, v, s),

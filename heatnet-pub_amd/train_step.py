@@ -73,6 +73,7 @@ def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_w
     if grad_sync is not None:
         grad_sync.begin_step()
     with ops.frozen_weights():  # day and night passes share one preparation of every conv's weight operands
+        ops.prepare_weights()   # ... made by one launch for all layers seen in earlier iterations
         out = model(day, night)
     losses = {}
     if state == "train_seg":
@@ -99,7 +100,9 @@ def segmentation_step(model, optimizer, rgb, ir, labels, ignore_index=-100, grad
     optimizer.zero_grad(set_to_none=grad_sync is None)
     if grad_sync is not None:
         grad_sync.begin_step()
-    res = model(rgb, ir) if ir is not None else model(rgb)
+    with ops.frozen_weights():
+        ops.prepare_weights()  # one launch prepares the weight operands of every conv seen in earlier iterations
+        res = model(rgb, ir) if ir is not None else model(rgb)
     logits = res[0] if isinstance(res, tuple) else res
     loss = segmentation_loss(logits, labels, ignore_index)
     loss.backward()

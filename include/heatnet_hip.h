@@ -102,6 +102,21 @@ int hn_split_bf16x3(const float* src, void* dst, int64_t n, void* stream);
 int hn_weight_flip_transpose(const float* w, void* w_x3, float* wt, void* wt_x3, int Cout, int KH, int KW, int Cin, int stride,
                              int pad, int dil, void* stream);
 
+/* The same preparation for MANY convolutions in one launch (a model has ~90; as separate launches they are latency-bound).
+ * Fill a host table from the items (hn_weight_prep_table_bytes(n) bytes), copy it to the device once -- it only holds
+ * pointers and geometry -- and run hn_weight_prepare_batch whenever the weights have changed.  Outputs may be NULL
+ * individually (w_x3: planes of w; wt / wt_x3: the data-gradient operand, fp32 / planes). */
+typedef struct HnWeightPrepItem {
+    const float* w;
+    void* w_x3;
+    float* wt;
+    void* wt_x3;
+    int32_t Cout, KH, KW, Cin, stride, pad, dil, reserved;
+} HnWeightPrepItem;
+size_t hn_weight_prep_table_bytes(int n);
+int hn_weight_prep_table_fill(const HnWeightPrepItem* items, int n, void* table_host, int* total_blocks);
+int hn_weight_prepare_batch(const void* table_dev, int n, int total_blocks, void* stream);
+
 /* dx = conv_transpose(dy, w) [+ addend] for the forward geometry `d` (dy is N x Hout x Wout x Cout with pixel stride
  * d->ldy, dx is N x Hin x Win x Cin with pixel stride d->ldx); `wt` from hn_weight_flip_transpose.  `addend`
  * (optional, pixel stride ldadd, must not overlap dx) is a gradient that reached the same tensor through another branch --

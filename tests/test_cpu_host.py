@@ -18,7 +18,9 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 30
     for name in declared:
         assert hasattr(lib, name), name
-    assert declared - {"hn_strerror", "hn_version"} == set(_lib.SIGNATURES)
+    # (the three with a non-int return type are bound separately in _lib.load())
+    assert declared - {"hn_strerror", "hn_version", "hn_weight_prep_table_bytes"} == set(_lib.SIGNATURES)
+    assert ctypes.sizeof(_lib.HnWeightPrepItem) == 4 * 8 + 8 * 4 and lib.hn_weight_prep_table_bytes(2) > 2 * 772
     assert lib.hn_strerror(-4) == b"inconsistent shapes"
     assert ctypes.sizeof(_lib.HnConvDesc) == 14 * 4
 
