@@ -275,16 +275,6 @@ def x3_plane(n):
     return (n + 7) & ~7
 
 
-def split_weight(w):
-    """The three bf16 planes (hi, mid, lo) of a dense fp32 weight, for the bf16x3 kernels; None under "f32"."""
-    if _math("fwd") != "bf16x3":
-        return None
-    n = w.numel()
-    out = torch.empty(3 * x3_plane(n), device=w.device, dtype=torch.int16)
-    check(_lib.load().hn_split_bf16x3(_ptr(w), _ptr(out), n, _stream()), "hn_split_bf16x3")
-    return out
-
-
 def _kind(kind):
     """Tune-cache key of a launch kind under the current arithmetic."""
     return kind if _math(kind) == "f32" else kind + "." + _math(kind)
