@@ -337,8 +337,9 @@ def _wgrad_candidates(cout, cin):
 # ---- dgrad || wgrad overlap ----------------------------------------------------------------------------------------
 # The two gradient kernels of a convolution are independent.  Launched back to back on one stream, each ends with a
 # partially filled last round of workgroups (grids are small multiples of the 256 CUs); launched on two streams the
-# tails overlap.  Measured on MI355X (bs 8, 320x704): 85.0 ms/step with the overlap vs 83.4 without -- two MFMA-bound
-# kernels mostly contend for the same pipes -- so it is OFF unless HEATNET_OVERLAP=1.
+# tails overlap.  Measured on MI355X (bs 8, 320x704): 85.0 ms/step with the overlap vs 83.4 without on the fp32-MFMA
+# kernels, 58.2-58.3 vs 57.2-57.6 on the bf16x3 kernels -- two MFMA kernels mostly contend for the same pipes and LDS --
+# so it is OFF unless HEATNET_OVERLAP=1.
 OVERLAP = os.environ.get("HEATNET_OVERLAP", "0") == "1"
 _side_streams = {}
 
