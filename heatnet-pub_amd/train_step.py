@@ -63,11 +63,15 @@ class PhaseSchedule:
         return True
 
 
-def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_weight=0.1, grad_sync=None):
+def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_weight=0.1, grad_sync=None,
+               night_teacher=None, teacher_modalities=("ir",)):
     """One iteration: zero_grad, forward (day + night passes, critics), loss of the phase, backward, step.
 
     `model` is a `conv_segnet` (possibly wrapped so that `.module` exists); `grad_sync`, when given, is a
     `ddp.GradBuckets` whose all-reduce overlaps the backward pass.  Returns the loss tensors (no host sync).
+    `night_teacher` (optional): the night-supervision model of train_trgb_segnet_conf.py:209-229 -- a frozen
+    PSPNet fed the night thermal image (`teacher_modalities=("ir",)`) or RGB + thermal; in `train_seg` its arg-max
+    prediction supervises the night pass (:430-434, 455-457; the unweighted variant, `--weight_ir_sup` off).
     """
     optimizer.zero_grad(set_to_none=grad_sync is None)  # flat-arena optimizers always zero in place
     if grad_sync is not None:
@@ -78,6 +82,14 @@ def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_w
     losses = {}
     if state == "train_seg":
         seg = segmentation_loss(out["pred_label_a"], label_day)
+        if night_teacher is not None:
+            with torch.no_grad():
+                t_in = [night[0], night[1]] if "rgb" in teacher_modalities else [night[1]]
+                t_logits = night_teacher(*t_in)[0]
+                pseudo, _ = ops.argmax_confusion(t_logits, None, t_logits.size(1))  # = argmax(softmax(.)), on the device
+            seg_night = segmentation_loss(out["pred_label_b"], pseudo.long())
+            losses["seg_night"] = seg_night.detach()
+            seg = seg + seg_night
         losses["seg"] = seg.detach()
         if "critics_a" in out:
             conf = confusion_loss(out, adv)

@@ -322,17 +322,27 @@ def confusion_loss(out, kind, weights=None, multidir=False):
     return total
 
 
-def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_weight=0.1):
+def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_weight=0.1, night_teacher=None,
+               teacher_modalities=("ir",)):
     """One iteration of train_trgb_segnet_conf.py:383-574 for `state` in {train_seg, train_critic}.
 
     Returns a dict of the scalar losses.  `optimizer.zero_grad()` leaves grads
     None (torch >= 2.0), so frozen-phase parameters are skipped by the optimizer.
+    `night_teacher`: the night-supervision model of :209-229 (a frozen segmentation net fed the night IR image, or RGB+IR);
+    its arg-max prediction is the label of the night pass in train_seg (:430-434, 455-457, unweighted variant).
     """
     optimizer.zero_grad()
     out = model(day, night)
     losses = {}
     if state == "train_seg":
         seg = F.cross_entropy(out["pred_label_a"], label_day)
+        if night_teacher is not None:
+            with torch.no_grad():
+                t_in = [night[0], night[1]] if "rgb" in teacher_modalities else [night[1]]
+                pseudo = torch.argmax(F.softmax(night_teacher(*t_in)[0], dim=1), 1)
+            seg_night = F.cross_entropy(out["pred_label_b"], pseudo)
+            losses["seg_night"] = float(seg_night.detach())
+            seg = seg + seg_night
         conf = confusion_loss(out, adv)
         total = seg + conf_weight * conf
         losses.update(seg=float(seg.detach()), conf=float(conf.detach()))

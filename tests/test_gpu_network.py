@@ -238,6 +238,51 @@ def test_confusion_maximisation_steps(dev, golden_dir, adv, conv_math, optimizer
         assert worst[0] < (5e-3 if step == 0 else 5e-2), worst
 
 
+def test_night_supervision_teacher_matches_oracle(dev):
+    """train_seg with the night-supervision teacher (train_trgb_segnet_conf.py:209-229, 430-457): a frozen IR-only PSPNet
+    labels the night image, the night pass gets a cross-entropy term -- losses and gradient norms against the oracle."""
+    from heatnet_amd import conf_segnet, train_step
+    from heatnet_amd.pspnet import PSPNet
+    from oracle import heatnet_ref as R
+    rgb_d, ir_d, lab = seeded_inputs(2, 256, 256, seed=11)
+    rgb_n, ir_n, _ = seeded_inputs(2, 256, 256, seed=12)
+    ref = R.RefConfSegnet()
+    state = seeded_state(ref, seed=7)
+    ref.load_state_dict(state)
+    set_dropout(ref, 0.0)
+    ref.train()
+    ref.setPhase("train_seg")
+    r_teacher = R.RefPSPNet(backend="resnet50", late_fusion=False, in_channels=1)
+    t_state = seeded_state(r_teacher, seed=9)
+    r_teacher.load_state_dict(t_state)
+    set_dropout(r_teacher, 0.0)
+    r_teacher.train()  # the reference never switches the teacher to eval mode either
+    r_losses = R.train_step(ref, torch.optim.RMSprop(ref.parameters(), lr=1e-4), [rgb_d, ir_d], [rgb_n, ir_n], lab,
+                            "train_seg", night_teacher=r_teacher)
+    r_norms = {k: float(p.grad.double().norm()) for k, p in ref.named_parameters() if p.grad is not None}
+
+    model = conf_segnet.conv_segnet(pretrained=False, disc_arch="cyclegan", num_critics=6, arch="pspnet", late_fusion=True)
+    model.load_state_dict(state)
+    set_dropout(model, 0.0)
+    model = model.to(dev).train()
+    model.setPhase("train_seg")
+    teacher = PSPNet(backend="resnet50", pretrained=False, late_fusion=False, in_channels=1)
+    teacher.load_state_dict(t_state)
+    set_dropout(teacher, 0.0)
+    teacher = teacher.to(dev).train()
+    losses = train_step.train_step(model, torch.optim.RMSprop(model.parameters(), lr=1e-4),
+                                   [rgb_d.to(dev), ir_d.to(dev)], [rgb_n.to(dev), ir_n.to(dev)], lab.to(dev), "train_seg",
+                                   night_teacher=teacher)
+    # a pseudo-label flips where the teacher's two best classes are within fp32 noise of each other; the loss moves by
+    # at most (flipped pixels / pixels) * a few nats
+    assert abs(losses["seg_night"].item() - r_losses["seg_night"]) < 2e-3, (losses["seg_night"].item(), r_losses["seg_night"])
+    assert abs(losses["total"].item() - r_losses["total"]) < 3e-3 * max(1.0, abs(r_losses["total"]))
+    got = {k: float(p.grad.double().norm()) for k, p in model.named_parameters() if p.grad is not None and p.requires_grad}
+    floor = 1e-4 * max(r_norms.values())
+    worst = max((abs(got[k] - r_norms[k]) / max(r_norms[k], floor), k) for k in r_norms if k in got)
+    assert worst[0] < 2e-2, worst
+
+
 def test_flat_arena_rmsprop_matches_torch(dev):
     """FlatRMSprop / FlatAdam on a ParamArena == torch.optim over three steps (same gradients), views stay attached."""
     from heatnet_amd import optim
