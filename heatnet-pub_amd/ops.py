@@ -244,7 +244,8 @@ class _WeightPrepRegistry:
                 cout, cin, kh, kw = w.shape
                 stride, pad, dil = e["geom"]
                 it.w, it.w_x3 = w.data_ptr(), e["wx3"].data_ptr()
-                it.wt, it.wt_x3 = e["wt"].data_ptr(), e["wtx3"].data_ptr()
+                it.wt = e["wt"].data_ptr() if e["wt"] is not None else None      # forward-only layers (frozen phase):
+                it.wt_x3 = e["wtx3"].data_ptr() if e["wtx3"] is not None else None  # planes of w only
                 it.Cout, it.KH, it.KW, it.Cin, it.stride, it.pad, it.dil = cout, kh, kw, cin, stride, pad, dil
             host = torch.empty(lib.hn_weight_prep_table_bytes(len(live)), dtype=torch.uint8)
             blocks = ctypes.c_int(0)
@@ -461,9 +462,8 @@ class _Conv2d(torch.autograd.Function):
                 prep = (key, wx3, wt, wtx3)
                 if leaf is not None and _frozen_depth > 0:
                     leaf._hn_prep = prep
-                    if want_t:
-                        _prep_registry.touch(leaf, (stride, pad, dil), wx3, wt, wtx3)  # next scope: one batched launch
-            elif leaf is not None and want_t:
+                    _prep_registry.touch(leaf, (stride, pad, dil), wx3, wt, wtx3)  # next scope: one batched launch
+            elif leaf is not None:
                 _prep_registry.touch(leaf, (stride, pad, dil), prep[1], prep[2], prep[3])
             _, wx3, ctx.wt, ctx.wtx3 = prep
         var = _pick(_kind("fwd"), d, _igemm_candidates(cout, "fwd"), lambda v: check(
