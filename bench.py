@@ -8,8 +8,10 @@ A step = one pass of the hot path over one synthetic batch resident in HBM:
       320x704, forward + per-pixel CE + backward + RMSprop update.
   confmax_seg / confmax_critic (configs[2]): one train_seg / train_critic iteration of the confusion-maximisation
       trainer (day + night passes, six critics); an "image" is then one day+night pair.
-N>1 is launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: one process per GPU,
-full replica each, gradients all-reduced by RCCL in flat buckets overlapped with backward (weak scaling).
+N>1: one process per GPU, full replica each, gradients all-reduced by RCCL in flat buckets overlapped with backward (weak
+scaling).  Either launch it as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, or just run
+`python bench.py --gpus N`: without a torchrun environment this process starts the N workers itself (as a child
+`torch.distributed.run`, before anything here touches the GPU), relays their output and exits with their code.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernels -- the implicit-GEMM convolutions -- as
 algorithmic conv FLOPs (2*M*N*K of every conv forward / data-gradient / weight-gradient launch) over the HIP-event time
@@ -26,6 +28,8 @@ reported as `alt_conv_math` (same workload, same step, K steps), so both numbers
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -85,7 +89,7 @@ def make_step(workload, model, opt, batch, buckets):
                                          adv="MSE", grad_sync=buckets)
 
 
-def measure_conv_roofline(step_fn, steps, workload, scale=1.0):
+def measure_conv_roofline(step_fn, steps, workload, scale=1.0, geom=(BS, H, W)):
     """Instrumented pass: HIP events (torch's current stream = the launch stream) around every conv-kernel launch."""
     from heatnet_amd import ops
     records = []
@@ -100,8 +104,12 @@ def measure_conv_roofline(step_fn, steps, workload, scale=1.0):
     flops = ms = 0.0
     table = {}
     nbytes = 0.0
-    for kind, fl, e0, e1, shape, by in records:
+    inst = {}
+    for kind, fl, e0, e1, shape, by, kname in records:
         nbytes += by
+        ie = inst.setdefault(kname, [0, 0.0])
+        ie[0] += 1
+        ie[1] += by
         t = e0.elapsed_time(e1)
         row = table.setdefault((kind,) + shape, [0, 0.0, 0.0])
         row[0] += 1
@@ -127,11 +135,17 @@ def measure_conv_roofline(step_fn, steps, workload, scale=1.0):
     ref_tflop = REFERENCE_CONV_TFLOP.get(workload) if scale == 1.0 else None
     math = ops.CONV_MATH
     peak = round(PEAK_TFLOPS[math], 1)
-    traffic_all, traffic_dominant = pmc_traffic(math)
+    traffic_all, traffic_per_kernel, traffic_source = pmc_traffic(math, workload, *geom)
+    # algorithmic (compulsory) bytes per launch of each kernel instantiation, next to its measured traffic
+    per_inst = {}
+    for name, (cnt, by) in inst.items():
+        per_inst[name] = {"launches_per_step": cnt // steps, "algorithmic_bytes_per_launch": round(by / cnt),
+                          "traffic": (traffic_per_kernel or {}).get(name)}
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
-            "traffic": traffic_all, "traffic_dominant_kernel": traffic_dominant,
+            "traffic": traffic_all, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": round(nbytes / max(launches, 1)),
+            "by_instantiation": per_inst,
             "kernel": KERNEL_LABEL[math], "conv_math": math,
             "launches_per_step": launches // steps,
             # executed = 2*M*N*K of the launches actually made (the pyramid bottleneck is applied per level at the
@@ -144,30 +158,64 @@ def measure_conv_roofline(step_fn, steps, workload, scale=1.0):
             "by_kind": detail}
 
 
-def pmc_traffic(math):
-    """HBM bytes per conv-kernel launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE,
-    separate runs of this same benchmark, FETCH_SIZE doubled per MI355X_MICROARCH.md; tools/pmc_aggregate.py): counters
-    cannot be collected from inside this process, so the figures are read from profiles/ and are null if absent.
-    Returns (mean over ALL conv-kernel launches -- the set `achieved` and `algorithmic_bytes_per_launch` are taken
-    over --, bytes per launch of the dominant instantiation alone)."""
-    name, kernel = {"f32": ("r01_pmc_hbm_traffic.json", "conv_igemm_kernel<2, 2, 4, 32>"),
-                    "bf16x3": ("r01_pmc_hbm_traffic_bf16x3.json", "conv_igemm_kernel<2, 2, 4, 32, 1>")}[math]
+def pmc_traffic(math, workload, batch, height, width):
+    """HBM bytes per conv-kernel launch from PMC passes of THIS benchmark (rocprofv3 --pmc FETCH_SIZE and --pmc
+    WRITE_SIZE, separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md; tools/pmc_aggregate.py).  Counters cannot be
+    collected from inside this process, so the figures come from profiles/pmc_traffic_<math>.json -- and ONLY when that
+    file's `_meta` says it was measured on the same workload, geometry, conv arithmetic and kernel generation
+    (hn_version) as this run; otherwise they are null.  `source` names the file and the commit it was measured at.
+    Returns (mean over ALL conv-kernel launches, per-instantiation {kernel: bytes per launch}, source)."""
+    from heatnet_amd import _lib
+    name = "pmc_traffic_%s.json" % math
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             data = json.load(f)
-        conv = [v for k, v in data.items() if k.startswith("conv_igemm_kernel") or k.startswith("conv_wgrad")]
-        ncalls = lambda v: v.get("calls", v.get("launches", 0))  # (the round-1 f32 file names the field "launches")
-        calls = sum(ncalls(v) for v in conv)
-        mean = sum(ncalls(v) * v["hbm_bytes_per_launch"] for v in conv) / calls
-        return round(mean), round(data[kernel]["hbm_bytes_per_launch"])
+        meta = data.pop("_meta")
+        want = {"workload": workload, "batch": batch, "height": height, "width": width, "conv_math": math,
+                "hn_version": _lib.load().hn_version()}
+        if any(meta.get(k) != v for k, v in want.items()):
+            return None, None, None
+        conv = {k: v for k, v in data.items() if k.startswith("conv_igemm_kernel") or k.startswith("conv_wgrad")}
+        calls = sum(v["calls"] for v in conv.values())
+        mean = sum(v["calls"] * v["hbm_bytes_per_launch"] for v in conv.values()) / calls
+        per = {k: round(v["hbm_bytes_per_launch"]) for k, v in conv.items()}
+        return round(mean), per, "profiles/%s @ %s" % (name, meta.get("commit", "?"))
     except (OSError, KeyError, ValueError, ZeroDivisionError):
-        return None, None
+        return None, None, None
+
+
+def host_cpu():
+    """(model name, physical cores) of this host from /proc/cpuinfo; falls back to the logical count."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    n = len(cores) or (os.cpu_count() or 1)
+    try:  # never more threads than this process may run on (cgroup / affinity limits of the box)
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    return model, n
 
 
 def cpu_baseline(workload):
     """The oracle on this host's cores: bs=1, 320x704, 1 warm-up + 2 timed steps (about 15-30 s of CPU work)."""
     from oracle import heatnet_ref as R
-    cores = torch.get_num_threads()
+    cpu_model, cores = host_cpu()
+    torch.set_num_threads(cores)  # one thread per physical core (SURVEY.md section 8d)
     torch.manual_seed(0)
     g = torch.Generator().manual_seed(99)
     rgb, ir = torch.randn(1, 3, H, W, generator=g).clamp_(-1, 1), torch.rand(1, 1, H, W, generator=g) * 2 - 1
@@ -194,9 +242,26 @@ def cpu_baseline(workload):
     for _ in range(n):
         step()
     dt = (time.time() - t0) / n
-    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "oracle/heatnet_ref.py, %s step at bs=1 320x704 fp32, 1 warm-up + %d timed steps, %.1f s/step"
-                      % (workload, n, dt)}
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+            "sample": "oracle/heatnet_ref.py, %s step at bs=1 320x704 fp32, %d threads (one per physical core), 1 warm-up "
+                      "+ %d timed steps, %.1f s/step" % (workload, cores, n, dt)}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` from a bare shell: start the N workers (one process per GPU) as a child
+    `torch.distributed.run`, which sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* for them.  This parent never
+    initialises the GPU (it only spawns -- no exec from a process that touched HIP); the workers' stdout (rank 0's JSON
+    line) and stderr pass straight through, and a worker failure is this process's exit code."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -213,13 +278,13 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the second timing under the other conv arithmetic")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))  # nothing has touched the GPU yet in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     # rehearsal knobs for a 1-GPU box (never set by the driver): every rank on one device, gloo instead of RCCL
     if os.environ.get("HN_BENCH_SHARE_GPU"):
         local = 0
@@ -233,6 +298,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if os.environ.get("HN_BENCH_FAIL_RANK") == str(rank) and world > 1:
+        raise RuntimeError("HN_BENCH_FAIL_RANK: injected worker failure (tests/test_gpu_bench_contract.py)")
     from heatnet_amd import ddp, optim
     model = build(args.workload, dev)
     if world > 1:
@@ -271,7 +338,8 @@ def main():
         # every rank runs the instrumented steps (a step contains the gradient all-reduce); only rank 0 records events
         nprof = max(1, min(3, args.steps))
         if rank == 0:
-            roof = measure_conv_roofline(step, nprof, args.workload, scale=scale)
+            roof = measure_conv_roofline(step, nprof, args.workload, scale=scale,
+                                         geom=(args.batch, args.height, args.width))
         else:
             for _ in range(nprof):
                 step()
@@ -296,7 +364,8 @@ def main():
             alt_elapsed = time.perf_counter() - t1
             alt_roof = None
             if not args.no_roofline:
-                r = measure_conv_roofline(step, max(1, min(3, args.steps)), args.workload, scale=scale)
+                r = measure_conv_roofline(step, max(1, min(3, args.steps)), args.workload, scale=scale,
+                                          geom=(args.batch, args.height, args.width))
                 alt_roof = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "conv_ms_per_step", "kernel")}
             alt = {"conv_math": other, "value": round(args.batch * args.steps / alt_elapsed, 3), "unit": "images/s",
                    "ms_per_step": round(1e3 * alt_elapsed / args.steps, 3), "steps": args.steps, "roofline": alt_roof}
@@ -311,7 +380,7 @@ def main():
                         "backward + RMSprop",
                  "confmax_seg": "configs[2]: confusion-maximisation train_seg iteration (day+night passes, 6 critics)",
                  "confmax_critic": "configs[2]: confusion-maximisation train_critic iteration (day+night passes, 6 critics)"}
-        out = {"metric": "training images/s at 320x704 RGB+IR, bs=8/GPU", "value": round(world * args.batch * args.steps / elapsed, 3),
+        out = {"metric": "training images/s at %dx%d RGB+IR, bs=%d/GPU" % (args.height, args.width, args.batch), "value": round(world * args.batch * args.steps / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -18,18 +18,25 @@ import torch.distributed as dist
 
 class GradBuckets:
     """`params`: the buckets allocate their own flat gradient storage.  `arenas` (optim.ParamArena): the buckets are
-    contiguous slices of the arenas' flat gradient buffers -- the optimizer then reads the reduced gradients in place."""
+    contiguous slices of the arenas' flat gradient buffers -- the optimizer then reads the reduced gradients in place.
+
+    Training phases (conv_segnet.setPhase flips `requires_grad` between the segmentation net and the critics every
+    50 / 500 iterations, cm/train_trgb_segnet_conf.py:577-592): buckets and hooks are built ONCE for every arena, and
+    `begin_step()` arms exactly the buckets whose arena takes part in the current phase -- nothing has to be rebuilt
+    at a phase switch, and a frozen arena's stale gradients are never exchanged.  With plain `params` there is one
+    fixed set: `begin_step()` raises if the set of trainable parameters no longer matches it."""
 
     def __init__(self, params=None, bucket_bytes=64 << 20, process_group=None, average=True, arenas=None):
         self.group = process_group
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.buckets = []  # dicts: flat, params, pending, work
+        self.arenas = list(arenas) if arenas is not None else None
         if arenas is not None:
-            arenas = [a for a in arenas if a.active()]
             self.params = [p for a in arenas for p in a.params]
         else:
-            self.params = [p for p in params if p.requires_grad]
+            self._all_params = list(params)
+            self.params = [p for p in self._all_params if p.requires_grad]
         if not self.params:
             raise ValueError("GradBuckets: no trainable parameters")
         self.device = self.params[0].device
@@ -42,10 +49,10 @@ class GradBuckets:
                 for p, end in zip(a.params, ends):
                     cur.append(p)
                     if (end - start) * 4 >= bucket_bytes:
-                        self._adopt(a.grad[start:end], cur)
+                        self._adopt(a.grad[start:end], cur, a)
                         start, cur = end, []
                 if cur:
-                    self._adopt(a.grad[start:a.numel], cur)
+                    self._adopt(a.grad[start:a.numel], cur, a)
         else:
             order = list(reversed(self.params))  # backward reaches the last-registered parameters first
             cur, cur_bytes = [], 0
@@ -61,12 +68,20 @@ class GradBuckets:
         self._index = {}
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
-                self._index[p] = bi
+                self._index[id(p)] = bi
+                # hooks can only be registered on parameters that require grad: flip a frozen phase's parameters for
+                # the registration (as optim.ParamArena does)
+                frozen = not p.requires_grad
+                if frozen:
+                    p.requires_grad_(True)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                if frozen:
+                    p.requires_grad_(False)
         self._active = False
 
-    def _adopt(self, flat, plist):
-        self.buckets.append({"flat": flat, "params": list(plist), "pending": 0, "work": None})
+    def _adopt(self, flat, plist, arena):
+        self.buckets.append({"flat": flat, "params": list(plist), "pending": 0, "work": None, "arena": arena,
+                             "armed": False})
 
     def _seal(self, plist):
         n = sum(p.numel() for p in plist)
@@ -77,26 +92,53 @@ class GradBuckets:
             view = flat[off:off + p.numel()].as_strided(p.size(), p.stride())
             p.grad = view
             off += p.numel()
-        self.buckets.append({"flat": flat, "params": list(plist), "pending": 0, "work": None})
+        self.buckets.append({"flat": flat, "params": list(plist), "pending": 0, "work": None, "arena": None,
+                             "armed": False})
 
     # -- per-step protocol -------------------------------------------------------------------------------
     def begin_step(self):
-        """Call after optimizer.zero_grad(set_to_none=False): re-arms the arrival counters."""
+        """Call after optimizer.zero_grad(set_to_none=False): arms the arrival counters of the buckets that take part in
+        the current training phase."""
+        if self.arenas is None:
+            for p in self._all_params:
+                if p.requires_grad and id(p) not in self._index:
+                    raise RuntimeError("GradBuckets: a parameter became trainable after the buckets were built (build "
+                                       "them from optim arenas, or rebuild them at a phase switch)")
+        any_armed = False
         for b in self.buckets:
-            b["pending"] = len(b["params"])
+            a = b["arena"]
             b["work"] = None
+            if a is not None:
+                state = [p.requires_grad for p in b["params"]]
+                if any(state) != all(state) or state[0] != a.active():
+                    raise RuntimeError("GradBuckets: requires_grad differs inside one arena (phases are per arena)")
+                b["armed"] = a.active()
+            else:
+                if not all(p.requires_grad for p in b["params"]):
+                    raise RuntimeError("GradBuckets: a bucketed parameter was frozen (build the buckets from optim "
+                                       "arenas, or rebuild them at a phase switch)")
+                b["armed"] = True
+            if not b["armed"]:
+                b["pending"] = -1
+                continue
+            any_armed = True
+            b["pending"] = len(b["params"])
             for p in b["params"]:
                 if p.grad is None and hasattr(p, "_hn_grad_slot"):
                     continue  # arena parameter after zero_grad(): backward re-attaches a view of its slot
                 if p.grad is None or p.grad.data_ptr() < b["flat"].data_ptr() or \
                         p.grad.data_ptr() >= b["flat"].data_ptr() + b["flat"].numel() * 4:
                     raise RuntimeError("GradBuckets: a gradient left its bucket (use zero_grad(set_to_none=False))")
+        if not any_armed:
+            raise RuntimeError("GradBuckets: no trainable parameters in this phase")
         self._active = True
 
     def _on_grad(self, p):
         if not self._active:
             return
-        b = self.buckets[self._index[p]]
+        b = self.buckets[self._index[id(p)]]
+        if not b["armed"]:
+            raise RuntimeError("GradBuckets: a gradient arrived for a parameter of a frozen phase")
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch(b)
@@ -122,7 +164,7 @@ class GradBuckets:
         the compute stream wait for every collective before the optimizer reads the gradients."""
         self._active = False
         for b in self.buckets:
-            if b["pending"] != 0 and b["work"] is None:
+            if b["armed"] and b["pending"] != 0 and b["work"] is None:
                 b["pending"] = 0
                 self._launch(b)
         for b in self.buckets:

@@ -194,6 +194,7 @@ class frozen_weights:
         global _frozen_depth, _frozen_scope
         if _frozen_depth == 0:
             _frozen_scope += 1
+            _prep_registry.new_scope()
         _frozen_depth += 1
         return self
 
@@ -220,24 +221,34 @@ class _WeightPrepRegistry:
         self.signature = None  # what the device table was built for
         self.table = None
         self.n = self.blocks = 0
+        # scope ids are not consecutive (weights_changed() -- every optimizer step -- bumps them too): remember which
+        # id the layers of the previous frozen_weights() scope were touched under
+        self.prev_touch = self.cur_touch = None
+
+    def new_scope(self):
+        if self.cur_touch is not None:
+            self.prev_touch, self.cur_touch = self.cur_touch, None
 
     def touch(self, leaf, geom, wx3, wt, wtx3):
         key = (id(leaf),) + geom
         e = self.entries.get(key)
         if e is None or e["ref"]() is not leaf or e["wx3"] is not wx3:
             e = self.entries[key] = dict(ref=weakref.ref(leaf), geom=geom, wx3=wx3, wt=wt, wtx3=wtx3)
-        e["last_scope"] = _frozen_scope
+        e["last_scope"] = self.cur_touch = _frozen_scope
 
     def run(self):
         dead = [k for k, e in self.entries.items() if e["ref"]() is None]
         for k in dead:
             del self.entries[k]
-        live = [(e["ref"](), e) for e in self.entries.values() if e["last_scope"] == _frozen_scope - 1]
+        if self.prev_touch is None:
+            return
+        live = [(e["ref"](), e) for e in self.entries.values() if e["last_scope"] == self.prev_touch]
         live = [(w, e) for w, e in live if w is not None and w.is_cuda]
         if not live:
             return
         lib = _lib.load()
-        sig = tuple((w.data_ptr(), e["geom"], e["wx3"].data_ptr()) for w, e in live)
+        sig = tuple((w.data_ptr(), e["geom"], e["wx3"].data_ptr(), e["wt"].data_ptr() if e["wt"] is not None else 0,
+                     e["wtx3"].data_ptr() if e["wtx3"] is not None else 0) for w, e in live)
         if sig != self.signature:  # first use, parameters re-homed (arena), or another set of layers (phase switch)
             items = (HnWeightPrepItem * len(live))()
             for it, (w, e) in zip(items, live):
@@ -256,7 +267,7 @@ class _WeightPrepRegistry:
         check(lib.hn_weight_prepare_batch(_ptr(self.table), self.n, self.blocks, _stream()), "hn_weight_prepare_batch")
         for w, e in live:
             w._hn_prep = ((w.data_ptr(), w._version, _frozen_scope) + e["geom"], e["wx3"], e["wt"], e["wtx3"])
-            e["last_scope"] = _frozen_scope
+            e["last_scope"] = self.cur_touch = _frozen_scope
 
 
 _prep_registry = _WeightPrepRegistry()
@@ -359,6 +370,16 @@ def _side_stream(device):
 # adopts that tensor as `.grad` without a copy or an add.  A further contribution in the same step (a layer applied
 # twice: day and night passes) is ADDED into the slot by the kernel itself and reported to autograd as "no gradient"
 # (None): the leaf's AccumulateGrad -- and any hook on it -- still runs once, after all of its uses.
+#
+# "First use" is decided per BACKWARD CALL, not from `_hn_slot_used` alone: the flag is reset only by the arena's own
+# zero_grad(), and gradients can be dropped in other ways (nn.Module.zero_grad() sets `.grad = None` in torch >= 2,
+# `p.grad = None`, an exception in the middle of a backward).  The slot remembers the autograd graph-task id of the
+# backward that claimed it: a later use inside the SAME backward adds; a use from ANOTHER backward that finds `.grad`
+# gone means the slot holds a dropped gradient -- it is cleared and claimed afresh instead of being added to.
+def _graph_task():
+    return torch._C._current_graph_task_id()
+
+
 def grad_slot(param, accumulate_ok=True):
     """(view, first) for `param`'s arena gradient slot -- `first`: the slot is empty (zero) and the caller's result
     becomes the gradient; not first: the caller must add into it -- or None when there is no slot to use."""
@@ -367,10 +388,15 @@ def grad_slot(param, accumulate_ok=True):
         return None
     flat, off = slot
     view = flat[off:off + param.numel()].as_strided(param.size(), param.stride())
-    if not getattr(param, "_hn_slot_used", False) and param.grad is None:
+    task = _graph_task()
+    used = getattr(param, "_hn_slot_used", False)
+    if param.grad is None and (not used or getattr(param, "_hn_slot_task", None) != task):
+        if used:  # gradient dropped behind the arena's back: the slot still holds it
+            flat[off:off + param.numel()].zero_()
         param._hn_slot_used = True  # reset by the optimizer's zero_grad()
+        param._hn_slot_task = task
         return view, True
-    if accumulate_ok and param._hn_slot_used and (param.grad is None or param.grad.data_ptr() == view.data_ptr()):
+    if accumulate_ok and used and (param.grad is None or param.grad.data_ptr() == view.data_ptr()):
         return view, False
     return None
 
@@ -390,10 +416,11 @@ def set_conv_profiler(records):
 class _ConvTimer:
     """HIP events on the launch stream (torch's current stream) around one conv-kernel launch."""
 
-    def __init__(self, kind, d):
+    def __init__(self, kind, d, kname=None):
         self.on = _conv_prof is not None
         if self.on:
             self.kind = kind
+            self.kname = kname() if callable(kname) else (kname or kind)
             self.flops = 2.0 * d.N * d.Hout * d.Wout * d.Cout * d.KH * d.KW * d.Cin
             self.shape = (d.N, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.Cout, d.KH, d.stride, d.dil)
             # compulsory HBM traffic: each of the three tensors of the convolution touched once
@@ -407,7 +434,7 @@ class _ConvTimer:
     def __exit__(self, *exc):
         if self.on:
             self.e1.record()
-            _conv_prof.append((self.kind, self.flops, self.e0, self.e1, self.shape, self.bytes))
+            _conv_prof.append((self.kind, self.flops, self.e0, self.e1, self.shape, self.bytes, self.kname))
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -97,6 +97,12 @@ class ParamArena:
             if g is not None and g.data_ptr() != base + 4 * off:
                 raise RuntimeError("ParamArena: a gradient left the arena (a foreign zero_grad(set_to_none=True), or a "
                                    "gradient tensor autograd could not adopt in place)")
+            if g is None and p._hn_slot_used:
+                # a backward kernel wrote this slot, but the parameter's `.grad` was dropped afterwards (e.g.
+                # nn.Module.zero_grad() between backward and step): stepping now would apply a gradient the caller
+                # believes cleared
+                raise RuntimeError("ParamArena: a parameter's gradient was dropped after backward wrote its arena slot "
+                                   "(clear gradients with the optimizer's zero_grad(), before the forward pass)")
 
 
 class _FlatOptimizer(torch.optim.Optimizer):
@@ -192,6 +198,7 @@ class FlatRMSprop(_FlatOptimizer):
             self.steps[i] += 1
             a.check()
             ops.rmsprop_step_(a.flat, a.grad, sq, g["lr"], g["alpha"], g["eps"], g["weight_decay"])
+        ops.weights_changed()  # the update goes through raw pointers (no version bump): drop prepared weight operands
 
 
 class FlatAdam(_FlatOptimizer):
@@ -213,6 +220,7 @@ class FlatAdam(_FlatOptimizer):
             self.steps[i] += 1
             ops.adam_step_(a.flat, a.grad, self.exp_avg[i], self.exp_avg_sq[i], self.steps[i], g["lr"], g["betas"][0],
                            g["betas"][1], g["eps"], g["weight_decay"])
+        ops.weights_changed()  # see FlatRMSprop.step
 
 
 def arenas_for(model):

@@ -120,3 +120,98 @@ def test_grad_buckets_single_process_is_a_no_op():
     with pytest.raises(RuntimeError, match="left its bucket"):
         opt.zero_grad(set_to_none=True)
         b.begin_step()
+
+
+# ---- phase switches (conv_segnet.setPhase flips requires_grad between two parameter sets) --------------------------------
+
+def _phase_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from heatnet_amd import ddp, optim
+    m = _model()
+    seg, critic = list(m.body[0].parameters()) + list(m.body[2].parameters()), list(m.body[4].parameters())
+    for p in m.unused.parameters():
+        p.requires_grad = False
+
+    def set_phase(phase):
+        for p in seg:
+            p.requires_grad = phase == "seg"
+        for p in critic:
+            p.requires_grad = phase == "critic"
+
+    set_phase("critic")
+    arenas = [optim.ParamArena(seg), optim.ParamArena(critic)]
+    buckets = ddp.GradBuckets(arenas=arenas, bucket_bytes=256)  # built once, while `seg` is frozen
+    g = torch.Generator().manual_seed(100 + rank)
+    errs, frozen_moved = [], []
+    for phase in ("critic", "seg", "critic", "seg"):
+        set_phase(phase)
+        x = torch.randn(4, 3, 6, 6, generator=g)
+        y = torch.randn(4, 5, generator=g)
+        active = arenas[0] if phase == "seg" else arenas[1]
+        frozen = arenas[1] if phase == "seg" else arenas[0]
+        ref = _model()
+        ref.load_state_dict(m.state_dict())
+        ((ref(x) - y) ** 2).mean().backward()
+        ref_params = (list(ref.body[0].parameters()) + list(ref.body[2].parameters())) if phase == "seg" \
+            else list(ref.body[4].parameters())
+        expected = []
+        for p in ref_params:
+            gl = p.grad.clone()
+            dist.all_reduce(gl)
+            expected.append(gl / world)
+        before = frozen.grad.clone()
+        for a in arenas:
+            if a.active():
+                a.zero_grad()
+        buckets.begin_step()
+        ((m(x) - y) ** 2).mean().backward()
+        buckets.finish_step()
+        for p, e in zip(active.params, expected):
+            errs.append(float((active.grad_view(p) - e).abs().max()))
+        frozen_moved.append(float((frozen.grad - before).abs().max()))
+        with torch.no_grad():
+            active.flat.sub_(0.1 * active.grad)
+    flat = torch.cat([a.flat for a in arenas])
+    other = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    ret[rank] = (max(errs), max(frozen_moved), float((other[0] - other[1]).abs().max()))
+    dist.destroy_process_group()
+
+
+def test_grad_buckets_follow_phase_switches():
+    """Buckets are built once for every arena; each step exchanges exactly the arena that is trainable in that phase
+    (after setPhase the newly active arena was never all-reduced and the frozen one's stale gradients were)."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_phase_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for rank in range(world):
+        err, moved, drift = ret[rank]
+        assert err < 1e-6, err
+        assert moved == 0.0      # a frozen arena's gradient buffer is neither reduced nor scaled
+        assert drift == 0.0      # replicas stay identical through the switches
+
+
+def test_param_buckets_refuse_a_changed_trainable_set():
+    sys.path.insert(0, ROOT)
+    from heatnet_amd import ddp
+    m = _model()
+    for p in m.unused.parameters():
+        p.requires_grad = False
+    b = ddp.GradBuckets(list(m.parameters()))
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    opt.zero_grad(set_to_none=False)
+    b.begin_step()
+    m(torch.randn(2, 3, 6, 6)).sum().backward()
+    b.finish_step()
+    for p in m.unused.parameters():
+        p.requires_grad = True  # a phase switch the fixed bucket set does not cover
+    with pytest.raises(RuntimeError, match="became trainable"):
+        b.begin_step()
+    for p in m.unused.parameters():
+        p.requires_grad = False
+    m.body[0].weight.requires_grad = False
+    with pytest.raises(RuntimeError, match="was frozen"):
+        b.begin_step()

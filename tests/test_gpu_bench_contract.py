@@ -36,3 +36,32 @@ def test_bench_prints_one_contract_line():
     assert j["cpu_baseline"] is None  # --no-cpu-baseline
     alt = j["alt_conv_math"]
     assert alt["conv_math"] in ("f32", "bf16x3") and alt["conv_math"] != r["conv_math"] and alt["value"] > 0
+
+
+def test_bench_self_launches_its_workers():
+    """`python bench.py --gpus 2` from a bare shell (no torchrun environment) must start its own workers before touching
+    the GPU, print rank 0's line and exit 0.  Rehearsed on the one GPU: both ranks share it and talk over gloo."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HN_BENCH_SHARE_GPU="1", HN_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "1", "--height", "256", "--width", "256", "--workload", "confmax_seg"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 2 and j["config"]["parallelism"] == "dp2"
+    assert j["value"] > 0 and j["scaling"] == "weak"
+
+
+def test_bench_worker_failure_is_reported():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HN_BENCH_SHARE_GPU="1", HN_BENCH_BACKEND="gloo", HN_BENCH_FAIL_RANK="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--batch", "2", "--height", "128", "--width", "256", "--no-roofline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode != 0

@@ -116,3 +116,185 @@ def test_two_ranks_on_one_gpu_match_single_process():
     scale = float(last.abs().max())
     assert float((g0 - last).abs().max()) <= 2e-5 * scale, float((g0 - last).abs().max()) / scale
     assert float((w0 - arenas[0].flat.detach().cpu()).abs().max()) <= 1e-4
+
+
+# ---- confusion-maximisation pattern under data parallelism (BASELINE configs[3]) ----------------------------------------
+# The segmentation net is applied TWICE per iteration (day and night batches: the second use of every layer adds into its
+# gradient slot in place and reports no gradient of its own, ops.grad_slot) and the trainable half of the model changes
+# with the phase (conv_segnet.setPhase, cm/models/conf_segnet.py:86-104; cm/train_trgb_segnet_conf.py:577-592).
+
+def _build_conf():
+    sys.path.insert(0, ROOT)
+    import torch.nn as nn
+    from heatnet_amd import ops
+    from heatnet_amd.layers import HnBatchNorm2d, HnConv2d, conv_bn_act
+
+    class Seg(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1, self.b1 = HnConv2d(32, 64, 3, padding=1, bias=False), HnBatchNorm2d(64)
+            self.c2, self.b2 = HnConv2d(64, 32, 1, bias=True), HnBatchNorm2d(32)
+            self.head = HnConv2d(32, 5, 1, bias=True)
+
+        def forward(self, x):
+            z1 = conv_bn_act(x, self.c1, self.b1, ops.ACT_RELU)
+            z2 = conv_bn_act(z1, self.c2, self.b2, ops.ACT_RELU)
+            out = self.head(z2)
+            return out, [out, z1], None
+
+    class Critic(nn.Module):
+        def __init__(self, cin):
+            super().__init__()
+            self.conv1 = HnConv2d(cin, 32, 4, stride=2, padding=1)
+            self.classifier = HnConv2d(32, 1, 4, stride=2, padding=1)
+
+        def forward(self, x):
+            x = self.classifier(self.conv1(x, act=ops.ACT_LEAKY, slope=0.2))
+            return ops.bilinear(x, (4 * x.size(2), 4 * x.size(3)))
+
+    class Conf(nn.Module):  # the slice of conv_segnet the trainer touches
+        def __init__(self):
+            super().__init__()
+            self.trgb_segnet = Seg()
+            self.critics = nn.ModuleList([Critic(5), Critic(64)])
+
+        def setPhase(self, phase):
+            seg = phase == "train_seg"
+            for p in self.critics.parameters():
+                p.requires_grad = not seg
+            for p in self.trgb_segnet.parameters():
+                p.requires_grad = seg
+
+        def forward(self, a, b):
+            la, fa, _ = self.trgb_segnet(*a)
+            lb, fb, _ = self.trgb_segnet(*b)
+            return {"critics_a": [c(fa[i]) for i, c in enumerate(self.critics)],
+                    "critics_b": [c(fb[i]) for i, c in enumerate(self.critics)],
+                    "pred_label_a": la, "pred_label_b": lb}
+
+    torch.manual_seed(0)
+    return Conf()
+
+
+_PHASES = ["train_critic", "train_seg", "train_seg", "train_critic"]
+
+
+def _conf_data(rank, dev):
+    g = torch.Generator().manual_seed(200 + rank)
+    mk = lambda: torch.randn(2, 32, 16, 16, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    return mk(), mk(), torch.randint(0, 5, (2, 16, 16), generator=g).to(dev)
+
+
+def _conf_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from heatnet_amd import ddp, optim, train_step
+    dev = torch.device("cuda:0")
+    model = _build_conf().to(dev).train()
+    ddp.broadcast_module_state(model)
+    model.setPhase(_PHASES[0])
+    arenas = optim.arenas_for(model)                 # [segmentation net, critics]
+    opt = optim.FlatRMSprop(arenas, lr=1e-3)
+    buckets = ddp.GradBuckets(arenas=arenas, bucket_bytes=16 << 10)  # built ONCE, for both phases
+    day, night, lab = _conf_data(rank, dev)
+    out = []
+    for phase in _PHASES:
+        model.setPhase(phase)
+        train_step.train_step(model, opt, [day], [night], lab, phase, adv="MSE", grad_sync=buckets)
+        out.append([a.flat.detach().cpu().clone() for a in arenas])
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_confmax_phases_two_ranks_match_single_process():
+    """Layer reuse (day + night) + phase switches + bucket hooks: both ranks stay bit-identical and follow the
+    single-process trajectory that averages the two ranks' gradients."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_conf_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    r0, r1 = ret[0], ret[1]
+    for s0, s1 in zip(r0, r1):
+        for a0, a1 in zip(s0, s1):
+            assert torch.equal(a0, a1)
+    sys.path.insert(0, ROOT)
+    from heatnet_amd import optim, train_step
+    dev = torch.device("cuda:0")
+    model = _build_conf().to(dev).train()
+    model.setPhase(_PHASES[0])
+    arenas = optim.arenas_for(model)
+    opt = optim.FlatRMSprop(arenas, lr=1e-3)
+    data = [_conf_data(r, dev) for r in range(2)]
+
+    class Capture:  # grad_sync stand-in: snapshot this "rank"'s gradients instead of exchanging them
+        def __init__(self):
+            self.grads = []
+
+        def begin_step(self):
+            pass
+
+        def finish_step(self):
+            self.grads.append([a.grad.detach().clone() for a in arenas])
+
+    class NoStep:  # the optimizer interface train_step drives, without the update
+        def zero_grad(self, set_to_none=False):
+            opt.zero_grad()
+
+        def step(self):
+            pass
+
+    for it, phase in enumerate(_PHASES):
+        model.setPhase(phase)
+        cap = Capture()
+        for day, night, lab in data:
+            train_step.train_step(model, NoStep(), [day], [night], lab, phase, adv="MSE", grad_sync=cap)
+        active = 0 if phase == "train_seg" else 1
+        opt.zero_grad()
+        for p in arenas[active].params:
+            p.grad = arenas[active].grad_view(p)
+            p._hn_slot_used = True
+        arenas[active].grad.copy_((cap.grads[0][active] + cap.grads[1][active]) / 2)
+        opt.step()
+        for k in range(2):
+            ref = arenas[k].flat.detach().cpu()
+            err = float((r0[it][k] - ref).abs().max())
+            assert err <= 1e-4, (it, phase, k, err)
+        # the frozen arena's weights did not move in this iteration
+        if it > 0:
+            assert torch.equal(r0[it][1 - active], r0[it - 1][1 - active])
+
+
+def test_foreign_zero_grad_does_not_accumulate_stale_gradients():
+    """nn.Module.zero_grad() (set_to_none) instead of the arena optimizer's: the next backward must start from an empty
+    slot, not add to the previous step's contents (ops.grad_slot keyed only on `_hn_slot_used`)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    sys.path.insert(0, ROOT)
+    from heatnet_amd import optim, train_step
+    dev = torch.device("cuda:0")
+    net = _build().to(dev).train()
+    arenas = optim.arenas_for(net)
+    x, lab = _data(0)
+    x = x.to(dev).contiguous(memory_format=torch.channels_last)
+    grads = []
+    for _ in range(2):
+        net.zero_grad()  # torch >= 2: p.grad = None, arena not cleared
+        train_step.segmentation_loss(net(x), lab.to(dev)).backward()
+        grads.append(arenas[0].grad.detach().clone())
+        arenas[0].check()
+    scale = float(grads[0].abs().max())
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * scale  # same inputs, same weights: same gradient, not 2x
+    # dropping gradients AFTER backward and then stepping is refused
+    opt = optim.FlatRMSprop(arenas, lr=1e-3)
+    net.zero_grad()
+    with pytest.raises(RuntimeError, match="dropped after backward"):
+        opt.step()
