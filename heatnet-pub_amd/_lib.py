@@ -34,6 +34,7 @@ SIGNATURES = {
     "hn_weight_flip_transpose": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_conv2d_dgrad": [P, P, P, P, P, c_int, DP, c_int, P],
     "hn_conv2d_wgrad": [P, P, P, DP, c_int, c_int, c_int, P],
+    "hn_conv2d_wgrad_det": [P, P, P, DP, c_int, c_int, c_int, P, P],
     "hn_channel_sum": [P, c_int, c_i64, c_int, P, P],
     "hn_channel_stats": [P, c_int, c_i64, c_int, P, P],
     "hn_bn_finalize": [P, c_i64, P, P, P, P, c_float, c_float, P, P, P, P, c_int, P],
@@ -60,6 +61,10 @@ SIGNATURES = {
     "hn_thermal_augment": [P, P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P, P],
     "hn_set_conv_math": [c_int],
     "hn_get_conv_math": [],
+    "hn_set_deterministic": [c_int],
+    "hn_get_deterministic": [],
+    "hn_conv2d_fwd_affine": [P, P, P, P, P, P, P, P, DP, c_int, P],
+    "hn_conv2d_plan": [c_int, DP, c_int, c_int, ctypes.c_char_p, c_int],
     "hn_pyramid_pool_bwd": [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "hn_ce_fwd": [P, c_int, P, c_i64, c_int, c_i64, P, P],
     "hn_ce_bwd": [P, c_int, P, c_i64, c_int, c_i64, P, P, P, c_int, P],
@@ -97,6 +102,8 @@ def load():
     lib.hn_weight_prep_table_bytes.restype = ctypes.c_size_t
     lib.hn_version.argtypes = []
     lib.hn_version.restype = c_int
+    if os.environ.get("HEATNET_DETERMINISTIC", "0") == "1":
+        lib.hn_set_deterministic(1)  # ops.DETERMINISTIC mirrors this (no split-K float atomics)
     _lib = lib
     return lib
 

@@ -1,0 +1,270 @@
+// Shared by the implicit-GEMM convolution kernels (conv_igemm.hip: fp32-MFMA and the first bf16x3 schedule;
+// conv_igemm2.hip: the one-wave-per-SIMD software-pipelined schedule for bf16x3 and plain bf16).
+#pragma once
+#include <type_traits>
+
+#include "hn_common.h"
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+
+namespace hnconv {
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    double* stats;
+    const float* addend;     // optional tensor added to the output (gradient of a branch that by-passed this conv)
+    int ldadd;
+    int H, W, C, ldx;        // input tensor
+    int Ho, Wo, K, ldy;      // output tensor (K = output channels)
+    int KH, KW, stride, pad, pad_w, dil, in_dil;  // pad = rows, pad_w = columns
+    // output mapping (parity classes of a stride-2 data gradient): output pixel (n, i, j) of this launch is pixel
+    // (n, ostep*i + oph, ostep*j + opw) of a tensor with oH x oW pixels per image; omap = 0 -> dense (identity)
+    int omap, oH, oW, ostep, oph, opw;
+    // split-K (launches with few output tiles but a long reduction): K steps per split, 0 = no split.  Split launches
+    // add into a pre-initialised output with global_atomic_add_f32 and leave bias / activation / statistics to a follow-up pass.
+    int cps;
+    int M, Kdim, ntm, ntn;
+    int gm;  // row tiles per group of the tile order (see the kernel)
+    int act;
+    float slope;
+    long long x_bytes;  // extent of the gathered tensor from p.x, for the buffer descriptors
+    // bf16x3 / bf16: the weight matrix pre-split into three bf16 planes (hn_split_bf16x3 / hn_weight_flip_transpose),
+    // plane p = wx3 + p * wx3_plane elements, each laid out exactly like the fp32 matrix `w`; plane 0 alone is the
+    // round-to-nearest bf16 weight of the plain bf16 arithmetic
+    const unsigned short* wx3;
+    long long wx3_plane;
+    // A-operand transform (forward only): the gathered tensor is the PRE-normalisation output of the producing
+    // convolution and the loader applies relu(x * in_scale[c] + in_shift[c]) on the fly (BatchNorm + ReLU of a layer
+    // whose only consumer is this convolution); taps that fall into the zero padding stay zero.  NULL = plain gather.
+    const float* in_scale;
+    const float* in_shift;
+};
+
+// bf16x3 LDS image: [split][row][32 k] bf16 with 80-byte rows (64 B of data + 16 B pad: 16 consecutive rows start in
+// 16 distinct 16-B slots of the 256-B bank row -> conflict-free ds_read_b128 of a lane's 8 consecutive k)
+constexpr int X3_ROW = 80;
+// ds_read_b128 is served in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, {32-35,44-47,52-59},
+// {36-43,48-51,60-63} (MI355X_MICROARCH.md, LDS): with the 16x16x32 operand map (lane -> row lane & 15, k group
+// lane >> 4) each group holds every row once, rows {0-3,12-15} at k group g and rows {4-11} at g ^ 1.  Storing the
+// 16-B k groups of rows 4-11 with their low index bit flipped makes all 16 lanes of a group address the same physical
+// position of 16 different rows: conflict-free with the 80-B row stride (measured before: SQ_LDS_BANK_CONFLICT = 50 %
+// of SQ_LDS_IDX_ACTIVE, profiles/r01_pmc_conv_igemm_bf16x3.txt).
+__device__ __forceinline__ int x3_kflip(int row) { return ((row >> 2) ^ (row >> 3)) & 1; }
+
+// exact three-way split of four consecutive-k fp32 values into packed bf16 (hi, mid, lo)
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 hh = (__bf16)v[e];
+        const float r = v[e] - (float)hh;  // exact
+        const __bf16 mm = (__bf16)r;
+        const float r2 = r - (float)mm;    // exact
+        h[e] = hh;
+        m[e] = mm;
+        l[e] = (__bf16)r2;
+    }
+}
+
+__device__ __forceinline__ bf16x4 round_bf16(const f32x4 v) {
+    bf16x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];  // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+    return h;
+}
+
+__device__ __forceinline__ f32x4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
+}
+
+
+// ---- accumulator <-> tile coordinates ----------------------------------------------------------------------------
+// A wave owns TM x TN blocks of 32x32 outputs; element r (0..15) of acc[i][j]:
+//   32x32 MFMA (S16 = false):  column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+//   16x16 MFMA (S16 = true):   registers 4s..4s+3 hold sub-block s = 2 * (row half) + (column half):
+//                              column = 16 * ((r >> 2) & 1) + (lane & 15), row = 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3)
+template <int TM, int TN, bool S16>
+struct AccMap {
+    static constexpr int NC = S16 ? 2 : 1;  // distinct columns a lane holds per 32-column block
+    int wm, wn, lane, n0;
+    __device__ __forceinline__ static int c2_of(int r) { return S16 ? (r >> 2) & 1 : 0; }
+    __device__ __forceinline__ int row(int i, int r) const {  // row inside the block tile
+        return (wm * TM + i) * 32 + (S16 ? 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+    }
+    __device__ __forceinline__ int col(int j, int c2) const {  // global output channel
+        return n0 + (wn * TN + j) * 32 + (S16 ? 16 * c2 + (lane & 15) : (lane & 31));
+    }
+};
+
+// Accumulators start at zero -- or at the addend (a gradient that reached this tensor through another branch): its
+// loads are issued ahead of the operand prologue and their latency disappears behind the first K steps, so the
+// epilogue stays a pure store loop.  The addend never overlaps the output (header contract).
+template <int TM, int TN, bool S16>
+__device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[TM][TN], const AccMap<TM, TN, S16>& am,
+                                              const int* rowinfo, int m0) {
+    if (p.addend != nullptr && p.cps == 0) {
+        const float* __restrict__ add = p.addend;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = am.row(i, r), col = am.col(j, am.c2_of(r));
+                    float v = 0.f;
+                    if (m0 + row < p.M && col < p.K) v = add[(size_t)rowinfo[row * 4 + 3] * p.ldadd + col];
+                    acc[i][j][r] = v;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+}
+
+// ---- epilogue: bias, batch-statistics partials, activation, store -------------------------------------------------
+// The bias is loaded unconditionally (clamped index) and folded in BEFORE any store is issued, and full tiles take a
+// branch-free path: a conditional load inside the store loop makes hipcc wait vmcnt(0) -- i.e. for the previous store --
+// in front of every store.
+template <int TM, int TN, bool S16>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], const AccMap<TM, TN, S16>& am,
+                                              const int* rowinfo, int m0, int tile_m, int split) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, NC = AccMap<TM, TN, S16>::NC;
+    const int lane = am.lane, n0 = am.n0;
+    if (p.cps > 0) {  // split-K partial
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {  // accumulate into the pre-initialised output
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + am.row(i, r), col = am.col(j, am.c2_of(r));
+                    if (row < p.M && col < p.K) {
+                        const size_t opix = p.omap ? (size_t)rowinfo[(row - m0) * 4 + 3] : (size_t)row;
+                        atomicAdd(p.y + opix * p.ldy + col, acc[i][j][r]);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.K);
+    float bias_v[TN][NC];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int c2 = 0; c2 < NC; ++c2) bias_v[j][c2] = p.bias != nullptr ? p.bias[min(am.col(j, c2), p.K - 1)] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += bias_v[j][am.c2_of(r)];
+
+    // branch-free activation: out = v > 0 ? v : v * neg_slope  (none: 1, relu: 0, leaky/prelu: slope)
+    const float neg_slope = p.act == HN_ACT_NONE ? 1.f : (p.act == HN_ACT_RELU ? 0.f : p.slope);
+    auto finish = [&](auto full_tag, auto map_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        constexpr bool OMAP = decltype(map_tag)::value;  // rows land on interleaved pixels (rowinfo[.][3])
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int c2 = 0; c2 < NC; ++c2) {
+                const int col = am.col(j, c2);
+                const bool cok = FULL || col < p.K;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (am.c2_of(r) != c2) continue;
+                        const int row = m0 + am.row(i, r);
+                        const float v = acc[i][j][r];
+                        if (FULL || (row < p.M && cok)) {
+                            if constexpr (OMAP) {
+                                const size_t opix = (size_t)rowinfo[(row - m0) * 4 + 3];
+                                p.y[opix * p.ldy + col] = v;
+                            } else {
+                                s1 += v;
+                                s2 += v * v;
+                                p.y[(size_t)row * p.ldy + col] = v > 0.f ? v : v * neg_slope;
+                            }
+                        }
+                    }
+                }
+                if (p.stats != nullptr) {
+                    // <= 64 rows per lane were summed in fp32; everything across tiles is accumulated in double
+                    // (global_atomic_add_f64), like the double accumulators of the CPU reference's BatchNorm.
+                    double d1 = (double)s1, d2 = (double)s2;
+                    d1 += __shfl_xor(d1, 32);
+                    d2 += __shfl_xor(d2, 32);
+                    if constexpr (S16) {
+                        d1 += __shfl_xor(d1, 16);
+                        d2 += __shfl_xor(d2, 16);
+                    }
+                    if ((S16 ? (lane >> 4) : (lane >> 5)) == 0 && cok) {
+                        double* rep = p.stats + (size_t)(tile_m % HN_STAT_REPLICAS) * 2 * p.K;  // spread same-address atomics
+                        unsafeAtomicAdd(rep + col, d1);
+                        unsafeAtomicAdd(rep + p.K + col, d2);
+                    }
+                }
+            }
+        }
+    };
+    if (p.omap) {  // parity class of a strided data gradient (no activation / statistics on this path)
+        finish(std::false_type{}, std::true_type{});
+    } else if (full) {
+        finish(std::true_type{}, std::false_type{});
+    } else {
+        finish(std::false_type{}, std::false_type{});
+    }
+}
+
+// Tile order inside an XCD's contiguous range: groups of `gm` row tiles are walked column by column, so the ~64
+// workgroups an XCD runs at a time cover a gm x (64/gm) patch -- each A panel and each B panel in its L2 is shared
+// by several of them -- instead of a few rows across every column.  gm = 1: row-major.
+__device__ __forceinline__ void conv_tile_of(const ConvArgs& p, int tile, int& tile_m, int& tile_n) {
+    const int gm = p.gm, per_group = gm * p.ntn;
+    const int g = tile / per_group, in_g = tile - g * per_group;
+    const int first = g * gm, rows = min(gm, p.ntm - first);
+    tile_n = in_g / rows;
+    tile_m = first + (in_g - tile_n * rows);
+}
+
+// rowinfo[r] = {h base, w base, image pixel base, output pixel} of block-tile row r
+template <int BM>
+__device__ __forceinline__ void conv_fill_rowinfo(const ConvArgs& p, int* rowinfo, int m0, int tid) {
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        int hb = -0x40000000, wb = 0, nb = 0, opix = 0;  // rows past M: every tap lands out of range
+        if (m < p.M) {
+            const int hw = p.Ho * p.Wo;
+            const int n = m / hw, rem = m - n * hw;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            hb = ho * p.stride - p.pad;
+            wb = wo * p.stride - p.pad_w;
+            nb = n * p.H * p.W;
+            opix = p.omap ? (n * p.oH + p.ostep * ho + p.oph) * p.oW + p.ostep * wo + p.opw : m;
+        }
+        rowinfo[r * 4 + 0] = hb;
+        rowinfo[r * 4 + 1] = wb;
+        rowinfo[r * 4 + 2] = nb;
+        rowinfo[r * 4 + 3] = opix;
+    }
+}
+
+// conv_igemm2.hip
+enum : int { MATH2_X3 = 3, MATH2_BF16 = 1 };  // = number of bf16 planes per operand
+// runs the v2 schedule if it covers (tall, wide, ns); returns HN_OK / error, or 1 when it does not cover the request
+int launch_conv2(const ConvArgs& a, bool tall, bool wide, int ns, hipStream_t stream);
+const char* conv2_kernel_name(bool tall, bool wide, int ns);
+
+}  // namespace hnconv

@@ -23,12 +23,11 @@
 // the fp32 MFMA (profiles/r01_bf16x3_probe.txt: rms error 0.38-0.57 x 2^-24 of sum|products| vs 0.44-0.50) at 16/6
 // of its matrix-core rate.  Not a reduced-precision mode: nothing of the fp32 operands is dropped above 2^-24.
 #include <cstdlib>
+#include <cstdio>
+#include <cstring>
 #include <type_traits>
 
-#include "hn_common.h"
-
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
-typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+#include "conv_common.h"
 
 #ifdef HN_EXP_PIN
 #define HN_PIN() __builtin_amdgcn_sched_barrier(0)
@@ -49,68 +48,12 @@ struct KStep {
     static constexpr int SROWS = 256 / BK_;  // same, scalar path
 };
 
-struct ConvArgs {
-    const float* x;
-    const float* w;
-    const float* bias;
-    float* y;
-    double* stats;
-    const float* addend;     // optional tensor added to the output (gradient of a branch that by-passed this conv)
-    int ldadd;
-    int H, W, C, ldx;        // input tensor
-    int Ho, Wo, K, ldy;      // output tensor (K = output channels)
-    int KH, KW, stride, pad, pad_w, dil, in_dil;  // pad = rows, pad_w = columns
-    // output mapping (parity classes of a stride-2 data gradient): output pixel (n, i, j) of this launch is pixel
-    // (n, ostep*i + oph, ostep*j + opw) of a tensor with oH x oW pixels per image; omap = 0 -> dense (identity)
-    int omap, oH, oW, ostep, oph, opw;
-    // split-K (launches with few output tiles but a long reduction): K steps per split, 0 = no split.  Split launches
-    // add into a pre-initialised output with global_atomic_add_f32 and leave bias / activation / statistics to a
-    // follow-up pass.
-    int cps;
-    int M, Kdim, ntm, ntn;
-    int gm;  // row tiles per group of the tile order (see the kernel)
-    int act;
-    float slope;
-    long long x_bytes;  // extent of the gathered tensor from p.x, for the buffer descriptors
-    // bf16x3: the weight matrix pre-split into three bf16 planes (hn_split_bf16x3 / hn_weight_flip_transpose), plane p
-    // = wx3 + p * wx3_plane elements, each laid out exactly like the fp32 matrix `w`
-    const unsigned short* wx3;
-    long long wx3_plane;
-};
+using namespace hnconv;
 
 // Loader variants.  BUF fetches through buffer descriptors: one SGPR resource per tile, 32-bit byte offsets, and
 // out-of-range taps / rows are zero-filled by the hardware range check instead of by selects.
 enum : int { MODE_SCALAR = 0, MODE_SCALAR_STRIDED = 1, MODE_VEC = 2, MODE_VEC_STRIDED = 3, MODE_VEC_BUF = 4 };
 enum : int { MATH_F32 = 0, MATH_X3 = 1 };
-
-// bf16x3 LDS image: [split][row][32 k] bf16 with 80-byte rows (64 B of data + 16 B pad: 16 consecutive rows start in
-// 16 distinct 16-B slots of the 256-B bank row -> conflict-free ds_read_b128 of a lane's 8 consecutive k)
-constexpr int X3_ROW = 80;
-// ds_read_b128 is served in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, {32-35,44-47,52-59},
-// {36-43,48-51,60-63} (MI355X_MICROARCH.md, LDS): with the 16x16x32 operand map (lane -> row lane & 15, k group
-// lane >> 4) each group holds every row once, rows {0-3,12-15} at k group g and rows {4-11} at g ^ 1.  Storing the
-// 16-B k groups of rows 4-11 with their low index bit flipped makes all 16 lanes of a group address the same physical
-// position of 16 different rows: conflict-free with the 80-B row stride (measured before: SQ_LDS_BANK_CONFLICT = 50 %
-// of SQ_LDS_IDX_ACTIVE, profiles/r01_pmc_conv_igemm_bf16x3.txt).
-__device__ __forceinline__ int x3_kflip(int row) { return ((row >> 2) ^ (row >> 3)) & 1; }
-
-// exact three-way split of four consecutive-k fp32 values into packed bf16 (hi, mid, lo)
-__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const __bf16 hh = (__bf16)v[e];
-        const float r = v[e] - (float)hh;  // exact
-        const __bf16 mm = (__bf16)r;
-        const float r2 = r - (float)mm;    // exact
-        h[e] = hh;
-        m[e] = mm;
-        l[e] = (__bf16)r2;
-    }
-}
-
-__device__ __forceinline__ f32x4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
-}
 
 // STRIDED = the gathered tensor is "dilated" by in_dil > 1 (data gradient of a strided convolution): taps must
 // land on multiples of in_dil.  Kept out of the common instantiation because it costs integer divisions per tap.
@@ -134,36 +77,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     const int logical = hn_xcd_remap(blockIdx.x, gridDim.x);
     const int ntiles = p.ntm * p.ntn;
     const int split = logical / ntiles, tile = logical - split * ntiles;
-    // Tile order inside an XCD's contiguous range: groups of `gm` row tiles are walked column by column, so the ~64
-    // workgroups an XCD runs at a time cover a gm x (64/gm) patch -- each A panel and each B panel in its L2 is shared
-    // by several of them -- instead of a few rows across every column.  gm = 1: row-major.
     int tile_m, tile_n;
-    {
-        const int gm = p.gm, per_group = gm * p.ntn;
-        const int g = tile / per_group, in_g = tile - g * per_group;
-        const int first = g * gm, rows = min(gm, p.ntm - first);
-        tile_n = in_g / rows;
-        tile_m = first + (in_g - tile_n * rows);
-    }
+    conv_tile_of(p, tile, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    for (int r = tid; r < BM; r += 256) {
-        const int m = m0 + r;
-        int hb = -0x40000000, wb = 0, nb = 0, opix = 0;  // rows past M: every tap lands out of range
-        if (m < p.M) {
-            const int hw = p.Ho * p.Wo;
-            const int n = m / hw, rem = m - n * hw;
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            hb = ho * p.stride - p.pad;
-            wb = wo * p.stride - p.pad_w;
-            nb = n * p.H * p.W;
-            opix = p.omap ? (n * p.oH + p.ostep * ho + p.oph) * p.oW + p.ostep * wo + p.opw : m;
-        }
-        rowinfo[r * 4 + 0] = hb;
-        rowinfo[r * 4 + 1] = wb;
-        rowinfo[r * 4 + 2] = nb;
-        rowinfo[r * 4 + 3] = opix;
-    }
+    conv_fill_rowinfo<BM>(p, rowinfo, m0, tid);
     __syncthreads();
 
     // ---- operand staging -------------------------------------------------------------------------------
@@ -361,46 +278,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 
     // ---- main loop ---------------------------------------------------------------------------------------
     const int lr = lane & 31, lh = lane >> 5;
-    // Accumulators start at zero -- or at the addend (a gradient that reached this tensor through another branch): its
-    // loads are issued here, ahead of the operand prologue, and their latency disappears behind the first K steps, so
-    // the epilogue stays a pure store loop.  The addend never overlaps the output (header contract).
-    // Accumulator element r of acc[i][j] (a 32x32 block of the tile):
-    //   32x32 MFMA:  column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    //   16x16 MFMA:  registers 4s..4s+3 hold sub-block s = 2 * (row half) + (column half):
-    //                column = 16 * ((r >> 2) & 1) + (lane & 15), row = 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3)
-    // NC = distinct columns a lane holds per 32-column block; c2_of(r) = which of them element r belongs to.
-    constexpr int NC = S16 ? 2 : 1;
-    auto c2_of = [](int r) { return S16 ? (r >> 2) & 1 : 0; };
-    auto acc_row = [&](int i, int r) {  // row inside the block tile
-        return (wm * TM + i) * 32 + (S16 ? 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * lh);
-    };
-    auto acc_col = [&](int j, int c2) {  // global output channel
-        return n0 + (wn * TN + j) * 32 + (S16 ? 16 * c2 + (lane & 15) : lr);
-    };
+    const AccMap<TM, TN, S16> am{wm, wn, lane, n0};
     f32x16 acc[TM][TN];
-    if (p.addend != nullptr && p.cps == 0) {
-        const float* __restrict__ add = p.addend;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = acc_row(i, r), col = acc_col(j, c2_of(r));
-                    float v = 0.f;
-                    if (m0 + row < p.M && col < p.K) v = add[(size_t)rowinfo[row * 4 + 3] * p.ldadd + col];
-                    acc[i][j][r] = v;
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    }
+    conv_init_acc<TM, TN, S16>(p, acc, am, rowinfo, m0);
     const int total_chunks = (p.Kdim + BK - 1) / BK;
     const int kc_first = p.cps > 0 ? split * p.cps : 0;
     const int nchunks = p.cps > 0 ? min(p.cps, total_chunks - kc_first) : total_chunks;  // >= 1 by construction
@@ -548,98 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     k_step(kc & 1, std::false_type{}, std::false_type{});
     }
 
-    // ---- epilogue: bias, batch-statistics partials, activation, store -------------------------------------
-    // Accumulator map (32x32 MFMA): column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-    // The bias is loaded unconditionally (clamped index) and folded in BEFORE any store is issued, and full tiles
-    // take a branch-free path: a conditional load inside the store loop makes hipcc wait vmcnt(0) -- i.e. for the
-    // previous store -- in front of every store.
-    if (p.cps > 0) {  // split-K partial: accumulate into the pre-initialised output
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + acc_row(i, r), col = acc_col(j, c2_of(r));
-                    if (row < p.M && col < p.K) {
-                        const size_t opix = p.omap ? (size_t)rowinfo[(row - m0) * 4 + 3] : (size_t)row;
-                        atomicAdd(p.y + opix * p.ldy + col, acc[i][j][r]);
-                    }
-                }
-            }
-        }
-        return;
-    }
-    const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.K);
-    float bias_v[TN][NC];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int c2 = 0; c2 < NC; ++c2) bias_v[j][c2] = p.bias != nullptr ? p.bias[min(acc_col(j, c2), p.K - 1)] : 0.f;
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] += bias_v[j][c2_of(r)];
-
-    // branch-free activation: out = v > 0 ? v : v * neg_slope  (none: 1, relu: 0, leaky/prelu: slope)
-    const float neg_slope = p.act == HN_ACT_NONE ? 1.f : (p.act == HN_ACT_RELU ? 0.f : p.slope);
-    auto finish = [&](auto full_tag, auto map_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        constexpr bool OMAP = decltype(map_tag)::value;  // rows land on interleaved pixels (rowinfo[.][3])
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int c2 = 0; c2 < NC; ++c2) {
-                const int col = acc_col(j, c2);
-                const bool cok = FULL || col < p.K;
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if (c2_of(r) != c2) continue;
-                        const int row = m0 + acc_row(i, r);
-                        const float v = acc[i][j][r];
-                        if (FULL || (row < p.M && cok)) {
-                            if constexpr (OMAP) {
-                                const size_t opix = (size_t)rowinfo[(row - m0) * 4 + 3];
-                                p.y[opix * p.ldy + col] = v;
-                            } else {
-                                s1 += v;
-                                s2 += v * v;
-                                p.y[(size_t)row * p.ldy + col] = v > 0.f ? v : v * neg_slope;
-                            }
-                        }
-                    }
-                }
-                if (p.stats != nullptr) {
-                    // <= 64 rows per lane were summed in fp32; everything across tiles is accumulated in double
-                    // (global_atomic_add_f64), like the double accumulators of the CPU reference's BatchNorm.
-                    double d1 = (double)s1, d2 = (double)s2;
-                    d1 += __shfl_xor(d1, 32);
-                    d2 += __shfl_xor(d2, 32);
-                    if constexpr (S16) {
-                        d1 += __shfl_xor(d1, 16);
-                        d2 += __shfl_xor(d2, 16);
-                    }
-                    if ((S16 ? (lane >> 4) : lh) == 0 && cok) {
-                        double* rep = p.stats + (size_t)(tile_m % HN_STAT_REPLICAS) * 2 * p.K;  // spread same-address atomics
-                        unsafeAtomicAdd(rep + col, d1);
-                        unsafeAtomicAdd(rep + p.K + col, d2);
-                    }
-                }
-            }
-        }
-    };
-    if (p.omap) {  // parity class of a strided data gradient (no activation / statistics on this path)
-        finish(std::false_type{}, std::true_type{});
-    } else if (full) {
-        finish(std::true_type{}, std::false_type{});
-    } else {
-        finish(std::false_type{}, std::false_type{});
-    }
+    conv_epilogue<TM, TN, S16>(p, acc, am, rowinfo, m0, tile_m, split);
 }
 
 template <int TM, int TN, int MODE, int BK, int MATH = MATH_F32>
@@ -647,13 +436,9 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int lds = MATH != MATH_F32 ? 3 * (BM + BN) * X3_ROW + BM * 16
                                         : (2 * (BM + BN) * KStep<BK>::LDK + BM * 4) * (int)sizeof(float);
-    static bool configured = false;  // raising the dynamic-LDS cap is idempotent; the flag only saves calls
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<TM, TN, MODE, BK, MATH>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return HN_ELAUNCH;
-        configured = true;
-    }
+    static std::atomic<unsigned long long> configured{0};
+    if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_kernel<TM, TN, MODE, BK, MATH>), lds, configured) != HN_OK)
+        return HN_ELAUNCH;
     ConvArgs p = a;
     p.ntm = (a.M + BM - 1) / BM;
     p.ntn = (a.K + BN - 1) / BN;
@@ -679,14 +464,27 @@ int dispatch_tile(const ConvArgs& a, bool tall, bool wide, hipStream_t stream) {
     return wide ? launch_conv<1, 2, MODE, BK, MATH>(a, stream) : launch_conv<1, 1, MODE, BK, MATH>(a, stream);
 }
 
-int g_conv_math = MATH_F32;  // library default for variant codes that leave the math field 0 (hn_set_conv_math)
+bool g_deterministic = false;  // hn_set_deterministic: no split-K float atomics in these kernels
+int g_conv_math = 0;  // HN_MATH_* default for variant codes that leave the math field 0 (hn_set_conv_math)
 
-// variant: 0 = heuristics; otherwise (bk_sel) + 4 * (tm_sel) + 16 * (tn_sel) + 64 * (math_sel) with bk_sel 1 -> K step
-// 32, 2 -> 16; tm_sel / tn_sel 1 -> 64-wide, 2 -> 128-wide tile side; math_sel 1 -> fp32 MFMA, 2 -> bf16x3 (0 keeps the
-// heuristic / library default for that field).  Within one math mode all variants give bitwise identical results: the
-// per-element accumulation order does not depend on the tiling.
-int dispatch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
-    if (variant < 0 || variant >= 192) return HN_EINVAL;
+// What a launch will run: the kernel family, its tile and arithmetic.
+enum : int { FAM_V1 = 0, FAM_V2 = 1 };
+struct ConvPlan {
+    int family;      // FAM_V1: conv_igemm_kernel (this file); FAM_V2: conv_igemm2_kernel (conv_igemm2.hip)
+    bool tall, wide;
+    int mode, bk;    // FAM_V1: loader variant and K step
+    int math;        // FAM_V1: MATH_F32 / MATH_X3; FAM_V2: bf16 planes per operand (3 = bf16x3, 1 = bf16)
+};
+
+// variant: 0 = heuristics; otherwise (bk_sel) + 4 * (tm_sel) + 16 * (tn_sel) + 64 * (math_sel).
+//   math_sel 1 -> fp32 MFMA, 2 -> bf16x3, 3 -> bf16 (0: library default, hn_set_conv_math)
+//   bk_sel   fp32 MFMA: 1 -> K step 32, 2 -> 16.  bf16x3: 1 -> first schedule (two workgroups per CU, phases
+//            separated by barriers), 2 -> second schedule (one wave per SIMD, software-pipelined); 0 = the second.
+//   tm_sel / tn_sel 1 -> 64-wide, 2 -> 128-wide tile side.
+// Within one math mode all variants give bitwise identical results: the per-element accumulation order does not depend
+// on the tiling or the schedule.
+int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
+    if (variant < 0 || variant >= 256) return HN_EINVAL;
     const int bk_sel = variant & 3, tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3, math_sel = variant >> 6;
     if (bk_sel == 3 || tm_sel == 3 || tn_sel == 3) return HN_EINVAL;
     const bool vec = (a.C % 32 == 0) && (a.ldx % 4 == 0) && hn_aligned16(a.x) && hn_aligned16(a.w);
@@ -697,20 +495,65 @@ int dispatch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
     if (tm_sel) tall = tm_sel == 2;
     if (a.cps > 0) tall = false;   // split-K plans are made for 64-row tiles (plan_split_k)
     const bool strided = a.in_dil > 1;
-    const bool bk16 = bk_sel == 2;
     // buffer path: offsets are 32-bit relative to the first image a tile touches (a tile may reach into the next
     // image) and to the tile's first weight row
     const long long image_bytes = (long long)a.H * a.W * a.ldx * 4;
     const bool buf_ok = 3 * image_bytes < (1ll << 31) && 128ll * a.Kdim * 4 < (1ll << 31) &&
                         (long long)a.H * a.W >= 128;
-    // bf16x3 needs the pre-split weight planes and the buffer loaders; anything else runs on the fp32 MFMA
-    const bool x3 = (math_sel ? math_sel == 2 : g_conv_math == MATH_X3) && a.wx3 != nullptr && vec && !strided && buf_ok &&
-                    hn_aligned16(a.wx3) && a.wx3_plane % 8 == 0 && 6 * a.wx3_plane < (1ll << 32);
-    if (x3) return dispatch_tile<MODE_VEC_BUF, 32, MATH_X3>(a, tall, wide, stream);
-    if (vec && !strided && buf_ok)
-        return bk16 ? dispatch_tile<MODE_VEC_BUF, 16>(a, tall, wide, stream) : dispatch_tile<MODE_VEC_BUF, 32>(a, tall, wide, stream);
-    if (vec) return strided ? dispatch_tile<MODE_VEC_STRIDED, 32>(a, tall, wide, stream) : dispatch_tile<MODE_VEC, 32>(a, tall, wide, stream);
-    return strided ? dispatch_tile<MODE_SCALAR_STRIDED, 32>(a, tall, wide, stream) : dispatch_tile<MODE_SCALAR, 32>(a, tall, wide, stream);
+    // the bf16 kernels need the pre-split weight planes and the buffer loaders; anything else runs on the fp32 MFMA
+    const int math = math_sel ? math_sel - 1 : g_conv_math;  // HN_MATH_*
+    const bool planes_ok = a.wx3 != nullptr && vec && !strided && buf_ok && hn_aligned16(a.wx3) &&
+                           a.wx3_plane % 8 == 0 && 6 * a.wx3_plane < (1ll << 32);
+    pl.tall = tall;
+    pl.wide = wide;
+    pl.bk = 32;
+    if (math == HN_MATH_BF16 && planes_ok) {
+        pl.family = FAM_V2; pl.math = MATH2_BF16; pl.mode = MODE_VEC_BUF;
+        pl.bk = a.C % 64 == 0 ? 64 : 32;
+    } else if (math == HN_MATH_BF16X3 && planes_ok) {
+        pl.mode = MODE_VEC_BUF;
+        if (bk_sel == 1) { pl.family = FAM_V1; pl.math = MATH_X3; }
+        else { pl.family = FAM_V2; pl.math = MATH2_X3; }
+    } else {
+        pl.family = FAM_V1; pl.math = MATH_F32;
+        if (vec && !strided && buf_ok) { pl.mode = MODE_VEC_BUF; pl.bk = bk_sel == 2 ? 16 : 32; }
+        else if (vec) pl.mode = strided ? MODE_VEC_STRIDED : MODE_VEC;
+        else pl.mode = strided ? MODE_SCALAR_STRIDED : MODE_SCALAR;
+    }
+    if (a.in_scale != nullptr && pl.family != FAM_V2) return HN_ESHAPE;  // the A-operand transform lives in the v2 loader
+    return HN_OK;
+}
+
+int run_conv(const ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
+    if (pl.family == FAM_V2) {
+        const int rc = launch_conv2(a, pl.tall, pl.wide, pl.math, stream);
+        return rc == 1 ? HN_ESHAPE : rc;
+    }
+    if (pl.math == MATH_X3) return dispatch_tile<MODE_VEC_BUF, 32, MATH_X3>(a, pl.tall, pl.wide, stream);
+    switch (pl.mode) {
+        case MODE_VEC_BUF:
+            return pl.bk == 16 ? dispatch_tile<MODE_VEC_BUF, 16>(a, pl.tall, pl.wide, stream)
+                               : dispatch_tile<MODE_VEC_BUF, 32>(a, pl.tall, pl.wide, stream);
+        case MODE_VEC_STRIDED: return dispatch_tile<MODE_VEC_STRIDED, 32>(a, pl.tall, pl.wide, stream);
+        case MODE_VEC: return dispatch_tile<MODE_VEC, 32>(a, pl.tall, pl.wide, stream);
+        case MODE_SCALAR_STRIDED: return dispatch_tile<MODE_SCALAR_STRIDED, 32>(a, pl.tall, pl.wide, stream);
+        default: return dispatch_tile<MODE_SCALAR, 32>(a, pl.tall, pl.wide, stream);
+    }
+}
+
+int dispatch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
+    ConvPlan pl;
+    const int rc = plan_conv(a, variant, pl);
+    if (rc != HN_OK) return rc;
+    return run_conv(a, pl, stream);
+}
+
+// the kernel's name as rocprofv3 prints it (tools/pmc_aggregate.py keys), for per-instantiation accounting
+void plan_name(const ConvPlan& pl, char* buf, int n) {
+    const int tm = pl.tall ? 2 : 1, tn = pl.wide ? 2 : 1;
+    if (pl.family == FAM_V2) snprintf(buf, n, "conv_igemm2_kernel<%d, %d, %d, %d, false>", tm, tn, pl.math, pl.bk);
+    else if (pl.math == MATH_X3) snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 1>", tm, tn, pl.mode, pl.bk);
+    else snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d>", tm, tn, pl.mode, pl.bk);
 }
 
 // Split-K plan: K steps (of 32) per split, or 0.  Used when the output has so few tiles that the chip would idle
@@ -916,12 +759,9 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 
 }  // namespace
 
-extern "C" int hn_conv2d_fwd(const float* x, const float* w, const void* w_x3, const float* bias, float* y, double* stats,
-                             const HnConvDesc* d, int act, float slope, int variant, void* stream) {
-    if (x == nullptr || w == nullptr || y == nullptr) return HN_EINVAL;
-    if (act < HN_ACT_NONE || act > HN_ACT_LEAKY) return HN_EINVAL;
-    const int rc = check_desc(d);
-    if (rc != HN_OK) return rc;
+namespace {
+ConvArgs fwd_args(const float* x, const float* w, const void* w_x3, const float* bias, float* y, double* stats,
+                  const HnConvDesc* d, int act, float slope) {
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats; a.addend = nullptr; a.ldadd = 0;
     a.H = d->Hin; a.W = d->Win; a.C = d->Cin; a.ldx = d->ldx;
@@ -930,18 +770,76 @@ extern "C" int hn_conv2d_fwd(const float* x, const float* w, const void* w_x3, c
     a.omap = 0; a.oH = a.oW = a.oph = a.opw = 0; a.ostep = 1; a.cps = 0;
     a.M = d->N * d->Hout * d->Wout;
     a.Kdim = d->KH * d->KW * d->Cin;
-    a.ntm = a.ntn = 0;
+    a.ntm = a.ntn = 0; a.gm = 1;
     a.act = act; a.slope = slope;
     a.x_bytes = (((long long)d->N * d->Hin * d->Win - 1) * d->ldx + d->Cin) * 4;
     a.wx3 = static_cast<const unsigned short*>(w_x3);
     a.wx3_plane = hn_x3_plane((long long)d->Cout * a.Kdim);
+    a.in_scale = a.in_shift = nullptr;
+    return a;
+}
+}  // namespace
+
+extern "C" int hn_set_deterministic(int on) {
+    g_deterministic = on != 0;
+    return HN_OK;
+}
+
+extern "C" int hn_get_deterministic(void) { return g_deterministic ? 1 : 0; }
+
+extern "C" int hn_conv2d_fwd_affine(const float* x, const float* in_scale, const float* in_shift, const float* w,
+                                    const void* w_x3, const float* bias, float* y, double* stats, const HnConvDesc* d,
+                                    int variant, void* stream) {
+    if (x == nullptr || w == nullptr || y == nullptr || in_scale == nullptr || in_shift == nullptr) return HN_EINVAL;
+    const int rc = check_desc(d);
+    if (rc != HN_OK) return rc;
+    if (!hn_aligned16(in_scale) || !hn_aligned16(in_shift)) return HN_EALIGN;
+    ConvArgs a = fwd_args(x, w, w_x3, bias, y, stats, d, HN_ACT_NONE, 0.f);
+    a.in_scale = in_scale;
+    a.in_shift = in_shift;
+    return dispatch_conv(a, variant, static_cast<hipStream_t>(stream));  // HN_ESHAPE when no kernel with the transform covers it
+}
+
+extern "C" int hn_conv2d_plan(int kind, const HnConvDesc* d, int has_planes, int variant, char* name, int name_len) {
+    if (kind < 0 || kind > 1 || name == nullptr || name_len <= 0) return HN_EINVAL;
+    const int rc = check_desc(d);
+    if (rc != HN_OK) return rc;
+    // operand pointers only enter the plan through their alignment: stand-ins with the alignment the host guarantees
+    const float* al = reinterpret_cast<const float*>(uintptr_t(256));
+    ConvArgs a = fwd_args(al, al, has_planes ? al : nullptr, nullptr, const_cast<float*>(al), nullptr, d, HN_ACT_NONE, 0.f);
+    bool can_split = d->ldy == d->Cout;
+    if (kind == 1) {  // data gradient: the gathered tensor is dY, the produced one dX (first parity class when strided)
+        const bool classes = parity_decomposable(d->KH, d->KW, d->stride, d->dil);
+        a.H = d->Hout; a.W = d->Wout; a.C = d->Cout; a.ldx = d->ldy; a.K = d->Cin; a.ldy = d->ldx;
+        a.stride = 1; a.Ho = d->Hin; a.Wo = d->Win; a.M = d->N * d->Hin * d->Win; a.Kdim = d->KH * d->KW * d->Cout;
+        a.in_dil = classes ? 1 : d->stride;
+        if (classes) { a.Ho = (d->Hin + 1) / 2; a.Wo = (d->Win + 1) / 2; a.M = d->N * a.Ho * a.Wo; a.Kdim = ((d->KH + 1) / 2) * ((d->KW + 1) / 2) * d->Cout; }
+        a.wx3_plane = hn_x3_plane((long long)d->Cin * d->KH * d->KW * d->Cout);
+        a.x_bytes = (((long long)d->N * d->Hout * d->Wout - 1) * d->ldy + d->Cout) * 4;
+        can_split = d->ldx == d->Cin && (d->stride == 1 || classes);
+    }
+    a.cps = (can_split && !g_deterministic) ? plan_split_k(a.M, a.K, a.Kdim) : 0;
+    ConvPlan pl;
+    const int rp = plan_conv(a, a.cps > 0 ? (variant & ~3) : variant, pl);
+    if (rp != HN_OK) return rp;
+    plan_name(pl, name, name_len);
+    return pl.family == FAM_V2 ? 1 : 0;
+}
+
+extern "C" int hn_conv2d_fwd(const float* x, const float* w, const void* w_x3, const float* bias, float* y, double* stats,
+                             const HnConvDesc* d, int act, float slope, int variant, void* stream) {
+    if (x == nullptr || w == nullptr || y == nullptr) return HN_EINVAL;
+    if (act < HN_ACT_NONE || act > HN_ACT_LEAKY) return HN_EINVAL;
+    const int rc = check_desc(d);
+    if (rc != HN_OK) return rc;
+    ConvArgs a = fwd_args(x, w, w_x3, bias, y, stats, d, act, slope);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    a.cps = (d->ldy == d->Cout) ? plan_split_k(a.M, a.K, a.Kdim) : 0;
+    a.cps = (d->ldy == d->Cout && !g_deterministic) ? plan_split_k(a.M, a.K, a.Kdim) : 0;
     if (a.cps == 0) return dispatch_conv(a, variant, s);
     // split-K: zero y, accumulate partial products, then bias / activation and (for BatchNorm) the statistics
     if (hipMemsetAsync(y, 0, (size_t)a.M * a.K * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
     a.bias = nullptr; a.stats = nullptr; a.act = HN_ACT_NONE;
-    const int rcs = dispatch_conv(a, variant & ~3, s);  // split-K plans assume K step 32
+    const int rcs = dispatch_conv(a, variant & ~3, s);  // split-K plans are made for the default K step / schedule
     if (rcs != HN_OK) return rcs;
     if (bias != nullptr || act != HN_ACT_NONE) {
         const float neg_slope = act == HN_ACT_NONE ? 1.f : (act == HN_ACT_RELU ? 0.f : slope);
@@ -984,6 +882,8 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, const void* wt_
     a.x_bytes = (((long long)d->N * d->Hout * d->Wout - 1) * d->ldy + d->Cout) * 4;
     a.wx3 = static_cast<const unsigned short*>(wt_x3);
     a.wx3_plane = hn_x3_plane((long long)d->Cin * d->KH * d->KW * d->Cout);
+    a.in_scale = a.in_shift = nullptr;
+    a.gm = 1;
 
     if (!parity_decomposable(d->KH, d->KW, d->stride, d->dil)) {
         // stride 1: a plain convolution of dY with the flipped taps; other strides: the same kernel gathering from the
@@ -995,7 +895,7 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, const void* wt_
         a.M = d->N * d->Hin * d->Win;
         a.Kdim = d->KH * d->KW * d->Cout;
         a.omap = 0; a.oH = a.oW = a.oph = a.opw = 0; a.ostep = 1;
-        a.cps = (d->ldx == d->Cin && d->stride == 1) ? plan_split_k(a.M, a.K, a.Kdim) : 0;
+        a.cps = (d->ldx == d->Cin && d->stride == 1 && !g_deterministic) ? plan_split_k(a.M, a.K, a.Kdim) : 0;
         if (a.cps > 0) {  // split-K partials add into dX, which therefore starts as the addend (or zero)
             const int rci = init_output(dx, d->ldx, addend, ldadd, (int64_t)a.M, d->Cin, stream);
             if (rci != HN_OK) return rci;
@@ -1013,7 +913,7 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, const void* wt_
     const bool some_empty = gh[0].T == 0 || gh[1].T == 0 || gw[0].T == 0 || gw[1].T == 0;
     // split-K when the classes are tiny (critic tails): every class then ADDS into a pre-initialised dX
     const int Mc = d->N * ((d->Hin + 1) / 2) * ((d->Win + 1) / 2);
-    const bool split = d->ldx == d->Cin && plan_split_k(Mc, d->Cin, gh[1].T * gw[1].T * d->Cout) > 0;
+    const bool split = d->ldx == d->Cin && !g_deterministic && plan_split_k(Mc, d->Cin, gh[1].T * gw[1].T * d->Cout) > 0;
     if (some_empty || split) {  // pixels no tap reaches, or accumulation target: dX = addend or 0
         const int rci = init_output(dx, d->ldx, addend, ldadd, (int64_t)d->N * d->Hin * d->Win, d->Cin, stream);
         if (rci != HN_OK) return rci;
@@ -1115,7 +1015,7 @@ extern "C" int hn_split_bf16x3(const float* src, void* dst, int64_t n, void* str
 }
 
 extern "C" int hn_set_conv_math(int math) {
-    if (math != MATH_F32 && math != MATH_X3) return HN_EINVAL;
+    if (math != HN_MATH_F32 && math != HN_MATH_BF16X3 && math != HN_MATH_BF16) return HN_EINVAL;
     g_conv_math = math;
     return HN_OK;
 }

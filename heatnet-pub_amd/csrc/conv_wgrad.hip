@@ -43,6 +43,7 @@ struct WgradArgs {
     int atomic;
     int dw_zeroed;  // the caller guarantees dW is all zero on entry: accumulate without a fill
     int accumulate; // dW += (always through atomics, never filled)
+    float* slab;    // deterministic mode: split s stores its partial dW to slab + s*K*Kdim (no atomics); NULL otherwise
     long long x_bytes, dy_bytes;
 };
 
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
 
     // D row = output channel, D column = (tap, ci): column on the lane -> 128-B runs of dW per store / atomic.
     const bool full = (co0 + BM <= p.K) && (n0 + BN <= p.Kdim);
+    float* out = p.slab != nullptr ? p.slab + (size_t)split * p.K * p.Kdim : p.dw;
     auto finish = [&](auto full_tag, auto atomic_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr bool ATOMIC = decltype(atomic_tag)::value;
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int rbase = co0 + (wm * TM + i) * 32 + 4 * lh;
-                float* dst = p.dw + (size_t)rbase * p.Kdim + n;
+                float* dst = out + (size_t)rbase * p.Kdim + n;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ro = (r & 3) + 8 * (r >> 2);
@@ -443,6 +445,13 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16
     }
 }
 
+__device__ __forceinline__ bf16x4 round4(const f32x4 v) {
+    bf16x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+    return h;
+}
+
 __device__ __forceinline__ bf16x4 lds_read_tr(const char* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
@@ -460,14 +469,16 @@ __device__ __forceinline__ int x3_off(int k, int c) {
     return k * (2 * B) + ((((c >> 5) ^ swz) << 6) | (((c & 31) ^ (((k >> 3) & 1) << 4)) * 2));
 }
 
-template <int TM, int TN>
+// NS = 3: bf16x3 as described above.  NS = 1: plain bf16 (HN_MATH_BF16, reduced precision) -- operands rounded to nearest
+// bf16 when staged, one MFMA per product.
+template <int TM, int TN, int NS = 3>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p) {
     constexpr int BKP = 32;
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int PLANE_A = BKP * BM * 2, PLANE_B = BKP * BN * 2;  // bytes per bf16 plane
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* As = reinterpret_cast<char*>(smem);  // [3][32][BM] bf16   dY tile
-    char* Bs = As + 3 * PLANE_A;               // [3][32][BN] bf16   gathered X tile
+    char* As = reinterpret_cast<char*>(smem);  // [NS][32][BM] bf16   dY tile
+    char* Bs = As + NS * PLANE_A;              // [NS][32][BN] bf16   gathered X tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -552,21 +563,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
     auto store_chunk = [&](const f32x4 (&sa)[RA], const f32x4 (&sb)[RB]) {
 #pragma unroll
         for (int q = 0; q < RA; ++q) {
-            bf16x4 h, m, l;
-            split3(sa[q], h, m, l);
             char* dst = As + x3_off<BM>(a_r0 + ROWS_A * q, a_c4 * 4);
-            *reinterpret_cast<bf16x4*>(dst) = h;
-            *reinterpret_cast<bf16x4*>(dst + PLANE_A) = m;
-            *reinterpret_cast<bf16x4*>(dst + 2 * PLANE_A) = l;
+            if constexpr (NS == 3) {
+                bf16x4 h, m, l;
+                split3(sa[q], h, m, l);
+                *reinterpret_cast<bf16x4*>(dst) = h;
+                *reinterpret_cast<bf16x4*>(dst + PLANE_A) = m;
+                *reinterpret_cast<bf16x4*>(dst + 2 * PLANE_A) = l;
+            } else {
+                *reinterpret_cast<bf16x4*>(dst) = round4(sa[q]);
+            }
         }
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
-            bf16x4 h, m, l;
-            split3(sb[q], h, m, l);
             char* dst = Bs + x3_off<BN>(b_r0 + ROWS_B * q, b_c4 * 4);
-            *reinterpret_cast<bf16x4*>(dst) = h;
-            *reinterpret_cast<bf16x4*>(dst + PLANE_B) = m;
-            *reinterpret_cast<bf16x4*>(dst + 2 * PLANE_B) = l;
+            if constexpr (NS == 3) {
+                bf16x4 h, m, l;
+                split3(sb[q], h, m, l);
+                *reinterpret_cast<bf16x4*>(dst) = h;
+                *reinterpret_cast<bf16x4*>(dst + PLANE_B) = m;
+                *reinterpret_cast<bf16x4*>(dst + 2 * PLANE_B) = l;
+            } else {
+                *reinterpret_cast<bf16x4*>(dst) = round4(sb[q]);
+            }
         }
     };
 
@@ -592,20 +611,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
     // accumulator element r of acc[i][j]: registers 4s..4s+3 hold the 16x16 sub-block s = 2 * (row half) + (column half);
     // column = 16 * ((r >> 2) & 1) + (lane & 15), row = 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3)
     auto x3_k32 = [&]() {
-        bf16x8 fb[2 * TN][3];
+        bf16x8 fb[2 * TN][NS];
 #pragma unroll
         for (int bj = 0; bj < 2 * TN; ++bj)
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
+            for (int s3 = 0; s3 < NS; ++s3) {
                 const char* b = Bs + s3 * PLANE_B + offB[bj];
                 const bf16x4 lo = lds_read_tr(b), hi = lds_read_tr(b + 4 * (2 * BN));
                 fb[bj][s3] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
         for (int bi = 0; bi < 2 * TM; ++bi) {
-            bf16x8 fa[3];
+            bf16x8 fa[NS];
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
+            for (int s3 = 0; s3 < NS; ++s3) {
                 const char* a = As + s3 * PLANE_A + offA[bi];
                 const bf16x4 lo = lds_read_tr(a), hi = lds_read_tr(a + 4 * (2 * BM));
                 fa[s3] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -615,11 +634,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
                 const int sb = 4 * (2 * (bi & 1) + (bj & 1));
                 f32x16& blk = acc[bi >> 1][bj >> 1];
                 f32x4 c = {blk[sb], blk[sb + 1], blk[sb + 2], blk[sb + 3]};
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][1], c, 0, 0, 0);  // mid*mid
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][2], c, 0, 0, 0);  // hi*lo
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[bj][0], c, 0, 0, 0);  // lo*hi
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][1], c, 0, 0, 0);  // hi*mid
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][0], c, 0, 0, 0);  // mid*hi
+                if constexpr (NS == 3) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][1], c, 0, 0, 0);  // mid*mid
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][2], c, 0, 0, 0);  // hi*lo
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[bj][0], c, 0, 0, 0);  // lo*hi
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][1], c, 0, 0, 0);  // hi*mid
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][0], c, 0, 0, 0);  // mid*hi
+                }
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][0], c, 0, 0, 0);  // hi*hi
                 blk[sb] = c[0];
                 blk[sb + 1] = c[1];
@@ -651,6 +672,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
     }
 
     const bool full = (co0 + BM <= p.K) && (n0 + BN <= p.Kdim);
+    float* out = p.slab != nullptr ? p.slab + (size_t)split * p.K * p.Kdim : p.dw;
     auto finish = [&](auto full_tag, auto atomic_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr bool ATOMIC = decltype(atomic_tag)::value;
@@ -663,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
                     const int row = co0 + (wm * TM + i) * 32 + 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3);
                     const int n = n0 + (wn * TN + j) * 32 + 16 * ((r >> 2) & 1) + (lane & 15);
                     if (FULL || (n < p.Kdim && row < p.K)) {
-                        float* dst = p.dw + (size_t)row * p.Kdim + n;
+                        float* dst = out + (size_t)row * p.Kdim + n;
                         if constexpr (ATOMIC) atomicAdd(dst, acc[i][j][r]);
                         else *dst = acc[i][j][r];
                     }
@@ -680,17 +702,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
     }
 }
 
-template <int TM, int TN, int MODE, int BKP, bool X3 = false>
+// X3: 0 = fp32 MFMA kernel, 3 = bf16x3, 1 = bf16 (planes per operand of conv_wgrad_x3_kernel)
+template <int TM, int TN, int MODE, int BKP, int X3 = 0>
 int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int lds = X3 ? 3 * BKP * (BM + BN) * 2 : 2 * BKP * (BM + BN) * (int)sizeof(float);
-    const void* kern = X3 ? reinterpret_cast<const void*>(conv_wgrad_x3_kernel<TM, TN>)
+    constexpr int lds = X3 ? X3 * BKP * (BM + BN) * 2 : 2 * BKP * (BM + BN) * (int)sizeof(float);
+    const void* kern = X3 ? reinterpret_cast<const void*>(conv_wgrad_x3_kernel<TM, TN, X3 ? X3 : 3>)
                           : reinterpret_cast<const void*>(conv_wgrad_kernel<TM, TN, MODE, BKP>);
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return HN_ELAUNCH;
-        configured = true;
-    }
+    static std::atomic<unsigned long long> configured{0};
+    if (hn_ensure_dynamic_lds(kern, lds, configured) != HN_OK) return HN_ELAUNCH;
     a.ntm = (a.K + BM - 1) / BM;
     a.ntn = (a.Kdim + BN - 1) / BN;
     const int tiles = a.ntm * a.ntn;
@@ -708,17 +728,17 @@ int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     if (split_k > total_chunks) split_k = total_chunks;
     a.chunks_per_split = (total_chunks + split_k - 1) / split_k;
     split_k = (total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
-    a.atomic = split_k > 1 || a.accumulate;
+    a.atomic = (split_k > 1 || a.accumulate) && a.slab == nullptr;
     if (a.atomic && !a.dw_zeroed && !a.accumulate) {
         if (hipMemsetAsync(a.dw, 0, (size_t)a.K * a.Kdim * sizeof(float), stream) != hipSuccess) return HN_ELAUNCH;
     }
-    if constexpr (X3) HN_LAUNCH((conv_wgrad_x3_kernel<TM, TN>), dim3(tiles * split_k), dim3(256), lds, stream, a);
+    if constexpr (X3 != 0) HN_LAUNCH((conv_wgrad_x3_kernel<TM, TN, X3 ? X3 : 3>), dim3(tiles * split_k), dim3(256), lds, stream, a);
     else HN_LAUNCH((conv_wgrad_kernel<TM, TN, MODE, BKP>), dim3(tiles * split_k), dim3(256), lds, stream, a);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
 
-template <int MODE, int BKP, bool X3 = false>
+template <int MODE, int BKP, int X3 = 0>
 int dispatch_wgrad(const WgradArgs& a, bool wide_m, bool wide_n, int split_k, hipStream_t s) {
     if (wide_m)
         return wide_n ? launch_wgrad<2, 2, MODE, BKP, X3>(a, split_k, s) : launch_wgrad<2, 1, MODE, BKP, X3>(a, split_k, s);
@@ -727,14 +747,49 @@ int dispatch_wgrad(const WgradArgs& a, bool wide_m, bool wide_n, int split_k, hi
 
 }  // namespace
 
+// dw = (accumulate ? dw : 0) + slab[0] + slab[1] + ... in that order: the fixed-order second pass of the deterministic mode
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                               long long n, int splits, int accumulate) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = accumulate ? dw[i] : 0.f;
+        for (int s = 0; s < splits; ++s) v += slab[(long long)s * n + i];
+        dw[i] = v;
+    }
+}
+
+static thread_local float* g_wgrad_slab = nullptr;  // set by hn_conv2d_wgrad_det around its call of hn_conv2d_wgrad
+
+extern "C" int hn_conv2d_wgrad_det(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant,
+                                   int flags, float* workspace, void* stream) {
+    if (d == nullptr || workspace == nullptr || split_k <= 0) return HN_EINVAL;
+    if (d->N <= 0 || d->Hout <= 0 || d->Wout <= 0) return HN_EINVAL;
+    const long long total_chunks = ((long long)d->N * d->Hout * d->Wout + 31) / 32;  // reduction steps of 32 pixels
+    long long s = split_k < total_chunks ? split_k : total_chunks;
+    const long long cps = (total_chunks + s - 1) / s;
+    s = (total_chunks + cps - 1) / cps;  // what launch_wgrad arrives at for this request
+    const int accumulate = (flags & HN_WGRAD_ACCUMULATE) != 0;
+    variant = (variant & ~3) | 1;        // 32-pixel reduction step (the split arithmetic above)
+    if (s == 1 && !accumulate) return hn_conv2d_wgrad(x, dy, dw, d, 1, variant, 0, stream);  // single store pass
+    g_wgrad_slab = workspace;
+    const int rc = hn_conv2d_wgrad(x, dy, dw, d, (int)s, variant, flags, stream);
+    g_wgrad_slab = nullptr;
+    if (rc != HN_OK) return rc;
+    const long long n = (long long)d->Cout * d->KH * d->KW * d->Cin;
+    const long long blocks = (n + 255) / 256;
+    HN_LAUNCH(wgrad_slab_reduce_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0,
+              static_cast<hipStream_t>(stream), workspace, dw, n, (int)s, accumulate);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
 extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant,
                                int flags, void* stream) {
     if (x == nullptr || dy == nullptr || dw == nullptr || d == nullptr) return HN_EINVAL;
     if (d->N <= 0 || d->Hin <= 0 || d->Win <= 0 || d->Cin <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0 ||
         d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->dil <= 0 || d->pad < 0 || d->ldx < d->Cin || d->ldy < d->Cout)
         return HN_EINVAL;
-    if (variant < 0 || variant >= 192) return HN_EINVAL;
-    // same encoding as hn_conv2d_fwd; the K-step field selects the pixel step (1 -> 32, 2 -> 16)
+    if (variant < 0 || variant >= 256) return HN_EINVAL;
+    // same encoding as hn_conv2d_fwd; the K-step field selects the pixel step (1 -> 32, 2 -> 16; fp32 MFMA only)
     const int bk_sel = variant & 3, tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3, math_sel = variant >> 6;
     if (bk_sel == 3 || tm_sel == 3 || tn_sel == 3) return HN_EINVAL;
     WgradArgs a;
@@ -745,6 +800,7 @@ extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const
     a.M = d->N * d->Hout * d->Wout;
     a.Kdim = d->KH * d->KW * d->Cin;
     a.ntm = a.ntn = a.chunks_per_split = a.atomic = 0;
+    a.slab = g_wgrad_slab;
     a.dw_zeroed = (flags & HN_WGRAD_DW_ZEROED) != 0;
     a.accumulate = (flags & HN_WGRAD_ACCUMULATE) != 0;
     a.x_bytes = (((long long)d->N * d->Hin * d->Win - 1) * d->ldx + d->Cin) * 4;
@@ -759,10 +815,11 @@ extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const
         const bool buf_ok = a.x_bytes < 0xFFFF0000ll && a.dy_bytes + 64ll * d->ldy * 4 < 0xFFFF0000ll;
         const bool p16 = bk_sel == 2;
         // bf16x3: tiles are whole 64-channel blocks of dY as well (no partial column pieces in the transposed reads)
-        const bool x3 = (math_sel ? math_sel == 2 : hn_get_conv_math() == HN_MATH_BF16X3) && buf_ok && d->Cout % 64 == 0;
-        if (x3) {
+        const int math = math_sel ? math_sel - 1 : hn_get_conv_math();  // HN_MATH_*
+        if (math != HN_MATH_F32 && buf_ok && d->Cout % 64 == 0) {
             if (d->Cout % 128 != 0) wide_m = false;
-            return dispatch_wgrad<WG_VEC_BUF, 32, true>(a, wide_m, wide_n, split_k, s);
+            return math == HN_MATH_BF16 ? dispatch_wgrad<WG_VEC_BUF, 32, 1>(a, wide_m, wide_n, split_k, s)
+                                        : dispatch_wgrad<WG_VEC_BUF, 32, 3>(a, wide_m, wide_n, split_k, s);
         }
 #ifdef HN_WG_DMA
         if (buf_ok) return dispatch_wgrad<WG_VEC_DMA, 32>(a, wide_m, wide_n, split_k, s);  // experiment: LDS-DMA staging

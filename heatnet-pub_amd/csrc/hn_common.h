@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/heatnet_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -14,6 +16,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 #define HN_CHECK_LAUNCH() \
     do { if (hipGetLastError() != hipSuccess) return HN_ELAUNCH; } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: remember it per device ordinal (one bit each),
+// so a process that drives several GPUs configures every instantiation once on each of them.  Thread-safe.
+static inline int hn_ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& done_mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return HN_ELAUNCH;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if ((done_mask.load(std::memory_order_acquire) & bit) == 0) {
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return HN_ELAUNCH;
+        done_mask.fetch_or(bit, std::memory_order_release);
+    }
+    return HN_OK;
+}
 
 // bf16x3 weight planes: plane stride in elements for a matrix of n elements (HN_X3_PLANE in the header)
 static inline long long hn_x3_plane(long long n) { return HN_X3_PLANE(n); }

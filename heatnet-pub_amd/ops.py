@@ -153,7 +153,11 @@ if AUTOTUNE:
 #           accumulate: the same fp32 result quality (see conv_igemm.hip, profiles/r01_bf16x3_probe.txt) at the bf16
 #           matrix-core rate / 6 instead of the fp32 one.  Shapes the bf16x3 kernels do not cover (Cin % 32 != 0) run
 #           on the f32 kernels either way.
-_MATH_CODES = {"f32": 1, "bf16x3": 2}
+# "bf16":   REDUCED precision (BASELINE configs[4]): operands rounded to nearest bf16 as they are staged, one bf16 MFMA
+#           per product, fp32 accumulation; tensors in memory, BatchNorm statistics, master weights and the optimizer
+#           stay fp32.  Never the default; bench.py reports it as a separate workload with dtype "bf16".
+_MATH_CODES = {"f32": 1, "bf16x3": 2, "bf16": 3}
+_PLANE_MATHS = ("bf16x3", "bf16")  # arithmetics that take the weight operand as pre-made bf16 planes
 CONV_MATH = os.environ.get("HEATNET_CONV_MATH", "bf16x3")
 if CONV_MATH not in _MATH_CODES:
     raise RuntimeError("HEATNET_CONV_MATH must be one of %s" % sorted(_MATH_CODES))
@@ -166,12 +170,35 @@ def _math(kind):
 
 
 def set_conv_math(name):
-    """Select the conv arithmetic ("f32" | "bf16x3") for subsequent launches; returns the previous setting."""
+    """Select the conv arithmetic ("f32" | "bf16x3" | "bf16") for subsequent launches; returns the previous setting."""
     global CONV_MATH
     if name not in _MATH_CODES:
         raise ValueError("conv math must be one of %s" % sorted(_MATH_CODES))
     prev, CONV_MATH = CONV_MATH, name
     return prev
+
+
+# Deterministic mode (HEATNET_DETERMINISTIC=1 or set_deterministic(True)): no float atomics in the convolution kernels --
+# forward / data-gradient launches do not use split-K, weight gradients go through hn_conv2d_wgrad_det (partial sums
+# stored per reduction split, added in a fixed order).  Results are then bitwise reproducible run to run; it costs speed
+# on the small-pixel-count layers and a workspace of (splits x dW) floats.  The double-precision BatchNorm sums keep
+# their atomics (order effects of ~1e-16 relative, below fp32 resolution).
+DETERMINISTIC = False
+_det_ws = {}
+
+
+def set_deterministic(on):
+    global DETERMINISTIC
+    prev, DETERMINISTIC = DETERMINISTIC, bool(on)
+    check(_lib.load().hn_set_deterministic(int(DETERMINISTIC)), "hn_set_deterministic")
+    return prev
+
+
+def _det_workspace(device, numel):
+    buf = _det_ws.get(device)
+    if buf is None or buf.numel() < numel:
+        buf = _det_ws[device] = torch.empty(numel, device=device, dtype=torch.float32)
+    return buf
 
 
 def _variant(bk=0, tm=0, tn=0, math=0):
@@ -278,7 +305,7 @@ def prepare_weights():
     """Inside a frozen_weights() scope, before the forward passes: refresh the weight operands of every convolution seen
     in earlier scopes with ONE launch.  Layers not seen yet prepare themselves on first use (and are included next time).
     A no-op under the "f32" arithmetic or outside a scope."""
-    if _frozen_depth > 0 and CONV_MATH == "bf16x3" and not _MATH_F32_KINDS and BATCH_PREP:
+    if _frozen_depth > 0 and CONV_MATH in _PLANE_MATHS and not _MATH_F32_KINDS and BATCH_PREP:
         _prep_registry.run()
 
 
@@ -293,7 +320,7 @@ def _kind(kind):
 
 
 def _pick(kind, d, candidates, launch):
-    if not AUTOTUNE:
+    if not AUTOTUNE or DETERMINISTIC:  # (deterministic mode changes the split-K plans the cached timings were made for)
         return candidates[0]
     key = (kind,) + tuple(getattr(d, f) for f, _ in HnConvDesc._fields_)
     hit = _variant_cache.get(key)
@@ -334,7 +361,9 @@ def _tune_scratch(like):
 def _igemm_candidates(cout, kind):
     tiles = [(0, 0), (1, 2), (2, 1)] if cout > 64 else [(0, 0), (1, 1)]
     math = _MATH_CODES[_math(kind)]
-    bks = (1, 2) if _math(kind) == "f32" else (1,)  # the bf16x3 kernels have one K step
+    # the `bk` field: K step 32 / 16 of the fp32-MFMA kernels; schedule of the bf16x3 kernels (2 = wave-specialised,
+    # conv_igemm2.hip, 1 = two-phase, conv_igemm.hip); the bf16 kernels have one schedule
+    bks = {"f32": (1, 2), "bf16x3": (2, 1), "bf16": (0,)}[_math(kind)]
     return [_variant(bk, tm, tn, math) for tm, tn in tiles for bk in bks]
 
 
@@ -342,7 +371,7 @@ def _wgrad_candidates(cout, cin):
     tms = (0, 1) if cout > 64 else (0,)
     tns = (0, 1) if cin % 128 == 0 else (0,)
     math = _MATH_CODES[_math("wgrad")]
-    bks = (1, 2) if _math("wgrad") == "f32" else (1,)
+    bks = (1, 2) if _math("wgrad") == "f32" else (1,)  # (pixel step; the bf16 weight-gradient kernels have one)
     return [(split, _variant(bk, tm, tn, math)) for tm in tms for tn in tns for bk in bks for split in (0, -2, -3, -4)]
 
 
@@ -413,6 +442,14 @@ def set_conv_profiler(records):
     _conv_prof = records
 
 
+def _plan_name(kind, d, has_planes, variant):
+    """The kernel instantiation hn_conv2d_fwd (kind 0) / hn_conv2d_dgrad (kind 1) runs for this geometry, as rocprofv3
+    names it (per-instantiation accounting in bench.py)."""
+    buf = ctypes.create_string_buffer(128)
+    rc = _lib.load().hn_conv2d_plan(kind, ctypes.byref(d), int(has_planes), variant, buf, 128)
+    return buf.value.decode() if rc >= 0 else "conv_igemm_kernel<?>"
+
+
 class _ConvTimer:
     """HIP events on the launch stream (torch's current stream) around one conv-kernel launch."""
 
@@ -466,12 +503,12 @@ class _Conv2d(torch.autograd.Function):
         s = _stream()
         ctx.wt = ctx.wtx3 = None
         wx3 = None
-        if _math("fwd") == "bf16x3":
-            # Weight operands of the bf16x3 kernels: the bf16 planes of w for the forward and -- when a data gradient
+        if _math("fwd") in _PLANE_MATHS:
+            # Weight operands of the bf16x3 / bf16 kernels: the bf16 planes of w for the forward and -- when a data gradient
             # will follow -- the flipped / transposed weights (fp32 and planes) for dgrad, all made by ONE launch.  They
             # are kept on the parameter and reused inside a frozen_weights() scope (second pass of a confusion-
             # maximisation step, evaluation loops).
-            want_t = _math("dgrad") == "bf16x3" and ctx.needs_input_grad[0]
+            want_t = _math("dgrad") in _PLANE_MATHS and ctx.needs_input_grad[0]
             leaf = _leaf(w_in) if w is w_in else None
             key = (w.data_ptr(), w._version, _frozen_scope, stride, pad, dil)
             prep = getattr(leaf, "_hn_prep", None) if (leaf is not None and _frozen_depth > 0) else None
@@ -496,7 +533,7 @@ class _Conv2d(torch.autograd.Function):
         var = _pick(_kind("fwd"), d, _igemm_candidates(cout, "fwd"), lambda v: check(
             lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), None, ctypes.byref(d), act, slope, v, s),
             "hn_conv2d_fwd"))
-        with _ConvTimer("fwd", d):
+        with _ConvTimer("fwd", d, lambda: _plan_name(0, d, wx3 is not None, var)):
             check(lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), _ptr(stats), ctypes.byref(d), act, slope,
                                     var, s), "hn_conv2d_fwd")
         ctx.geom = (stride, pad, dil, act, slope)
@@ -544,7 +581,7 @@ class _Conv2d(torch.autograd.Function):
             if wt is None:
                 wt = torch.empty(nw, device=x.device, dtype=torch.float32)
                 wtx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16) \
-                    if _math("dgrad") == "bf16x3" else None
+                    if _math("dgrad") in _PLANE_MATHS else None
                 check(lib.hn_weight_flip_transpose(_ptr(w), None, _ptr(wt), _ptr(wtx3), cout, kh, kw, cin, stride, pad, dil,
                                                    s), "hn_weight_flip_transpose")
             dx = new_nhwc(n, cin, h, wd, x.device)
@@ -553,7 +590,7 @@ class _Conv2d(torch.autograd.Function):
                 lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(wtx3), _ptr(dx), None, 0, ctypes.byref(dd), v, s),
                 "hn_conv2d_dgrad"))
             add, ldadd = (None, 0) if dskip is None else as_nhwc(dskip)
-            with _ConvTimer("dgrad", dd):
+            with _ConvTimer("dgrad", dd, lambda: _plan_name(1, dd, wtx3 is not None, var)):
                 check(lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(wtx3), _ptr(dx), _ptr(add), ldadd, ctypes.byref(dd), var,
                                           s), "hn_conv2d_dgrad")
         elif dskip is not None:
@@ -568,10 +605,22 @@ class _Conv2d(torch.autograd.Function):
                 dw_out = dw if slot[1] else None  # a later use adds in place and reports no gradient of its own
             else:
                 dw_out = dw = torch.empty((cout, kh, kw, cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
-            split, var = _pick(_kind("wgrad"), d, _wgrad_candidates(cout, cin), lambda sv: check(
-                lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(_tune_scratch(dw) if flags else dw), ctypes.byref(d), sv[0], sv[1], 0, s),
-                "hn_conv2d_wgrad"))
-            if OVERLAP and _conv_prof is None and ctx.needs_input_grad[0]:
+            if DETERMINISTIC:
+                # fixed plan: one reduction split per 4096 output pixels (at most 32), tile choice left to the library
+                splits = max(1, min(32, npix // 4096))
+                wsp = _det_workspace(x.device, splits * dw.numel())
+                var = _variant(1, 0, 0, _MATH_CODES[_math("wgrad")])
+                with _ConvTimer("wgrad", d, "conv_wgrad_*"):
+                    check(lib.hn_conv2d_wgrad_det(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), splits, var, flags & 2,
+                                                  _ptr(wsp), s), "hn_conv2d_wgrad_det")
+                split = None
+            else:
+                split, var = _pick(_kind("wgrad"), d, _wgrad_candidates(cout, cin), lambda sv: check(
+                    lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(_tune_scratch(dw) if flags else dw), ctypes.byref(d), sv[0], sv[1], 0, s),
+                    "hn_conv2d_wgrad"))
+            if split is None:
+                pass
+            elif OVERLAP and _conv_prof is None and ctx.needs_input_grad[0]:
                 # the dgrad above is already queued on the main stream; wgrad runs beside it on the side stream
                 main, side = torch.cuda.current_stream(), _side_stream(x.device)
                 side.wait_event(fork)
@@ -579,7 +628,7 @@ class _Conv2d(torch.autograd.Function):
                                           ctypes.c_void_p(side.cuda_stream)), "hn_conv2d_wgrad")
                 main.wait_stream(side)
             else:
-                with _ConvTimer("wgrad", d):
+                with _ConvTimer("wgrad", d, "conv_wgrad_*"):
                     check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), split, var, flags, s),
                           "hn_conv2d_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -1087,3 +1136,7 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.99
     lib = _lib.load()
     check(lib.hn_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), lr, beta1, beta2,
                            eps, weight_decay, step, _stream()), "hn_adam_step")
+
+
+if os.environ.get("HEATNET_DETERMINISTIC", "0") == "1":
+    DETERMINISTIC = True  # the library flag is raised on first use (importing must not require the library on a CPU host)

@@ -16,8 +16,10 @@
  *     pixel index = (n*H + h)*W + w.
  *   - Convolution weights are [Cout][KH][KW][Cin] (= an OIHW tensor in channels-last
  *     memory format), dense.
- *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant,
- *     keeps no global mutable state and allocates nothing.
+ *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant and allocates
+ *     nothing.  The only process-wide state is the two settings hn_set_conv_math / hn_set_deterministic
+ *     (defaults for calls that do not choose themselves); they are not synchronised with in-flight
+ *     launches -- set them before the first call, one process per GPU.
  *   - Return value: HN_OK or a negative HN_E* code; nothing is thrown across the ABI.
  */
 #ifndef HEATNET_HIP_H
@@ -61,9 +63,11 @@ int hn_version(void);
 /* ---- convolution: nn.Conv2d in cm/models/extractors.py:71-77,111-146, cm/models/pspnet.py:13,18,32,57,
  *      cm/discriminator_model.py:40-44.  Implicit GEMM on v_mfma_f32_32x32x2_f32. ------------------------- */
 
-/* `variant` selects the kernel: 0 = built-in heuristics, else bk + 4*tm + 16*tn + 64*math with bk 1/2 = K step 32/16
- * (2 or 3 resident workgroups per CU), tm/tn 1/2 = 64/128-row/-column block tile and math 1/2 = fp32 MFMA / bf16x3
- * (see hn_set_conv_math); 0 = heuristic / library default for that field.  Within one math mode results are bitwise
+/* `variant` selects the kernel: 0 = built-in heuristics, else bk + 4*tm + 16*tn + 64*math with tm/tn 1/2 = 64/128-row/
+ * -column block tile, math 1/2/3 = fp32 MFMA / bf16x3 / bf16 (see hn_set_conv_math) and bk = the schedule: fp32 MFMA
+ * 1/2 = K step 32/16 (2 or 3 resident workgroups per CU); bf16x3 1 = two workgroups per CU with barrier-separated
+ * staging and MFMA phases, 2 = one wave per SIMD, software-pipelined (csrc/conv_igemm2.hip; the bf16 arithmetic always
+ * runs on this one).  0 = heuristic / library default for that field.  Within one math mode results are bitwise
  * identical across variants; callers may time them per shape (heatnet-pub_amd/ops.py does).
  *
  * y = act(conv(x, w) + bias).  `bias` may be NULL.  If `stats` is non-NULL it must hold
@@ -73,16 +77,41 @@ int hn_version(void);
 int hn_conv2d_fwd(const float* x, const float* w, const void* w_x3, const float* bias, float* y, double* stats,
                   const HnConvDesc* d, int act, float slope, int variant, void* stream);
 
-/* Arithmetic of hn_conv2d_fwd / hn_conv2d_dgrad for variant codes whose math field is 0 (see `variant` above):
+/* Arithmetic of hn_conv2d_fwd / hn_conv2d_dgrad / hn_conv2d_wgrad for variant codes whose math field is 0:
  * HN_MATH_F32 (0, the initial setting): v_mfma_f32_32x32x2_f32 on the fp32 operands.
  * HN_MATH_BF16X3 (1): each fp32 operand is split exactly into three bf16 terms inside the kernel and the six products of
- * weight >= 2^-24 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16 -- fp32-equivalent results (measured against fp64)
- * at 16/6 of the fp32 matrix-core rate.  Geometries the bf16x3 kernels do not cover (Cin % 32 != 0, unaligned
- * tensors, zero-dilated gathers) run on the fp32 kernels.  Process-wide; not synchronised with in-flight launches. */
+ * weight >= 2^-24 are accumulated in fp32 on v_mfma_f32_16x16x32_bf16 -- fp32-equivalent results (measured against fp64)
+ * at 16/6 of the fp32 matrix-core rate.
+ * HN_MATH_BF16 (2): REDUCED precision -- operands rounded to nearest bf16 (8 significant bits) as they are staged, one
+ * v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation; tensors in memory, BatchNorm statistics, master weights and the
+ * optimizer stay fp32 (BASELINE configs[4], "mixed-precision bf16 conv MFMA path").  Never the default.
+ * Geometries the bf16 kernels do not cover (Cin % 32 != 0, unaligned tensors, zero-dilated gathers) run on the fp32
+ * kernels under either setting.  Process-wide; not synchronised with in-flight launches. */
 #define HN_MATH_F32 0
 #define HN_MATH_BF16X3 1
+#define HN_MATH_BF16 2
 int hn_set_conv_math(int math);
 int hn_get_conv_math(void);
+
+/* Deterministic mode: no float atomics in the convolution kernels -- split-K is not used for the forward / data-gradient
+ * kernels, and hn_conv2d_wgrad_det writes its reduction splits to a caller-provided workspace and adds them up in a fixed
+ * order.  Results are then bitwise reproducible from run to run (the double-precision BatchNorm sums are still collected
+ * with global_atomic_add_f64; their order effects are below fp32 resolution).  Off by default. */
+int hn_set_deterministic(int on);
+int hn_get_deterministic(void);
+
+/* hn_conv2d_fwd with the A operand transformed on the fly: the kernel gathers relu(x * in_scale[c] + in_shift[c]) (zero
+ * where a tap falls into the padding) -- the BatchNorm + ReLU of the producing layer applied in this convolution's loader,
+ * so the normalised tensor is never written (cm/models/extractors.py:84-94: conv1 -> bn1 -> relu -> conv2 -> bn2 -> relu
+ * -> conv3).  in_scale / in_shift: Cin floats each, 16-B aligned.  Only the bf16x3 / bf16 kernels implement it:
+ * HN_ESHAPE when the launch would run on another kernel (ask hn_conv2d_plan first). */
+int hn_conv2d_fwd_affine(const float* x, const float* in_scale, const float* in_shift, const float* w, const void* w_x3,
+                         const float* bias, float* y, double* stats, const HnConvDesc* d, int variant, void* stream);
+
+/* Which kernel hn_conv2d_fwd (kind 0) / hn_conv2d_dgrad (kind 1) would launch for this geometry and variant, assuming
+ * 256-B aligned operands and (has_planes != 0) bf16 weight planes: writes the kernel's name as rocprofv3 prints it into
+ * `name`; returns 1 if it is a conv_igemm2 kernel (which hn_conv2d_fwd_affine needs), 0 otherwise, < 0 on error. */
+int hn_conv2d_plan(int kind, const HnConvDesc* d, int has_planes, int variant, char* name, int name_len);
 
 /* bf16x3 takes the WEIGHT operand pre-split (the activations / gradients are split inside the kernel): `w_x3` of
  * hn_conv2d_fwd and `wt_x3` of hn_conv2d_dgrad are three consecutive planes (hi, mid, lo) of HN_X3_PLANE(n) bf16 elements
@@ -135,6 +164,13 @@ int hn_conv2d_dgrad(const float* dy, const float* wt, const void* wt_x3, float* 
 #define HN_WGRAD_ACCUMULATE 2
 int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant,
                     int flags, void* stream);
+
+/* Deterministic form (see hn_set_deterministic): the `split_k` (> 0) reduction splits store their partial results to
+ * `workspace` (split_k * Cout*KH*KW*Cin floats, caller-owned) with plain stores and a second kernel adds them to dw in a
+ * fixed order -- no float atomics, bitwise reproducible.  flags as above (HN_WGRAD_ACCUMULATE: dw += in the same fixed
+ * order; HN_WGRAD_DW_ZEROED is not needed). */
+int hn_conv2d_wgrad_det(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant, int flags,
+                        float* workspace, void* stream);
 
 /* out[c] = sum over npix pixels of x[p*ld + c]  (bias gradient).  `out` is overwritten. */
 int hn_channel_sum(const float* x, int ld, int64_t npix, int C, float* out, void* stream);

@@ -164,6 +164,72 @@ def part_confstep():
         _save("confstep_%s_2x256x256" % adv.lower(), **out)
 
 
+# Parameters whose gradient TENSORS (not norms) are stored by part_confgrads: (key, index expression or None = whole).
+# A norm or a sum is invariant to a permuted / transposed dW; these slices are not.
+GRAD_SLICES = {
+    "train_seg": [
+        ("trgb_segnet.feats.conv1.weight", None), ("trgb_segnet.feats.conv1_2.weight", None),
+        ("trgb_segnet.feats.bn1_2.weight", None), ("trgb_segnet.feats.layer1.0.conv1.weight", None),
+        ("trgb_segnet.feats.layer1_2.2.conv3.weight", "[:32, :32]"), ("trgb_segnet.feats.layer2.0.conv2.weight", "[:16, :32]"),
+        ("trgb_segnet.feats.layer2.0.downsample.0.weight", "[:32, :64]"),
+        ("trgb_segnet.feats.layer2.1.bn2.weight", None), ("trgb_segnet.feats.layer2.1.bn2.bias", None),
+        ("trgb_segnet.feats.layer3.2.conv2.weight", "[:16, :16]"), ("trgb_segnet.feats.layer3.0.conv1.weight", "[:16, ::8]"),
+        ("trgb_segnet.feats.layer4.1.conv2.weight", "[:8, :32]"), ("trgb_segnet.feats.layer4.2.conv3.weight", "[::64, ::16]"),
+        ("trgb_segnet.psp.stages.2.1.weight", "[:32, :32]"), ("trgb_segnet.psp.bottleneck.weight", "[:16, ::64]"),
+        ("trgb_segnet.psp.bottleneck.bias", None), ("trgb_segnet.up_1.conv.0.weight", "[:16, :64]"),
+        ("trgb_segnet.up_1.conv.1.weight", None), ("trgb_segnet.up_1.conv.2.weight", None),
+        ("trgb_segnet.up_3.conv.0.weight", "[:, :16]"), ("trgb_segnet.final.0.weight", None),
+        ("trgb_segnet.final.0.bias", None),
+    ],
+    "train_critic": [
+        ("critics.0.conv1.weight", None), ("critics.0.conv1.bias", None), ("critics.1.conv2.weight", "[:8, :64]"),
+        ("critics.2.conv3.bias", None), ("critics.3.conv4.weight", "[:4, :64]"), ("critics.4.conv1.weight", "[:8, ::8]"),
+        ("critics.5.classifier.weight", None), ("critics.5.classifier.bias", None),
+    ],
+}
+
+
+def part_confgrads():
+    """Elementwise gradient tensors of ONE train_seg and ONE train_critic iteration, each from the seeded state
+    (train_trgb_segnet_conf.py:412-574), for both adversarial losses."""
+    sys.path.insert(0, CM)
+    from models import conf_segnet
+    out = {}
+    for adv in ("MSE", "BCE"):
+        crit = torch.nn.BCEWithLogitsLoss() if adv == "BCE" else torch.nn.MSELoss()
+        ce = torch.nn.CrossEntropyLoss()
+        rgb_d, ir_d, lab = seeded_inputs(2, 256, 256, seed=11)
+        rgb_n, ir_n, _ = seeded_inputs(2, 256, 256, seed=12)
+        for state in ("train_seg", "train_critic"):
+            model = conf_segnet.conv_segnet(pretrained=False, disc_arch="cyclegan", num_critics=6, arch="pspnet",
+                                            late_fusion=True)
+            model.load_state_dict(seeded_state(model, seed=7))
+            set_dropout(model, 0.0)
+            model.train()
+            model.setPhase(state)
+            o = model([rgb_d, ir_d], [rgb_n, ir_n])
+            if state == "train_seg":
+                seg = ce(o["pred_label_a"], lab)
+                ones = torch.ones_like(o["critics_a"][0])
+                conf = torch.zeros(1)
+                for c in list(o["critics_a"]) + list(o["critics_b"]):
+                    wmap = torch.nn.functional.interpolate(ones, size=(c.size(2), c.size(3)), mode="bilinear")
+                    conf = conf + torch.mean(wmap * crit(c, torch.full_like(c, 1))) * 1.0
+                total = seg + 0.1 * conf
+            else:
+                total = sum(torch.sum(crit(c, torch.full_like(c, 1))) for c in o["critics_a"]) + \
+                    sum(torch.sum(crit(c, torch.full_like(c, 0))) for c in o["critics_b"])
+            total.backward()
+            params = dict(model.named_parameters())
+            tag = "%s_%s" % (adv.lower(), state)
+            out[tag + "_total"] = np.array(float(total))
+            for key, idx in GRAD_SLICES[state]:
+                g = params[key].grad
+                out["%s|%s|norm" % (tag, key)] = np.array(float(g.double().norm()))
+                out["%s|%s" % (tag, key)] = (eval("g" + idx) if idx else g).numpy().copy()
+    _save("confgrads_2x256x256", **out)
+
+
 def part_rgb18():
     """BASELINE config 1: top-level PSPNet, ResNet-18, 1x3x320x704, forward + CE(ignore_index=13)."""
     sys.path.insert(0, REF)
@@ -208,7 +274,8 @@ def part_miou():
     _save("miou_cases", **out)
 
 
-PARTS = {"segnet": part_segnet, "confstep": part_confstep, "rgb18": part_rgb18, "miou": part_miou}
+PARTS = {"segnet": part_segnet, "confstep": part_confstep, "confgrads": part_confgrads, "rgb18": part_rgb18,
+         "miou": part_miou}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -474,3 +474,220 @@ def test_c_abi_rejects_bad_arguments(dev):
     with pytest.raises(RuntimeError, match="invalid argument"):
         _lib.check(-1, "probe")
     torch.cuda.synchronize()
+
+
+# ---- second bf16x3 schedule (conv_igemm2.hip), plain bf16 arithmetic, A-operand transform ---------------------------------
+
+def _abi_conv(dev, x, wt, stride, pad, dil, variant, bias=None, act=0, slope=0.0, want_stats=False, affine=None):
+    """hn_conv2d_fwd / hn_conv2d_fwd_affine through the C ABI with an explicit kernel variant; x NCHW cpu, wt OIHW cpu."""
+    import ctypes
+    from heatnet_amd import _lib, ops
+    lib = _lib.load()
+    n, cin, h, w = x.shape
+    cout, _, k, _ = wt.shape
+    ho, wo = ops.conv_out_size(h, k, stride, pad, dil), ops.conv_out_size(w, k, stride, pad, dil)
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous()
+    wd = wt.to(dev).permute(0, 2, 3, 1).contiguous()
+    nw = wd.numel()
+    wx3 = torch.empty(3 * ops.x3_plane(nw), device=dev, dtype=torch.int16)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.hn_split_bf16x3(P(wd), P(wx3), nw, s), "split")
+    y = torch.empty(n, ho, wo, cout, device=dev)
+    stats = torch.zeros(ops.STAT_REPLICAS * 2 * cout, device=dev, dtype=torch.float64) if want_stats else None
+    bd = bias.to(dev) if bias is not None else None
+    d = _lib.HnConvDesc(n, h, w, cin, cin, ho, wo, cout, cout, k, k, stride, pad, dil)
+    if affine is None:
+        _lib.check(lib.hn_conv2d_fwd(P(xd), P(wd), P(wx3), P(bd), P(y), P(stats), ctypes.byref(d), act, slope, variant, s),
+                   "hn_conv2d_fwd")
+    else:
+        sc, sh = affine[0].to(dev), affine[1].to(dev)
+        _lib.check(lib.hn_conv2d_fwd_affine(P(xd), P(sc), P(sh), P(wd), P(wx3), P(bd), P(y), P(stats), ctypes.byref(d),
+                                            variant, s), "hn_conv2d_fwd_affine")
+    torch.cuda.synchronize()
+    return y.permute(0, 3, 1, 2), stats
+
+
+X3_SCHEDULE_CASES = [
+    # n, cin, h, w, cout, k, stride, pad, dil     (all with H*W >= 128 and Cin % 32 == 0: the bf16 kernels' domain)
+    (2, 64, 40, 44, 256, 1, 1, 0, 1),      # 1x1, several 128x128 tiles
+    (2, 256, 24, 40, 256, 3, 1, 2, 2),     # dilated 3x3
+    (1, 128, 33, 47, 96, 3, 1, 1, 1),      # odd sizes: M tail and Cout tail (96)
+    (2, 128, 32, 48, 128, 3, 2, 1, 1),     # stride 2
+    (1, 512, 12, 16, 64, 1, 1, 0, 1),      # M = 192: split-K plan (atomics: compared with a tolerance)
+    (2, 32, 40, 48, 64, 3, 1, 4, 4),       # Cin = 32: one K step per tap
+]
+
+
+@pytest.mark.parametrize("tile", [(0, 0), (1, 1), (1, 2), (2, 1), (2, 2)], ids=str)
+@pytest.mark.parametrize("case", X3_SCHEDULE_CASES, ids=str)
+def test_bf16x3_schedules_agree_bitwise(dev, case, tile):
+    """The wave-specialised schedule (variant field bk = 2) computes every output element with the same MFMA sequence as the
+    two-phase schedule (bk = 1): bit-identical outputs and double-precision batch statistics equal to rounding of the
+    atomics' order, for every tile shape."""
+    ops = _ops()
+    n, cin, h, w, cout, k, stride, pad, dil = case
+    x = rnd(n, cin, h, w, seed=41)
+    wt = rnd(cout, cin, k, k, seed=42, scale=1.0 / np.sqrt(cin * k * k))
+    b = rnd(cout, seed=43)
+    tm, tn = tile
+    y1, s1 = _abi_conv(dev, x, wt, stride, pad, dil, ops._variant(1, tm, tn, 2), bias=b, want_stats=True)
+    y2, s2 = _abi_conv(dev, x, wt, stride, pad, dil, ops._variant(2, tm, tn, 2), bias=b, want_stats=True)
+    npix = y1.shape[0] * y1.shape[2] * y1.shape[3]
+    if npix > 2048:
+        assert torch.equal(y1, y2)
+    else:  # split-K: float atomics, order-dependent in the last bits
+        close(y2, y1, atol=1e-5, what="split-K")
+    t1, t2 = s1.view(ops.STAT_REPLICAS, 2, cout).sum(0).cpu(), s2.view(ops.STAT_REPLICAS, 2, cout).sum(0).cpu()  # doubles
+    assert float((t1 - t2).abs().max()) <= 1e-12 * float(t1.abs().max()), "batch statistics differ between the schedules"
+    # and both are the convolution
+    yr = F.conv2d(x, wt, b, stride=stride, padding=pad, dilation=dil)
+    close(y2, yr, atol=(3e-6 * np.sqrt(cin * k * k) + 2e-6) * 4, what="y vs torch")
+
+
+@pytest.mark.parametrize("case", X3_SCHEDULE_CASES, ids=str)
+def test_bf16x3_schedules_agree_through_autograd(dev, case):
+    """Same comparison for the data gradient (incl. the stride-2 parity classes), through ops.conv2d with the schedule
+    forced by the tune-cache-free variant path."""
+    ops = _ops()
+    n, cin, h, w, cout, k, stride, pad, dil = case
+    x = rnd(n, cin, h, w, seed=44)
+    wt = rnd(cout, cin, k, k, seed=45, scale=1.0 / np.sqrt(cin * k * k))
+    outs = []
+    prev_math = ops.set_conv_math("bf16x3")
+    prev_tune = ops.AUTOTUNE
+    cands = ops._igemm_candidates
+    try:
+        ops.AUTOTUNE = False  # candidates[0] is used
+        for bk in (1, 2):
+            ops._igemm_candidates = lambda cout_, kind, bk=bk: [ops._variant(bk, 0, 0, 2)]
+            xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+            wd = wt.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+            y = ops.conv2d(xd, wd, None, stride, pad, dil)
+            y.backward(rnd(*y.shape, seed=46).to(dev))
+            outs.append((y.detach().clone(), xd.grad.detach().clone()))
+    finally:
+        ops._igemm_candidates = cands
+        ops.AUTOTUNE = prev_tune
+        ops.set_conv_math(prev_math)
+    (y1, dx1), (y2, dx2) = outs
+    npix_y = y1.shape[0] * y1.shape[2] * y1.shape[3]
+    npix_x = n * h * w
+    if npix_y > 2048:
+        assert torch.equal(y1, y2)
+    if npix_x > 2048 * (4 if stride == 2 else 1):
+        assert torch.equal(dx1, dx2)
+    else:
+        close(dx2, dx1, atol=1e-5, what="dx (split-K)")
+
+
+@pytest.mark.parametrize("case", X3_SCHEDULE_CASES + [(2, 64, 40, 44, 64, 3, 1, 1, 1), (2, 128, 24, 40, 128, 1, 1, 0, 1)], ids=str)
+def test_conv2d_bf16_arithmetic(dev, case):
+    """HN_MATH_BF16 (configs[4]): the result must be the convolution of the bf16-ROUNDED operands accumulated in fp32 --
+    checked against exactly that computed in fp64 (so the only differences are fp32 accumulation order), and its distance
+    from the unrounded fp32 convolution must be what 8-bit significands give (relative 2^-8 / sqrt(3) per operand)."""
+    ops = _ops()
+    n, cin, h, w, cout, k, stride, pad, dil = case
+    x = rnd(n, cin, h, w, seed=51)
+    wt = rnd(cout, cin, k, k, seed=52, scale=1.0 / np.sqrt(cin * k * k))
+    gy_seed = 53
+    xb, wb = x.bfloat16().double().requires_grad_(), wt.bfloat16().double().requires_grad_()
+    yr = F.conv2d(xb, wb, None, stride=stride, padding=pad, dilation=dil)
+    gy = rnd(*yr.shape, seed=gy_seed)
+    # the gradients' operand dY is rounded too (it is the gathered operand of dgrad and one operand of wgrad)
+    yr.backward(gy.bfloat16().double())
+    prev = ops.set_conv_math("bf16")
+    try:
+        xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+        wd = wt.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+        y = ops.conv2d(xd, wd, None, stride, pad, dil)
+        y.backward(gy.to(dev))
+    finally:
+        ops.set_conv_math(prev)
+    kdim = cin * k * k
+    tol = 3e-6 * np.sqrt(kdim) + 2e-6
+    close(y, yr, atol=tol * 4, what="y vs bf16-rounded fp64")
+    # dx: the kernel multiplies bf16(dY) with bf16(W): the same reference
+    close(xd.grad, xb.grad, atol=(3e-6 * np.sqrt(cout * k * k) + 2e-6) * 4, what="dx vs bf16-rounded fp64")
+    npix = yr.shape[0] * yr.shape[2] * yr.shape[3]
+    close(wd.grad, wb.grad, atol=2e-5 * np.sqrt(npix) + 1e-5, rtol=1e-4, what="dw vs bf16-rounded fp64")
+    # distance from the fp32 convolution: rounding noise of two 8-bit operands, ~ 2^-9 * sqrt(2 K) * rms(x) * rms(w)
+    y32 = F.conv2d(x, wt, None, stride=stride, padding=pad, dilation=dil)
+    rel = float((y.detach().cpu() - y32).pow(2).mean().sqrt() / y32.pow(2).mean().sqrt())
+    assert 5e-4 < rel < 8e-3, rel
+
+
+AFFINE_CASES = [(2, 64, 40, 44, 64, 3, 1, 1, 1), (2, 256, 24, 40, 256, 3, 1, 2, 2), (2, 128, 24, 40, 512, 1, 1, 0, 1),
+                (1, 128, 33, 47, 96, 3, 1, 4, 4), (2, 128, 32, 48, 128, 3, 2, 1, 1)]
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("case", AFFINE_CASES, ids=str)
+def test_conv2d_affine_loader(dev, case, math):
+    """hn_conv2d_fwd_affine == hn_conv2d_fwd on the materialised relu(x * scale + shift): bit-identical (the transform is
+    the same two fp32 operations, fmaf then max, and taps in the zero padding stay zero although relu(shift) != 0)."""
+    ops = _ops()
+    n, cin, h, w, cout, k, stride, pad, dil = case
+    x = rnd(n, cin, h, w, seed=61)
+    wt = rnd(cout, cin, k, k, seed=62, scale=1.0 / np.sqrt(cin * k * k))
+    sc, sh = rnd(cin, seed=63) * 0.5 + 1.0, rnd(cin, seed=64) * 0.5 + 0.3  # mostly positive shifts: padding must stay 0
+    z = torch.relu(torch.addcmul(sh.view(1, -1, 1, 1), x, sc.view(1, -1, 1, 1)))
+    zd = torch.relu(torch.addcmul(sh.to(dev).view(1, -1, 1, 1), x.to(dev), sc.to(dev).view(1, -1, 1, 1)))
+    var = ops._variant(0, 0, 0, ops._MATH_CODES[math])
+    y_ref, s_ref = _abi_conv(dev, zd.cpu(), wt, stride, pad, dil, var, want_stats=True)
+    y_aff, s_aff = _abi_conv(dev, x, wt, stride, pad, dil, var, want_stats=True, affine=(sc, sh))
+    npix = y_ref.shape[0] * y_ref.shape[2] * y_ref.shape[3]
+    assert npix > 2048
+    # torch's addcmul on the GPU may or may not contract to an fma: allow one ulp of z to propagate
+    close(y_aff, y_ref, atol=2e-6 * np.sqrt(cin * k * k), what="affine vs materialised")
+    yr = F.conv2d(z, wt, None, stride=stride, padding=pad, dilation=dil)
+    tol = (3e-6 * np.sqrt(cin * k * k) + 2e-6) * 4 if math == "bf16x3" else 2e-2
+    close(y_aff, yr, atol=tol, what="affine vs torch")
+
+
+def test_conv2d_affine_is_refused_where_no_kernel_has_it(dev):
+    import ctypes
+    from heatnet_amd import _lib
+    ops = _ops()
+    x, wt = rnd(2, 64, 40, 44, seed=1), rnd(64, 64, 3, 3, seed=2)
+    with pytest.raises(RuntimeError, match="hn_conv2d_fwd_affine"):
+        _abi_conv(dev, x, wt, 1, 1, 1, ops._variant(0, 0, 0, 1), affine=(torch.ones(64), torch.zeros(64)))  # fp32 MFMA
+
+
+def test_deterministic_mode_is_bitwise_reproducible(dev):
+    """HEATNET_DETERMINISTIC: weight gradients through hn_conv2d_wgrad_det (per-split slabs + fixed-order sum) and no
+    split-K in forward / data gradient: two runs agree bit for bit, also for a layer applied twice (accumulate), and the
+    result equals the default (atomic) path to rounding."""
+    ops = _ops()
+    from heatnet_amd import optim
+    import torch.nn as nn
+    from heatnet_amd.layers import HnConv2d
+    cases = [(2, 64, 40, 44, 64, 3, 1, 1, 1), (1, 512, 12, 16, 64, 1, 1, 0, 1), (2, 128, 32, 48, 128, 3, 2, 1, 1),
+             (2, 3, 32, 48, 64, 7, 2, 3, 1)]
+    for math in ("bf16x3", "f32"):
+        prev_math = ops.set_conv_math(math)
+        try:
+            for n, cin, h, w, cout, k, stride, pad, dil in cases:
+                x1, x2 = rnd(n, cin, h, w, seed=71).to(dev), rnd(n, cin, h, w, seed=72).to(dev)
+                conv = HnConv2d(cin, cout, k, stride=stride, padding=pad, dilation=dil, bias=False).to(dev)
+                arena = optim.ParamArena(list(conv.parameters()))
+                runs = {}
+                for mode in ("det", "det", "atomic"):
+                    prev = ops.set_deterministic(mode == "det")
+                    try:
+                        arena.zero_grad()
+                        a = x1.clone().contiguous(memory_format=torch.channels_last).requires_grad_()
+                        b = x2.clone().contiguous(memory_format=torch.channels_last).requires_grad_()
+                        (conv(a).square().mean() + conv(b).square().mean()).backward()  # the layer is used twice
+                        res = (arena.grad.clone(), a.grad.clone(), b.grad.clone())
+                    finally:
+                        ops.set_deterministic(prev)
+                    if mode in runs:
+                        for t0, t1 in zip(runs[mode], res):
+                            assert torch.equal(t0, t1), (math, (n, cin, h, w, cout, k), "deterministic runs differ")
+                    runs[mode] = res
+                for t0, t1 in zip(runs["det"], runs["atomic"]):
+                    scale = float(t1.abs().max()) + 1e-30
+                    assert float((t0 - t1).abs().max()) <= 2e-5 * scale
+        finally:
+            ops.set_conv_math(prev_math)

@@ -379,3 +379,67 @@ def test_validation_convention_matches_oracle(dev):
     assert abs(np.nanmean(ref_ious) - res["miou"]) < 1e-3
     # BatchNorm running statistics moved, as they do in the reference's validation
     assert int(net.state_dict()["feats.bn1.num_batches_tracked"]) == 3
+
+
+@pytest.mark.parametrize("conv_math", ["f32", "bf16x3"], indirect=True)
+@pytest.mark.parametrize("adv", ["MSE", "BCE"])
+@pytest.mark.parametrize("state_name", ["train_seg", "train_critic"])
+def test_gradient_tensors_match_reference_elementwise(dev, golden_dir, adv, state_name, conv_math):
+    """ELEMENTWISE gradient tensors against the reference's own (tests/golden/confgrads_2x256x256.npz, written by
+    make_golden.py --part confgrads from /root/reference): a handful of parameters per stage -- stems, bottleneck convs of
+    every layer, a strided conv and its downsample, dilated convs, the pyramid convs, decoder conv / BatchNorm / PReLU, the
+    head, five critic layers -- compared value by value (a norm or a sum would not notice a permuted or transposed dW).
+    Run in deterministic mode (no float atomics) so that the comparison does not depend on atomic arrival order.
+    Bounds: relative to the tensor's norm <= 2e-2 and cosine >= 0.9999 -- the fp32 CPU path itself sits ~1e-2 from an fp64
+    run on this network (ReLU / max-pool decisions flip on fp32 noise, profiles/r01_grad_error_vs_fp64.txt)."""
+    from heatnet_amd import conf_segnet, ops, train_step
+    g = _load(golden_dir, "confgrads_2x256x256")
+    tag = "%s_%s" % (adv.lower(), state_name)
+    model = conf_segnet.conv_segnet(pretrained=False, disc_arch="cyclegan", num_critics=6, arch="pspnet",
+                                    late_fusion=True)
+    model.load_state_dict(seeded_state(model, seed=7))
+    set_dropout(model, 0.0)
+    model = model.to(dev).train()
+    model.setPhase(state_name)
+    rgb_d, ir_d, lab = [t.to(dev) for t in seeded_inputs(2, 256, 256, seed=11)]
+    rgb_n, ir_n, _ = [t.to(dev) for t in seeded_inputs(2, 256, 256, seed=12)]
+
+    class NoStep:
+        def zero_grad(self, set_to_none=True):
+            model.zero_grad()
+
+        def step(self):
+            pass
+
+    prev = ops.set_deterministic(True)
+    try:
+        losses = train_step.train_step(model, NoStep(), [rgb_d, ir_d], [rgb_n, ir_n], lab, state_name, adv=adv)
+    finally:
+        ops.set_deterministic(prev)
+    total = float(g[tag + "_total"])
+    assert abs(losses["total"].item() - total) < 1e-3 * max(1.0, abs(total))
+    params = dict(model.named_parameters())
+    keys = [k.split("|")[1] for k in g.files if k.startswith(tag + "|") and not k.endswith("|norm")]
+    assert len(keys) >= 8
+    import re
+    from golden.make_golden import GRAD_SLICES
+    slices = dict(GRAD_SLICES[state_name])
+    worst_rel, worst_cos = (0.0, None), (1.0, None)
+    for key in keys:
+        ref = torch.from_numpy(g["%s|%s" % (tag, key)]).double()
+        grad = params[key].grad
+        assert grad is not None, key
+        grad = grad.detach().cpu().double()
+        norm_full = float(g["%s|%s|norm" % (tag, key)])
+        assert abs(float(grad.norm()) - norm_full) <= 2e-2 * norm_full + 1e-9, key
+        idx = slices[key]
+        got = eval("grad" + idx) if idx else grad
+        assert got.shape == ref.shape, key
+        if float(ref.norm()) < 1e-6 * max(1.0, norm_full) or norm_full < 1e-9:
+            continue  # (a bias in front of a batch-statistics BatchNorm: true gradient zero, both sides rounding noise)
+        rel = float((got - ref).norm() / ref.norm())
+        cos = float((got * ref).sum() / (got.norm() * ref.norm()))
+        worst_rel = max(worst_rel, (rel, key))
+        worst_cos = min(worst_cos, (cos, key))
+    assert worst_rel[0] <= 2e-2, worst_rel
+    assert worst_cos[0] >= 0.9999, worst_cos

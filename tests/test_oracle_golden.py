@@ -157,3 +157,39 @@ def test_confusion_maximisation_steps(golden_dir, adv):
         scale = {k: float(p.detach().abs().double().sum()) for k, p in model.named_parameters()}
         worst = max(abs(mine[k] - sums[k]) / (scale[k] + 1e-12) for k in names)
         assert worst < 1e-3, worst
+
+
+@pytest.mark.parametrize("adv,state", [("MSE", "train_seg"), ("BCE", "train_critic")])
+def test_gradient_tensors_match_reference_elementwise(golden_dir, adv, state):
+    """The oracle's gradients against the reference's gradient TENSORS (make_golden.py --part confgrads): same op graph on
+    the same CPU library, so they agree to accumulation-order noise -- a transposed or permuted dW would not."""
+    from golden.make_golden import GRAD_SLICES
+
+    class NoStep:
+        def zero_grad(self, *a, **k):
+            model.zero_grad()
+
+        def step(self):
+            pass
+
+    g = _load(golden_dir, "confgrads_2x256x256")
+    tag = "%s_%s" % (adv.lower(), state)
+    model = R.RefConfSegnet(num_critics=6, late_fusion=True)
+    model.load_state_dict(seeded_state(model, seed=7))
+    set_dropout(model, 0.0)
+    model.train()
+    model.setPhase(state)
+    rgb_d, ir_d, lab = seeded_inputs(2, 256, 256, seed=11)
+    rgb_n, ir_n, _ = seeded_inputs(2, 256, 256, seed=12)
+    losses = R.train_step(model, NoStep(), [rgb_d, ir_d], [rgb_n, ir_n], lab, state, adv=adv)
+    assert abs(losses["total"] - float(g[tag + "_total"])) < 2e-4 * max(1.0, abs(float(g[tag + "_total"])))
+    params = dict(model.named_parameters())
+    for key, idx in GRAD_SLICES[state]:
+        ref = torch.from_numpy(g["%s|%s" % (tag, key)]).double()
+        grad = params[key].grad.detach().double()
+        got = eval("grad" + idx) if idx else grad
+        norm_full = float(g["%s|%s|norm" % (tag, key)])
+        if float(ref.norm()) < 1e-6 * max(1.0, norm_full) or norm_full < 1e-9:
+            continue
+        rel = float((got - ref).norm() / ref.norm())
+        assert rel < 5e-3, (key, rel)

@@ -16,7 +16,7 @@ import sys
 
 def kernel_key(name):
     """conv_igemm_kernel<2, 2, 4, 32, 1> from the demangled signature (namespaces and argument list dropped)."""
-    name = name.replace("(anonymous namespace)::", "")
+    name = name.replace("(anonymous namespace)::", "").replace("hnconv::", "")
     name = re.sub(r"^void\s+", "", name)
     depth, cut = 0, len(name)
     for i, ch in enumerate(name):
