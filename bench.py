@@ -42,16 +42,21 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # MI355X_MICROARCH.md, dense peaks: v_mfma_f32_32x32x2_f32 157.3 TFLOP/s; bf16 MFMA ~2500 TFLOP/s, of which one fp32
 # product costs six MFMAs under bf16x3
-PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 6.0}
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 6.0, "bf16": 2500.0}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured by a streaming copy)
 KERNEL_LABEL = {"f32": "conv_igemm_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32)",
                 "bf16x3": "conv_igemm_kernel<..,MATH_X3> / conv_wgrad_x3_kernel (6 x v_mfma_f32_16x16x32_bf16 per fp32 "
-                          "product; peak = dense bf16 MFMA peak / 6)"}
+                          "product; peak = dense bf16 MFMA peak / 6)",
+                "bf16": "conv_igemm2_kernel<..,1,..> / conv_wgrad_x3_kernel<..,1> (one v_mfma_f32_16x16x32_bf16 per product)"}
 CONV_MATH_NOTE = {"f32": "f32: v_mfma_f32_32x32x2_f32 on the fp32 operands",
                   "bf16x3": "bf16x3: fp32 operands split exactly into 3 bf16 terms in-kernel, 6 bf16 MFMAs per product, fp32 "
-                            "accumulate; error vs fp64 equal to the fp32 MFMA's (profiles/r01_bf16x3_probe.txt)"}
+                            "accumulate; error vs fp64 equal to the fp32 MFMA's (profiles/r01_bf16x3_probe.txt)",
+                  "bf16": "bf16 (REDUCED precision, BASELINE configs[4]): conv operands rounded to nearest bf16 in the "
+                          "loaders, one bf16 MFMA per product, fp32 accumulate; activations in HBM, BatchNorm statistics, "
+                          "master weights and optimizer fp32; stems / 13-class head (Cin % 32 != 0) on the fp32 MFMA"}
 H, W, BS = 320, 704, 8
 # conv FLOPs of one step in the REFERENCE's op graph (per image/pair x 8)
-REFERENCE_CONV_TFLOP = {"seg": 8 * 1.0738, "confmax_seg": 8 * 2.2532, "confmax_critic": 8 * 0.8484}
+REFERENCE_CONV_TFLOP = {"seg": 8 * 1.0738, "seg_bf16": 8 * 1.0738, "confmax_seg": 8 * 2.2532, "confmax_critic": 8 * 0.8484}
 
 
 def synthetic_batch(rank, dev, n=BS, h=H, w=W):
@@ -68,7 +73,7 @@ def build(workload, dev):
     from heatnet_amd.conf_segnet import weights_init_normal
     from heatnet_amd.pspnet import PSPNet
     torch.manual_seed(0)
-    if workload == "seg":
+    if workload in ("seg", "seg_bf16"):
         model = PSPNet(backend="resnet50", pretrained=False, late_fusion=True, in_channels=4)
         model.apply(weights_init_normal)
     else:
@@ -80,7 +85,7 @@ def build(workload, dev):
 
 def make_step(workload, model, opt, batch, buckets):
     from heatnet_amd import train_step
-    if workload == "seg":
+    if workload in ("seg", "seg_bf16"):
         return lambda: train_step.segmentation_step(model, opt, batch["rgb_day"], batch["ir_day"], batch["label_day"],
                                                     grad_sync=buckets)
     state = "train_seg" if workload == "confmax_seg" else "train_critic"
@@ -132,7 +137,7 @@ def measure_conv_roofline(step_fn, steps, workload, scale=1.0, geom=(BS, H, W)):
                   "ms_per_step": v[2] / steps, "avg_launch_us": 1e3 * v[2] / v[0], "tflops": v[1] / v[2] / 1e9}
               for k, v in per_kind.items()}
     achieved = flops / ms / 1e9 if ms > 0 else 0.0
-    ref_tflop = REFERENCE_CONV_TFLOP.get(workload) if scale == 1.0 else None
+    ref_tflop = REFERENCE_CONV_TFLOP.get(workload) * scale if abs(scale - round(scale)) < 1e-9 else None
     math = ops.CONV_MATH
     peak = round(PEAK_TFLOPS[math], 1)
     traffic_all, traffic_per_kernel, traffic_source = pmc_traffic(math, workload, *geom)
@@ -141,8 +146,16 @@ def measure_conv_roofline(step_fn, steps, workload, scale=1.0, geom=(BS, H, W)):
     for name, (cnt, by) in inst.items():
         per_inst[name] = {"launches_per_step": cnt // steps, "algorithmic_bytes_per_launch": round(by / cnt),
                           "traffic": (traffic_per_kernel or {}).get(name)}
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4),
+    # the same launches priced against bytes: compulsory traffic (each of a convolution's three tensors touched once)
+    # over the same time.  With one MFMA per product (bf16) the small-K layers are HBM-bound and the byte view is the
+    # tighter of the two; `bound` names the roof the kernels sit closer to.
+    gbs = nbytes / ms / 1e6 if ms > 0 else 0.0
+    hbm = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    mfma = {"achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4)}
+    bound = "hbm" if hbm["frac"] > mfma["frac"] else "mfma"
+    head = hbm if bound == "hbm" else mfma
+    return {"bound": bound, "achieved": head["achieved"], "peak": head["peak"], "unit": head["unit"],
+            "frac": head["frac"], "mfma_view": mfma, "hbm_view": hbm,
             "traffic": traffic_all, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": round(nbytes / max(launches, 1)),
             "by_instantiation": per_inst,
@@ -220,7 +233,7 @@ def cpu_baseline(workload):
     g = torch.Generator().manual_seed(99)
     rgb, ir = torch.randn(1, 3, H, W, generator=g).clamp_(-1, 1), torch.rand(1, 1, H, W, generator=g) * 2 - 1
     lab = torch.randint(0, 13, (1, H, W), generator=g)
-    if workload == "seg":
+    if workload in ("seg", "seg_bf16"):
         model = R.RefPSPNet(backend="resnet50", late_fusion=True, in_channels=4).train()
         opt = torch.optim.RMSprop(model.parameters(), lr=1e-4)
 
@@ -269,7 +282,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="seg", choices=["seg", "confmax_seg", "confmax_critic"])
+    ap.add_argument("--workload", default="seg", choices=["seg", "seg_bf16", "confmax_seg", "confmax_critic"])
     ap.add_argument("--height", type=int, default=H, help="input height (default: the BASELINE metric's 320)")
     ap.add_argument("--width", type=int, default=W, help="input width (default 704)")
     ap.add_argument("--batch", type=int, default=BS, help="images per GPU (default 8)")
@@ -300,7 +313,9 @@ def main():
 
     if os.environ.get("HN_BENCH_FAIL_RANK") == str(rank) and world > 1:
         raise RuntimeError("HN_BENCH_FAIL_RANK: injected worker failure (tests/test_gpu_bench_contract.py)")
-    from heatnet_amd import ddp, optim
+    from heatnet_amd import ddp, optim, ops
+    if args.workload == "seg_bf16":
+        ops.set_conv_math("bf16")  # reduced-precision arithmetic: a separate workload, never the headline
     model = build(args.workload, dev)
     if world > 1:
         ddp.broadcast_module_state(model)
@@ -331,7 +346,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    from heatnet_amd import ops
     scale = (args.height * args.width * args.batch) / float(H * W * BS)
     roof = None
     if not args.no_roofline:
@@ -347,7 +361,7 @@ def main():
     if world > 1:
         dist.barrier()
     alt = None
-    if world == 1 and not args.no_alt:
+    if world == 1 and not args.no_alt and args.workload != "seg_bf16":
         # the same step under the other conv arithmetic, timed the same way (N=1 only: like cpu_baseline, it is a
         # reference figure printed beside the headline, not part of it)
         main_math = ops.CONV_MATH
@@ -366,7 +380,7 @@ def main():
             if not args.no_roofline:
                 r = measure_conv_roofline(step, max(1, min(3, args.steps)), args.workload, scale=scale,
                                           geom=(args.batch, args.height, args.width))
-                alt_roof = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "conv_ms_per_step", "kernel")}
+                alt_roof = dict({k: r[k] for k in ("bound", "conv_ms_per_step", "kernel")}, **r["mfma_view"])
             alt = {"conv_math": other, "value": round(args.batch * args.steps / alt_elapsed, 3), "unit": "images/s",
                    "ms_per_step": round(1e3 * alt_elapsed / args.steps, 3), "steps": args.steps, "roofline": alt_roof}
         finally:
@@ -378,12 +392,13 @@ def main():
     if rank == 0:
         names = {"seg": "configs[1]: HeatNet RGB+thermal dual-stream PSPNet (ResNet-50, late fusion), forward + CE + "
                         "backward + RMSprop",
+                 "seg_bf16": "configs[4] (one GPU's share): the configs[1] step with the mixed-precision bf16 conv MFMA path",
                  "confmax_seg": "configs[2]: confusion-maximisation train_seg iteration (day+night passes, 6 critics)",
                  "confmax_critic": "configs[2]: confusion-maximisation train_critic iteration (day+night passes, 6 critics)"}
         out = {"metric": "training images/s at %dx%d RGB+IR, bs=%d/GPU" % (args.height, args.width, args.batch), "value": round(world * args.batch * args.steps / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": "bf16" if ops.CONV_MATH == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": names[args.workload], "global_batch": world * args.batch, "height": args.height,
                           "width": args.width,
                           "parallelism": "dp%d" % world, "optimizer": "RMSprop lr=1e-4 (fused, flat arena)", "weights": "random init",

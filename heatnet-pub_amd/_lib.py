@@ -68,6 +68,9 @@ SIGNATURES = {
     "hn_pyramid_pool_bwd": [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "hn_ce_fwd": [P, c_int, P, c_i64, c_int, c_i64, P, P],
     "hn_ce_bwd": [P, c_int, P, c_i64, c_int, c_i64, P, P, P, c_int, P],
+    "hn_ce_weighted_fwd": [P, c_int, P, P, c_i64, c_int, P, P],
+    "hn_ce_weighted_bwd": [P, c_int, P, P, c_i64, c_int, P, P, P, c_int, P],
+    "hn_teacher_cert": [P, c_int, c_i64, c_int, P, P, P],
     "hn_adv_loss_fwd": [P, c_i64, c_float, c_int, P, P],
     "hn_adv_loss_bwd": [P, c_i64, c_float, c_int, P, P, P],
     "hn_argmax_confusion": [P, c_int, P, c_i64, c_int, c_int, P, P, P],

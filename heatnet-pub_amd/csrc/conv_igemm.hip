@@ -479,7 +479,7 @@ struct ConvPlan {
 // variant: 0 = heuristics; otherwise (bk_sel) + 4 * (tm_sel) + 16 * (tn_sel) + 64 * (math_sel).
 //   math_sel 1 -> fp32 MFMA, 2 -> bf16x3, 3 -> bf16 (0: library default, hn_set_conv_math)
 //   bk_sel   fp32 MFMA: 1 -> K step 32, 2 -> 16.  bf16x3: 1 -> first schedule (two workgroups per CU, phases
-//            separated by barriers), 2 -> second schedule (one wave per SIMD, software-pipelined); 0 = the second.
+//            separated by barriers), 2 -> second schedule (producer / consumer waves, conv_igemm2.hip); 0 = the first.
 //   tm_sel / tn_sel 1 -> 64-wide, 2 -> 128-wide tile side.
 // Within one math mode all variants give bitwise identical results: the per-element accumulation order does not depend
 // on the tiling or the schedule.
@@ -512,8 +512,10 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
         pl.bk = a.C % 64 == 0 ? 64 : 32;
     } else if (math == HN_MATH_BF16X3 && planes_ok) {
         pl.mode = MODE_VEC_BUF;
-        if (bk_sel == 1) { pl.family = FAM_V1; pl.math = MATH_X3; }
-        else { pl.family = FAM_V2; pl.math = MATH2_X3; }
+        // default: the first schedule -- measured 2-10 % faster than the wave-specialised one on every layer shape of the
+        // network (profiles/r02_conv_schedules.txt)
+        if (bk_sel == 2) { pl.family = FAM_V2; pl.math = MATH2_X3; }
+        else { pl.family = FAM_V1; pl.math = MATH_X3; }
     } else {
         pl.family = FAM_V1; pl.math = MATH_F32;
         if (vec && !strided && buf_ok) { pl.mode = MODE_VEC_BUF; pl.bk = bk_sel == 2 ? 16 : 32; }

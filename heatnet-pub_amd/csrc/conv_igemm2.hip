@@ -188,6 +188,8 @@ __global__ __launch_bounds__(512, (conv2_waves<TM, TN, NS, BK>())) void conv_ige
         fetch(set0);
         __syncthreads();
         int kc = 0;
+        // (hipcc hoists the second step's split arithmetic above the first barrier, so the pair waits for its loads at
+        // the top; pinning the order with sched_barrier(0) restores the two-step fetch distance and measured 5-8 % SLOWER)
         for (; kc + 1 < nchunks; kc += 2) {
             store(stage1, set1);
             fetch(set1);

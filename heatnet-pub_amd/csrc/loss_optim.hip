@@ -16,8 +16,11 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// `weight` (optional): per-pixel factor on the loss (nn.CrossEntropyLoss(reduction='none') times a certainty map,
+// cm/train_trgb_segnet_conf.py:468-477); out[1] then counts ALL pixels (torch.mean over the map), not the non-ignored.
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
-                                                    int64_t npix, int C, int64_t ignore, float* __restrict__ out) {
+                                                    int64_t npix, int C, int64_t ignore, float* __restrict__ out,
+                                                    const float* __restrict__ weight) {
     __shared__ float red[4];
     float loss = 0.f, cnt = 0.f;
     for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
@@ -33,8 +36,12 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
 #pragma unroll
         for (int c = 0; c < MAXC; ++c)
             if (c < C) { se += expf(v[c] - mx); if (c == (int)lab) xl = v[c]; }
-        loss += (mx + logf(se)) - xl;
+        loss += ((mx + logf(se)) - xl) * (weight != nullptr ? weight[pix] : 1.f);
         cnt += 1.f;
+    }
+    if (weight != nullptr) {  // mean over every pixel of the map
+        cnt = 0.f;
+        for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) cnt += 1.f;
     }
     const float l = block_sum(loss, red);
     const float n = block_sum(cnt, red);
@@ -46,9 +53,10 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
 
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
                                                     int64_t npix, int C, int64_t ignore, const float* __restrict__ out,
-                                                    const float* __restrict__ gout, float* __restrict__ dl, int lddl) {
+                                                    const float* __restrict__ gout, float* __restrict__ dl, int lddl,
+                                                    const float* __restrict__ weight) {
     const float cnt = out[1];
-    const float g = cnt > 0.f ? gout[0] / cnt : 0.f;
+    const float g0 = cnt > 0.f ? gout[0] / cnt : 0.f;
     for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
         const int64_t lab = labels[pix];
         float* drow = dl + pix * lddl;
@@ -56,6 +64,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
             for (int c = 0; c < C; ++c) drow[c] = 0.f;
             continue;
         }
+        const float g = weight != nullptr ? g0 * weight[pix] : g0;
         const float* row = logits + pix * ld;
         float v[MAXC];
         float mx = -INFINITY;
@@ -70,6 +79,41 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 #pragma unroll
         for (int c = 0; c < MAXC; ++c)
             if (c < C) drow[c] = v[c] * inv - (c == (int)lab ? g : 0.f);
+    }
+}
+
+// Night-supervision teacher outputs (cm/train_trgb_segnet_conf.py:430-434, 468-472): p = softmax(logits) per pixel;
+// label = argmax p (first maximum); cert = max softmax(p) -- the reference applies softmax to the already normalised
+// probabilities (`cert = softmax(out_night_ir_only)` where out_night_ir_only is itself a softmax output), restated as is.
+__global__ __launch_bounds__(256) void teacher_cert_kernel(const float* __restrict__ logits, int ld, int64_t npix, int C,
+                                                          int64_t* __restrict__ label, float* __restrict__ cert) {
+    for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
+        const float* row = logits + pix * ld;
+        float v[MAXC];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) { v[c] = row[c]; mx = fmaxf(mx, v[c]); }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) { v[c] = expf(v[c] - mx); se += v[c]; }
+        float best = -1.f, pmax = 0.f;
+        int bi = 0;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) {
+                v[c] = v[c] / se;  // p_c
+                if (v[c] > best) { best = v[c]; bi = c; }
+                pmax = fmaxf(pmax, v[c]);
+            }
+        // softmax of the probabilities: exp(p_c - pmax) / sum
+        float se2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) se2 += expf(v[c] - pmax);
+        if (label != nullptr) label[pix] = bi;
+        if (cert != nullptr) cert[pix] = 1.f / se2;  // the maximum of softmax(p) belongs to p_max: exp(0) / sum
     }
 }
 
@@ -167,7 +211,36 @@ extern "C" int hn_ce_fwd(const float* logits, int ld, const int64_t* labels, int
     if (!logits || !labels || !out || npix <= 0 || C <= 0 || C > MAXC || ld < C) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(out, 0, 2 * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
-    HN_LAUNCH(ce_fwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, ignore_index, out);
+    HN_LAUNCH(ce_fwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, ignore_index, out,
+              static_cast<const float*>(nullptr));
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_ce_weighted_fwd(const float* logits, int ld, const int64_t* labels, const float* weight, int64_t npix, int C,
+                                  float* out, void* stream) {
+    if (!logits || !labels || !weight || !out || npix <= 0 || C <= 0 || C > MAXC || ld < C) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(out, 0, 2 * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
+    HN_LAUNCH(ce_fwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, (int64_t)-100, out, weight);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_ce_weighted_bwd(const float* logits, int ld, const int64_t* labels, const float* weight, int64_t npix, int C,
+                                  const float* out, const float* gout, float* dlogits, int lddl, void* stream) {
+    if (!logits || !labels || !weight || !out || !gout || !dlogits || npix <= 0 || C <= 0 || C > MAXC || ld < C || lddl < C)
+        return HN_EINVAL;
+    HN_LAUNCH(ce_bwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, static_cast<hipStream_t>(stream), logits, ld, labels, npix, C,
+              (int64_t)-100, out, gout, dlogits, lddl, weight);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_teacher_cert(const float* logits, int ld, int64_t npix, int C, int64_t* label, float* cert, void* stream) {
+    if (!logits || (!label && !cert) || npix <= 0 || C <= 0 || C > MAXC || ld < C) return HN_EINVAL;
+    HN_LAUNCH(teacher_cert_kernel, dim3(flat_grid(npix)), dim3(256), 0, static_cast<hipStream_t>(stream), logits, ld, npix, C,
+              label, cert);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -178,7 +251,7 @@ extern "C" int hn_ce_bwd(const float* logits, int ld, const int64_t* labels, int
         return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     HN_LAUNCH(ce_bwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, ignore_index, out,
-                       gout, dlogits, lddl);
+                       gout, dlogits, lddl, static_cast<const float*>(nullptr));
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

@@ -361,9 +361,10 @@ def _tune_scratch(like):
 def _igemm_candidates(cout, kind):
     tiles = [(0, 0), (1, 2), (2, 1)] if cout > 64 else [(0, 0), (1, 1)]
     math = _MATH_CODES[_math(kind)]
-    # the `bk` field: K step 32 / 16 of the fp32-MFMA kernels; schedule of the bf16x3 kernels (2 = wave-specialised,
-    # conv_igemm2.hip, 1 = two-phase, conv_igemm.hip); the bf16 kernels have one schedule
-    bks = {"f32": (1, 2), "bf16x3": (2, 1), "bf16": (0,)}[_math(kind)]
+    # the `bk` field: K step 32 / 16 of the fp32-MFMA kernels; schedule of the bf16x3 kernels (1 = two-phase,
+    # conv_igemm.hip; 2 = wave-specialised, conv_igemm2.hip -- slower on every shape of this network, so it is not a
+    # tuning candidate); the bf16 kernels have one schedule
+    bks = {"f32": (1, 2), "bf16x3": (1,), "bf16": (0,)}[_math(kind)]
     return [_variant(bk, tm, tn, math) for tm, tn in tiles for bk in bks]
 
 

@@ -282,6 +282,19 @@ int hn_ce_fwd(const float* logits, int ld, const int64_t* labels, int64_t npix, 
 int hn_ce_bwd(const float* logits, int ld, const int64_t* labels, int64_t npix, int C, int64_t ignore_index,
               const float* out, const float* gout, float* dlogits, int lddl, void* stream);
 
+/* Certainty-weighted night supervision (`--weight_ir_sup`, cm/train_trgb_segnet_conf.py:468-477):
+ * nn.CrossEntropyLoss(reduction='none')(logits, labels) * weight, then torch.mean over the whole map.
+ * out = {sum of weight * -log softmax[label], npix}; dlogits = (*gout / npix) * weight * (softmax - onehot). */
+int hn_ce_weighted_fwd(const float* logits, int ld, const int64_t* labels, const float* weight, int64_t npix, int C,
+                       float* out, void* stream);
+int hn_ce_weighted_bwd(const float* logits, int ld, const int64_t* labels, const float* weight, int64_t npix, int C,
+                       const float* out, const float* gout, float* dlogits, int lddl, void* stream);
+
+/* Outputs of the frozen night-supervision teacher (:430-434, 468-472): label[p] = argmax softmax(logits[p]) (int64) and
+ * cert[p] = max softmax(softmax(logits[p])) -- the reference applies softmax twice, restated as is.  Either output may be
+ * NULL. */
+int hn_teacher_cert(const float* logits, int ld, int64_t npix, int C, int64_t* label, float* cert, void* stream);
+
 /* nn.MSELoss / nn.BCEWithLogitsLoss against a constant map, mean-reduced,
  * cm/train_trgb_segnet_conf.py:237-240,437-446,536-540.  out[0] = mean loss (overwritten). */
 int hn_adv_loss_fwd(const float* x, int64_t n, float target, int kind, float* out, void* stream);

@@ -32,7 +32,10 @@ def test_bench_prints_one_contract_line():
     r = j["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["bound"] in ("mfma", "hbm") and r["unit"] == ("TFLOP/s" if r["bound"] == "mfma" else "GB/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["mfma_view"]["unit"] == "TFLOP/s" and r["hbm_view"]["unit"] == "GB/s" and "by_instantiation" in r
+    assert r["traffic"] is None or r["traffic_source"]  # a traffic figure always names the PMC file it came from
     assert j["cpu_baseline"] is None  # --no-cpu-baseline
     alt = j["alt_conv_math"]
     assert alt["conv_math"] in ("f32", "bf16x3") and alt["conv_math"] != r["conv_math"] and alt["value"] > 0
@@ -65,3 +68,17 @@ def test_bench_worker_failure_is_reported():
                           "--batch", "2", "--height", "128", "--width", "256", "--no-roofline"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode != 0
+
+
+def test_bench_bf16_workload_line():
+    """configs[4] arithmetic as its own workload: dtype "bf16", never mixed into the f32 headline."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2",
+                          "--height", "128", "--width", "256", "--no-cpu-baseline", "--workload", "seg_bf16"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert j["dtype"] == "bf16" and "configs[4]" in j["config"]["workload"] and j["alt_conv_math"] is None
+    assert j["metric"] == "training images/s at 128x256 RGB+IR, bs=2/GPU"
+    assert j["roofline"]["conv_math"] == "bf16" and j["roofline"]["mfma_view"]["peak"] == 2500.0
