@@ -1,14 +1,16 @@
 """Segmentation network + domain critics wrapper (the object the HeatNet trainer drives).
 
-models/confusion_maximization/models/conf_segnet.py:22-140 for arch='pspnet', disc_arch='cyclegan'.  The optional
-branches of the reference (ResNeXt 'custom' arch, ResNet critics, feedback_seg, input adapter, cert branch) are
-outside the hot path and raise NotImplementedError.
+models/confusion_maximization/models/conf_segnet.py:22-140 for arch='pspnet', disc_arch='cyclegan', with the
+`feedback_seg` branch (DownNets appended to the critic inputs, :61-70,121-125).  The remaining optional branches of the
+reference (ResNeXt 'custom' arch, ResNet critics, input adapter, cert branch) are outside the hot path (SURVEY.md
+section 2) and raise NotImplementedError.
 """
 import torch
 import torch.nn as nn
 
-from . import build_net
+from . import build_net, ops
 from .critics import FCDiscriminator
+from .downscale_network import DownNet
 
 
 def weights_init_normal(m):
@@ -33,16 +35,20 @@ class conv_segnet(nn.Module):
         super().__init__()
         if arch != "pspnet":
             raise NotImplementedError("arch=%r: only the PSPNet path is built for MI355X" % arch)
-        if feedback_seg or input_adapter or cert_branch:
-            raise NotImplementedError("feedback_seg / input_adapter / cert_branch are outside the MI355X hot path")
+        if input_adapter or cert_branch:
+            raise NotImplementedError("input_adapter / cert_branch are outside the MI355X hot path")
         num_input_channels = (3 if "rgb" in modalities else 0) + (1 if "ir" in modalities else 0)
         self.trgb_segnet = build_net.build_network(None, "resnet50", in_channels=num_input_channels,
                                                    late_fusion=late_fusion)
         critic_num = [13, 2048, 1024, 512 * 2, 256 * 2, 64 * 2] if late_fusion else [13, 2048, 1024, 512, 256, 64]
         self.trgb_segnet.apply(weights_init_normal)
-        self.feedback_seg = False
+        self.feedback_seg = feedback_seg
         self.input_adapter = False
         if not no_conf:
+            if feedback_seg:  # :61-70 -- every critic but the first also sees the (downscaled) segmentation output
+                num_downscale = [3, 3, 3, 2, 2]
+                critic_num = [critic_num[0]] + [c + 12 for c in critic_num[1:]]
+                self.downscale_nets = nn.ModuleList([DownNet(k) for k in num_downscale])
             self.critics = nn.ModuleList([create_critic(disc_arch, c) for c in critic_num[0:num_critics]])
         if pretrained:
             # the reference loads 'models_finished/training_nc_irrgb_best.pth' relative to the cwd here
@@ -71,8 +77,13 @@ class conv_segnet(nn.Module):
         pred_label_day, inter_f_a, cert_a = self.trgb_segnet(*input_a)
         pred_label_night, inter_f_b, cert_b = self.trgb_segnet(*input_b)
         if not self.no_conf:
-            output["critics_a"] = [c(inter_f_a[i]) for i, c in enumerate(self.critics)]
-            output["critics_b"] = [c(inter_f_b[i]) for i, c in enumerate(self.critics)]
+            output["critics_a"], output["critics_b"] = [], []
+            for i, c in enumerate(self.critics):
+                if self.feedback_seg and i > 0:  # :121-125 (raises for the 13-class PSPNet head, as the reference does)
+                    inter_f_a[i] = ops.concat([inter_f_a[i], self.downscale_nets[i - 1](pred_label_day)])
+                    inter_f_b[i] = ops.concat([inter_f_b[i], self.downscale_nets[i - 1](pred_label_night)])
+                output["critics_a"].append(c(inter_f_a[i]))
+                output["critics_b"].append(c(inter_f_b[i]))
         output["pred_label_a"] = pred_label_day
         output["pred_label_b"] = pred_label_night
         output["cert_a"] = cert_a

@@ -19,7 +19,21 @@ def _square(v, what):
     return int(v)
 
 
-class HnConv2d(nn.Conv2d):
+_DP_MESSAGE = ("heatnet_amd modules cannot be replicated by nn.DataParallel (one process, several GPUs, several threads): "
+               "the kernels' tuning / weight-preparation caches and per-layer workspaces are per process and per device. "
+               "Run one process per GPU -- torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) as "
+               "scripts/main.py:123 does, or heatnet_amd.ddp.GradBuckets (see INTEGRATION.md).")
+
+
+class _NoDataParallel:
+    """nn.DataParallel over ONE device never replicates and keeps working; over several it is refused loudly instead of
+    producing replicas that share device-0 workspaces."""
+
+    def _replicate_for_data_parallel(self):
+        raise RuntimeError(_DP_MESSAGE)
+
+
+class HnConv2d(_NoDataParallel, nn.Conv2d):
     """nn.Conv2d on the implicit-GEMM MFMA kernels.  Weights live in channels-last (OHWI) memory."""
 
     def __init__(self, *args, **kwargs):
@@ -36,7 +50,7 @@ class HnConv2d(nn.Conv2d):
         return ops.conv2d(x, self.weight, self.bias, s, p, d, act, slope)
 
 
-class HnBatchNorm2d(nn.BatchNorm2d):
+class HnBatchNorm2d(_NoDataParallel, nn.BatchNorm2d):
     """nn.BatchNorm2d (affine, tracked running stats) on the fused BN kernels."""
 
     _pending_batches = 0  # forward passes not yet added to `num_batches_tracked` (flushed on state_dict())

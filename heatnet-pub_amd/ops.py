@@ -796,6 +796,27 @@ def bn_act(y, stats, gamma, beta, running_mean, running_var, residual=None, prel
                         float(momentum), float(eps), int(act), float(leaky), ws, drop_mask)
 
 
+_in_consts = {}
+
+
+def instance_norm(x, eps=1e-5):
+    """nn.InstanceNorm2d (no affine, no running statistics): every image normalised with its own per-channel statistics
+    -- the BatchNorm kernels run once per image with unit scale / zero shift (an optional branch: the few small launches
+    per image do not matter, cm/models/downscale_network.py:18)."""
+    n, c = x.shape[0], x.shape[1]
+    key = (x.device, c)
+    if key not in _in_consts:
+        _in_consts[key] = (torch.ones(c, device=x.device), torch.zeros(c, device=x.device))
+    one, zero = _in_consts[key]
+    outs = [bn_act(x[i:i + 1], None, one, zero, None, None, training=True, eps=eps) for i in range(n)]
+    return outs[0] if n == 1 else concat_batch(outs)
+
+
+def concat_batch(xs):
+    """torch.cat(xs, 0) for NHWC tensors (a plain copy; autograd hands the slices back)."""
+    return torch.cat([as_nhwc(t)[0] for t in xs], 0)
+
+
 def drop_mask(n, c, p, device):
     """nn.Dropout2d's per-(image, channel) factor: 0 with probability p, else 1/(1-p)."""
     return torch.bernoulli(torch.full((n, c), 1.0 - p, device=device, dtype=torch.float32)) / (1.0 - p)
@@ -1077,6 +1098,56 @@ class _CrossEntropy(torch.autograd.Function):
 
 def cross_entropy(logits, labels, ignore_index=-100):
     return _CrossEntropy.apply(logits, labels, int(ignore_index))
+
+
+class _CrossEntropyWeighted(torch.autograd.Function):
+    """torch.mean(weight * nn.CrossEntropyLoss(reduction='none')(logits, labels)) with a constant per-pixel weight map
+    (`--weight_ir_sup`, cm/train_trgb_segnet_conf.py:468-477)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, weight):
+        lib = _lib.load()
+        logits, ld = as_nhwc(logits)
+        n, c, h, w = logits.shape
+        if labels.dtype != torch.int64 or not labels.is_cuda or labels.numel() != n * h * w:
+            raise RuntimeError("cross_entropy_weighted: labels must be a cuda int64 tensor matching the logits")
+        _require_gpu(weight)
+        if weight.numel() != n * h * w:
+            raise RuntimeError("cross_entropy_weighted: one weight per pixel")
+        labels, weight = labels.contiguous(), weight.contiguous()
+        out = torch.empty(2, device=logits.device, dtype=torch.float32)
+        check(lib.hn_ce_weighted_fwd(_ptr(logits), ld, _ptr(labels), _ptr(weight), n * h * w, c, _ptr(out), _stream()),
+              "hn_ce_weighted_fwd")
+        ctx.save_for_backward(logits, labels, weight, out)
+        return out[0] / out[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        logits, labels, weight, out = ctx.saved_tensors
+        logits, ld = as_nhwc(logits)
+        n, c, h, w = logits.shape
+        g = g.contiguous().reshape(1)
+        dl = new_nhwc(n, c, h, w, logits.device)
+        check(lib.hn_ce_weighted_bwd(_ptr(logits), ld, _ptr(labels), _ptr(weight), n * h * w, c, _ptr(out), _ptr(g), _ptr(dl),
+                                     c, _stream()), "hn_ce_weighted_bwd")
+        return dl, None, None
+
+
+def cross_entropy_weighted(logits, labels, weight):
+    return _CrossEntropyWeighted.apply(logits, labels, weight)
+
+
+def teacher_outputs(logits, want_cert=True):
+    """(label int64 [N,H,W], cert fp32 [N,H,W] or None) of the frozen night-supervision teacher: arg-max of its softmax and
+    the reference's certainty map max(softmax(softmax(logits))) (cm/train_trgb_segnet_conf.py:430-434, 468-472)."""
+    lib = _lib.load()
+    logits, ld = as_nhwc(logits)
+    n, c, h, w = logits.shape
+    label = torch.empty((n, h, w), device=logits.device, dtype=torch.int64)
+    cert = torch.empty((n, h, w), device=logits.device, dtype=torch.float32) if want_cert else None
+    check(lib.hn_teacher_cert(_ptr(logits), ld, n * h * w, c, _ptr(label), _ptr(cert), _stream()), "hn_teacher_cert")
+    return label, cert
 
 
 class _AdvLoss(torch.autograd.Function):

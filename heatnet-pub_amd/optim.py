@@ -229,5 +229,7 @@ def arenas_for(model):
         groups = [list(model.trgb_segnet.parameters())]
         if hasattr(model, "critics"):
             groups.append(list(model.critics.parameters()))
+        if hasattr(model, "downscale_nets"):  # feedback_seg: never frozen by setPhase (cm/models/conf_segnet.py:86-104)
+            groups.append(list(model.downscale_nets.parameters()))
         return [ParamArena(g) for g in groups]
     return [ParamArena(list(model.parameters()))]

@@ -63,15 +63,36 @@ class PhaseSchedule:
         return True
 
 
+def certainty_confusion_weights(cert, out, critic_weights=None):
+    """:531-540 with `--weight_ir_sup`: the confusion term of critic m is multiplied by
+    mean(F.interpolate((1 - cert)[None], size=critic map size, mode="bilinear")) -- the reference multiplies the (scalar,
+    mean-reduced) criterion by the resized map and averages, which is that product.  Returns one device scalar per critic.
+    (1 - cert and the means are a handful of tiny stock-torch ops on an optional branch; the resize is hn_bilinear_fwd.)"""
+    n_critics = len(out["critics_a"])
+    critic_weights = [1.0] * n_critics if critic_weights is None else critic_weights
+    one_minus = (1.0 - cert).unsqueeze(0)  # [1, N, H, W]: the reference resizes it with the batch as channels
+    scalars, cache = [], {}
+    for m, c in enumerate(out["critics_a"]):
+        size = (c.size(2), c.size(3))
+        if size not in cache:
+            resized = one_minus if size == tuple(one_minus.shape[2:]) else ops.bilinear(one_minus, size)
+            cache[size] = resized.mean()
+        scalars.append(cache[size] * critic_weights[m])
+    return scalars
+
+
 def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_weight=0.1, grad_sync=None,
-               night_teacher=None, teacher_modalities=("ir",)):
+               night_teacher=None, teacher_modalities=("ir",), weight_ir_sup=False):
     """One iteration: zero_grad, forward (day + night passes, critics), loss of the phase, backward, step.
 
     `model` is a `conv_segnet` (possibly wrapped so that `.module` exists); `grad_sync`, when given, is a
     `ddp.GradBuckets` whose all-reduce overlaps the backward pass.  Returns the loss tensors (no host sync).
     `night_teacher` (optional): the night-supervision model of train_trgb_segnet_conf.py:209-229 -- a frozen
     PSPNet fed the night thermal image (`teacher_modalities=("ir",)`) or RGB + thermal; in `train_seg` its arg-max
-    prediction supervises the night pass (:430-434, 455-457; the unweighted variant, `--weight_ir_sup` off).
+    prediction supervises the night pass (:430-434, 455-457).  `weight_ir_sup=True` is the trainer's `--weight_ir_sup`
+    without a cert branch (PSPNet has none: :467-477, 531-532): the night cross-entropy is weighted per pixel by the
+    teacher's certainty max(softmax(softmax(logits))) and averaged over the map, and every critic's confusion term is
+    scaled by the mean of (1 - certainty) resized to that critic's map.
     """
     optimizer.zero_grad(set_to_none=grad_sync is None)  # flat-arena optimizers always zero in place
     if grad_sync is not None:
@@ -82,17 +103,24 @@ def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_w
     losses = {}
     if state == "train_seg":
         seg = segmentation_loss(out["pred_label_a"], label_day)
+        conf_scalars = None
         if night_teacher is not None:
             with torch.no_grad():
                 t_in = [night[0], night[1]] if "rgb" in teacher_modalities else [night[1]]
                 t_logits = night_teacher(*t_in)[0]
-                pseudo, _ = ops.argmax_confusion(t_logits, None, t_logits.size(1))  # = argmax(softmax(.)), on the device
-            seg_night = segmentation_loss(out["pred_label_b"], pseudo.long())
+                pseudo, cert = ops.teacher_outputs(t_logits, want_cert=weight_ir_sup)  # argmax(softmax(.)), certainty
+            if weight_ir_sup:
+                seg_night = ops.cross_entropy_weighted(out["pred_label_b"], pseudo, cert)
+                if "critics_a" in out:
+                    with torch.no_grad():
+                        conf_scalars = certainty_confusion_weights(cert, out)
+            else:
+                seg_night = segmentation_loss(out["pred_label_b"], pseudo)
             losses["seg_night"] = seg_night.detach()
             seg = seg + seg_night
         losses["seg"] = seg.detach()
         if "critics_a" in out:
-            conf = confusion_loss(out, adv)
+            conf = confusion_loss(out, adv, weights=conf_scalars)
             total = seg + conf_weight * conf
             losses["conf"] = conf.detach()
         else:

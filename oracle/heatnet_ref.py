@@ -323,13 +323,16 @@ def confusion_loss(out, kind, weights=None, multidir=False):
 
 
 def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_weight=0.1, night_teacher=None,
-               teacher_modalities=("ir",)):
+               teacher_modalities=("ir",), weight_ir_sup=False):
     """One iteration of train_trgb_segnet_conf.py:383-574 for `state` in {train_seg, train_critic}.
 
     Returns a dict of the scalar losses.  `optimizer.zero_grad()` leaves grads
     None (torch >= 2.0), so frozen-phase parameters are skipped by the optimizer.
     `night_teacher`: the night-supervision model of :209-229 (a frozen segmentation net fed the night IR image, or RGB+IR);
-    its arg-max prediction is the label of the night pass in train_seg (:430-434, 455-457, unweighted variant).
+    its arg-max prediction is the label of the night pass in train_seg (:430-434, 455-457).  `weight_ir_sup`: the
+    `--weight_ir_sup` variant without a cert branch (:467-477, 531-540), line for line: certainty = max over classes of
+    softmax applied to the teacher's softmax output; night CE per pixel times certainty, averaged; each confusion term
+    times the (1 - certainty) map resized bilinearly to the critic's output size (batch used as the channel axis).
     """
     optimizer.zero_grad()
     out = model(day, night)
@@ -339,11 +342,26 @@ def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_w
         if night_teacher is not None:
             with torch.no_grad():
                 t_in = [night[0], night[1]] if "rgb" in teacher_modalities else [night[1]]
-                pseudo = torch.argmax(F.softmax(night_teacher(*t_in)[0], dim=1), 1)
-            seg_night = F.cross_entropy(out["pred_label_b"], pseudo)
+                probs = F.softmax(night_teacher(*t_in)[0], dim=1)
+                pseudo = torch.argmax(probs, 1)
+            conf_maps = None
+            if weight_ir_sup:
+                per_pixel = F.cross_entropy(out["pred_label_b"], pseudo, reduction="none")
+                cert = F.softmax(probs, dim=1).max(1)[0]
+                seg_night = torch.mean(cert * per_pixel)
+                conf_maps = (torch.full_like(cert, 1.0) - cert).unsqueeze(0)
+            else:
+                seg_night = F.cross_entropy(out["pred_label_b"], pseudo)
             losses["seg_night"] = float(seg_night.detach())
             seg = seg + seg_night
-        conf = confusion_loss(out, adv)
+        if night_teacher is not None and weight_ir_sup:
+            crit = adv_criterion(adv)
+            conf = 0.0
+            for c in list(out["critics_a"]) + list(out["critics_b"]):
+                wmap = F.interpolate(conf_maps, size=(c.size(2), c.size(3)), mode="bilinear")
+                conf = conf + torch.mean(wmap * crit(c, torch.full_like(c, 1))) * 1.0
+        else:
+            conf = confusion_loss(out, adv)
         total = seg + conf_weight * conf
         losses.update(seg=float(seg.detach()), conf=float(conf.detach()))
     else:

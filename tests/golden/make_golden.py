@@ -230,6 +230,36 @@ def part_confgrads():
     _save("confgrads_2x256x256", **out)
 
 
+def part_feedback():
+    """`--feedback_seg`: layout of conv_segnet with DownNets (conf_segnet.py:61-70) and one DownNet forward / backward
+    (downscale_network.py:23-35) on a 12-channel map."""
+    sys.path.insert(0, CM)
+    from models import conf_segnet
+    from models.downscale_network import DownNet
+    model = conf_segnet.conv_segnet(pretrained=False, disc_arch="cyclegan", num_critics=6, arch="pspnet",
+                                    late_fusion=True, feedback_seg=True)
+    keys = [k for k in model.state_dict().keys() if not k.startswith("trgb_segnet.")]
+    out = {"keys": np.array(keys), "shapes": np.array([list(model.state_dict()[k].shape) + [0] * (4 - model.state_dict()[k].dim())
+                                                       for k in keys])}
+    try:  # the reference itself cannot run this configuration on the 13-class PSPNet head
+        x = [torch.randn(1, 3, 256, 256), torch.randn(1, 1, 256, 256)]
+        model(x, x)
+        out["forward_error"] = np.array("")
+    except RuntimeError as e:
+        out["forward_error"] = np.array(str(e)[:200])
+    net = DownNet(3)
+    net.load_state_dict(seeded_state(net, seed=13))
+    r = np.random.RandomState(5)
+    x = torch.from_numpy(r.standard_normal((2, 12, 32, 48)).astype(np.float32)).requires_grad_()
+    gy = torch.from_numpy(r.standard_normal((2, 12, 4, 6)).astype(np.float32))
+    y = net(x)
+    y.backward(gy)
+    out.update(x=x.detach().numpy(), gy=gy.numpy(), y=y.detach().numpy(), dx=x.grad.numpy())
+    for k, p in net.named_parameters():
+        out["dw|" + k] = p.grad.numpy()
+    _save("feedback_seg", **out)
+
+
 def part_rgb18():
     """BASELINE config 1: top-level PSPNet, ResNet-18, 1x3x320x704, forward + CE(ignore_index=13)."""
     sys.path.insert(0, REF)
@@ -274,7 +304,8 @@ def part_miou():
     _save("miou_cases", **out)
 
 
-PARTS = {"segnet": part_segnet, "confstep": part_confstep, "confgrads": part_confgrads, "rgb18": part_rgb18,
+PARTS = {"segnet": part_segnet, "confstep": part_confstep, "confgrads": part_confgrads, "feedback": part_feedback,
+         "rgb18": part_rgb18,
          "miou": part_miou}
 
 if __name__ == "__main__":

@@ -232,3 +232,29 @@ def test_flat_optimizer_state_interchange(tmp_path):
         assert (epoch, best) == (7, 0.42) and flat2.steps == [2]
         assert all(torch.equal(a, b) for a, b in zip(net2.state_dict().values(), ref_net.state_dict().values()))
         assert torch.equal(getattr(flat2, bufs[0])[0], getattr(flat, bufs[0])[0])
+
+
+def test_feedback_seg_layout_matches_reference(golden_dir):
+    """conv_segnet(feedback_seg=True): the DownNets and the widened critics carry the reference's state_dict keys and
+    shapes (cm/models/conf_segnet.py:61-70; fixture written from the reference by make_golden.py --part feedback)."""
+    import numpy as np
+    from heatnet_amd import conf_segnet
+    g = np.load(os.path.join(golden_dir, "feedback_seg.npz"), allow_pickle=False)
+    model = conf_segnet.conv_segnet(pretrained=False, disc_arch="cyclegan", num_critics=6, arch="pspnet", late_fusion=True,
+                                    feedback_seg=True)
+    sd = model.state_dict()
+    mine = [k for k in sd.keys() if not k.startswith("trgb_segnet.")]
+    assert mine == [str(k) for k in g["keys"]]
+    for k, shape in zip(mine, g["shapes"]):
+        assert list(sd[k].shape) == [int(v) for v in shape[:sd[k].dim()]], k
+    assert "12 channels" in str(g["forward_error"])  # the reference cannot run this configuration on 13 classes either
+
+
+def test_data_parallel_replication_is_refused():
+    """nn.DataParallel over several devices replicates modules through `_replicate_for_data_parallel`; the HIP-backed layers
+    refuse it with a message that names the supported wrappers (the INTEGRATION.md claim was untested)."""
+    from heatnet_amd.layers import HnBatchNorm2d, HnConv2d
+    for m in (HnConv2d(4, 4, 1), HnBatchNorm2d(4)):
+        with pytest.raises(RuntimeError, match="DistributedDataParallel"):
+            m._replicate_for_data_parallel()
+    assert isinstance(HnConv2d(4, 4, 1), torch.nn.Conv2d) and isinstance(HnBatchNorm2d(4), torch.nn.BatchNorm2d)

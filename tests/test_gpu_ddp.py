@@ -298,3 +298,65 @@ def test_foreign_zero_grad_does_not_accumulate_stale_gradients():
     net.zero_grad()
     with pytest.raises(RuntimeError, match="dropped after backward"):
         opt.step()
+
+
+# ---- the reference's own wrapper: torch DistributedDataParallel around the built network (scripts/main.py:119-123) ------
+
+def _torch_ddp_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from _seeded import seeded_inputs, seeded_state, set_dropout
+    from heatnet_amd import ddp, train_step
+    from models.confusion_maximization.models import build_net  # the reference's import path (overlay package)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+
+    def fresh():
+        net = build_net.build_network(None, "resnet50", in_channels=4, late_fusion=True)  # ends with .cuda(), as the reference
+        net.load_state_dict(seeded_state(net, seed=1))
+        set_dropout(net, 0.0)
+        return net.train()
+
+    rgb, ir, lab = [t.to(dev) for t in seeded_inputs(2, 64, 96, seed=30 + rank)]
+    # (a) exactly what scripts/main.py:123 does
+    wrapped = torch.nn.parallel.DistributedDataParallel(fresh(), device_ids=[0])
+    out = wrapped(rgb, ir)[0]
+    train_step.segmentation_loss(out, lab).backward()
+    g_ddp = {k: p.grad.detach().cpu().clone() for k, p in wrapped.module.named_parameters()}
+    bn_ddp = wrapped.module.state_dict()["feats.bn1.running_mean"].cpu().clone()
+    # (b) the library's own exchange on an identical replica
+    net = fresh()
+    buckets = ddp.GradBuckets(list(net.parameters()), bucket_bytes=8 << 20)
+    buckets.begin_step()
+    train_step.segmentation_loss(net(rgb, ir)[0], lab).backward()
+    buckets.finish_step()
+    g_own = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
+    ret[rank] = (g_ddp, g_own, bn_ddp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_torch_ddp_wrapper_around_built_network_matches_grad_buckets():
+    """`DistributedDataParallel(build_network(...))` as scripts/main.py:119-123 wraps it (world size 2, gloo, both ranks on
+    the one GPU): the averaged gradients equal those of heatnet_amd.ddp.GradBuckets on the same replicas, on both ranks."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_torch_ddp_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+    (d0, o0, _), (d1, o1, _) = ret[0], ret[1]
+    assert sorted(d0) == sorted(o0) and len(d0) > 300
+    worst = 0.0
+    for k in d0:
+        scale = float(o0[k].abs().max()) + 1e-12
+        assert float((d0[k] - d1[k]).abs().max()) <= 1e-6 * scale + 1e-12, k       # both ranks hold the same average
+        worst = max(worst, float((d0[k] - o0[k]).abs().max()) / scale)
+        assert float((d0[k] - o0[k]).abs().max()) <= 5e-4 * scale + 1e-9, k       # == the library's own exchange

@@ -697,3 +697,26 @@ def test_deterministic_mode_is_bitwise_reproducible(dev):
                     assert float((t0 - t1).abs().max()) <= 2e-5 * scale
         finally:
             ops.set_conv_math(prev_math)
+
+
+def test_weighted_cross_entropy_and_teacher_certainty(dev):
+    """hn_teacher_cert / hn_ce_weighted_* against the reference's expressions (cm/train_trgb_segnet_conf.py:430-434,
+    468-477): probs = softmax(teacher logits); label = argmax probs; cert = softmax(probs).max(1)[0];
+    loss = mean(cert * CrossEntropyLoss(reduction='none')(logits, label))."""
+    ops = _ops()
+    t_logits = rnd(2, 13, 24, 40, seed=81, scale=2.0)
+    logits = rnd(2, 13, 24, 40, seed=82)
+    probs = F.softmax(t_logits, dim=1)
+    label_ref = torch.argmax(probs, 1)
+    cert_ref = F.softmax(probs, dim=1).max(1)[0]
+    lr = logits.clone().requires_grad_()
+    loss_ref = torch.mean(cert_ref * F.cross_entropy(lr, label_ref, reduction="none"))
+    loss_ref.backward()
+    label, cert = ops.teacher_outputs(t_logits.to(dev).contiguous(memory_format=torch.channels_last))
+    assert float((label.cpu() != label_ref).float().mean()) == 0.0
+    close(cert, cert_ref, atol=1e-6, what="cert")
+    ld = logits.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    loss = ops.cross_entropy_weighted(ld, label, cert)
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-5
+    close(ld.grad, lr.grad, atol=1e-7, rtol=1e-4, what="dlogits")

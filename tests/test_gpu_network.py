@@ -238,9 +238,11 @@ def test_confusion_maximisation_steps(dev, golden_dir, adv, conv_math, optimizer
         assert worst[0] < (5e-3 if step == 0 else 5e-2), worst
 
 
-def test_night_supervision_teacher_matches_oracle(dev):
+@pytest.mark.parametrize("weight_ir_sup", [False, True])
+def test_night_supervision_teacher_matches_oracle(dev, weight_ir_sup):
     """train_seg with the night-supervision teacher (train_trgb_segnet_conf.py:209-229, 430-457): a frozen IR-only PSPNet
-    labels the night image, the night pass gets a cross-entropy term -- losses and gradient norms against the oracle."""
+    labels the night image, the night pass gets a cross-entropy term -- losses and gradient norms against the oracle.
+    `weight_ir_sup`: the certainty-weighted variant (:467-477, 531-540)."""
     from heatnet_amd import conf_segnet, train_step
     from heatnet_amd.pspnet import PSPNet
     from oracle import heatnet_ref as R
@@ -258,7 +260,7 @@ def test_night_supervision_teacher_matches_oracle(dev):
     set_dropout(r_teacher, 0.0)
     r_teacher.train()  # the reference never switches the teacher to eval mode either
     r_losses = R.train_step(ref, torch.optim.RMSprop(ref.parameters(), lr=1e-4), [rgb_d, ir_d], [rgb_n, ir_n], lab,
-                            "train_seg", night_teacher=r_teacher)
+                            "train_seg", night_teacher=r_teacher, weight_ir_sup=weight_ir_sup)
     r_norms = {k: float(p.grad.double().norm()) for k, p in ref.named_parameters() if p.grad is not None}
 
     model = conf_segnet.conv_segnet(pretrained=False, disc_arch="cyclegan", num_critics=6, arch="pspnet", late_fusion=True)
@@ -272,7 +274,8 @@ def test_night_supervision_teacher_matches_oracle(dev):
     teacher = teacher.to(dev).train()
     losses = train_step.train_step(model, torch.optim.RMSprop(model.parameters(), lr=1e-4),
                                    [rgb_d.to(dev), ir_d.to(dev)], [rgb_n.to(dev), ir_n.to(dev)], lab.to(dev), "train_seg",
-                                   night_teacher=teacher)
+                                   night_teacher=teacher, weight_ir_sup=weight_ir_sup)
+    assert abs(losses["conf"].item() - r_losses["conf"]) < 2e-3 * max(1.0, abs(r_losses["conf"]))
     # a pseudo-label flips where the teacher's two best classes are within fp32 noise of each other; the loss moves by
     # at most (flipped pixels / pixels) * a few nats
     assert abs(losses["seg_night"].item() - r_losses["seg_night"]) < 2e-3, (losses["seg_night"].item(), r_losses["seg_night"])
@@ -593,3 +596,32 @@ def test_640x1408_batch8_properties(dev, conv_math):
         assert p.grad is not None and float(p.grad.abs().max()) > 0.0 or k.endswith("conv.0.bias"), k
     assert float((arenas[0].flat - before).abs().max()) > 0.0
     assert int(net.state_dict()["feats.bn1.num_batches_tracked"]) == 1
+
+
+def test_feedback_seg_downnet_matches_reference_fixture(dev, golden_dir):
+    """DownNet(3) (conv3x3 -> InstanceNorm2d -> bilinear x0.5, three times; cm/models/downscale_network.py:23-35) forward
+    and backward against the reference's own module (fixture from make_golden.py --part feedback)."""
+    from heatnet_amd.downscale_network import DownNet
+    g = _load(golden_dir, "feedback_seg")
+    net = DownNet(3)
+    net.load_state_dict(seeded_state(net, seed=13))
+    net = net.to(dev)
+    x = torch.from_numpy(g["x"]).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    y = net(x)
+    y.backward(torch.from_numpy(g["gy"]).to(dev))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["dx"], atol=2e-5 * np.abs(g["dx"]).max() + 1e-7, rtol=1e-3)
+    for k, p in net.named_parameters():
+        ref = g["dw|" + k]
+        assert float(np.abs(p.grad.cpu().numpy() - ref).max()) <= 2e-4 * np.abs(ref).max() + 1e-7, k
+
+
+def test_feedback_seg_on_the_pspnet_head_raises_like_the_reference(dev):
+    """conv_segnet(arch='pspnet', feedback_seg=True): DownNets are built for 12 channels, the PSPNet head has 13 classes --
+    the reference's forward raises a channel-mismatch RuntimeError (recorded in feedback_seg.npz), and so does this one."""
+    from heatnet_amd import conf_segnet
+    model = conf_segnet.conv_segnet(pretrained=False, disc_arch="cyclegan", num_critics=6, arch="pspnet", late_fusion=True,
+                                    feedback_seg=True).to(dev).train()
+    rgb, ir, _ = [t.to(dev) for t in seeded_inputs(1, 256, 256, seed=3)]
+    with pytest.raises(RuntimeError, match="13 channels"):
+        model([rgb, ir], [rgb, ir])
