@@ -623,7 +623,7 @@ def test_conv2d_bf16_arithmetic(dev, case):
     assert 5e-4 < rel < 8e-3, rel
 
 
-AFFINE_CASES = [(2, 64, 40, 44, 64, 3, 1, 1, 1), (2, 256, 24, 40, 256, 3, 1, 2, 2), (2, 128, 24, 40, 512, 1, 1, 0, 1),
+AFFINE_CASES = [(2, 64, 40, 44, 64, 3, 1, 1, 1), (2, 256, 32, 40, 256, 3, 1, 2, 2), (2, 128, 32, 40, 512, 1, 1, 0, 1),
                 (2, 128, 33, 47, 96, 3, 1, 4, 4), (2, 128, 64, 96, 128, 3, 2, 1, 1)]
 
 
@@ -637,15 +637,16 @@ def test_conv2d_affine_loader(dev, case, math):
     x = rnd(n, cin, h, w, seed=61)
     wt = rnd(cout, cin, k, k, seed=62, scale=1.0 / np.sqrt(cin * k * k))
     sc, sh = rnd(cin, seed=63) * 0.5 + 1.0, rnd(cin, seed=64) * 0.5 + 0.3  # mostly positive shifts: padding must stay 0
-    z = torch.relu(torch.addcmul(sh.view(1, -1, 1, 1), x, sc.view(1, -1, 1, 1)))
-    zd = torch.relu(torch.addcmul(sh.to(dev).view(1, -1, 1, 1), x.to(dev), sc.to(dev).view(1, -1, 1, 1)))
+    # the kernel's transform is fmaf(x, scale, shift) then max(., 0): one rounding -- the same value from double arithmetic
+    z = torch.relu((x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float())
     var = ops._variant(2 if math == "bf16x3" else 0, 0, 0, ops._MATH_CODES[math])  # (bf16x3: the conv_igemm2 schedule)
-    y_ref, s_ref = _abi_conv(dev, zd.cpu(), wt, stride, pad, dil, var, want_stats=True)
+    y_ref, s_ref = _abi_conv(dev, z, wt, stride, pad, dil, var, want_stats=True)
     y_aff, s_aff = _abi_conv(dev, x, wt, stride, pad, dil, var, want_stats=True, affine=(sc, sh))
     npix = y_ref.shape[0] * y_ref.shape[2] * y_ref.shape[3]
     assert npix > 2048
-    # torch's addcmul on the GPU may or may not contract to an fma: allow one ulp of z to propagate
-    close(y_aff, y_ref, atol=2e-6 * np.sqrt(cin * k * k), what="affine vs materialised")
+    # bit-identical up to the (very rare) double rounding of the host-side z; under bf16 such a one-ulp difference of z can
+    # flip a bf16 rounding (2^-9 relative on one product)
+    close(y_aff, y_ref, atol=1e-6 if math == "bf16x3" else 2e-3, what="affine vs materialised")
     yr = F.conv2d(z, wt, None, stride=stride, padding=pad, dilation=dil)
     tol = (3e-6 * np.sqrt(cin * k * k) + 2e-6) * 4 if math == "bf16x3" else 2e-2
     close(y_aff, yr, atol=tol, what="affine vs torch")
