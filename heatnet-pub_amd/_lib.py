@@ -59,6 +59,7 @@ SIGNATURES = {
     "hn_weight_prep_table_fill": [P, c_int, P, P],
     "hn_weight_prepare_batch": [P, c_int, c_int, P],
     "hn_thermal_augment": [P, P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P, P],
+    "hn_thermal_resize": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "hn_set_conv_math": [c_int],
     "hn_get_conv_math": [],
     "hn_set_deterministic": [c_int],

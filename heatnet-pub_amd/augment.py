@@ -5,7 +5,9 @@ Replaces, for a batch of already resized samples held as uint8 / uint16 device t
 `rectDropTensor` (train_trgb_segnet_conf.py:82-86) by ONE kernel launch (`hn_thermal_augment`): random crop, thermal
 clip / scale, horizontal flip, rotation (Pillow's bilinear / nearest affine transforms, bit-exact), to_tensor,
 normalisation to [-1, 1], modality block drop.  `draw_params` draws the random decisions with the loader's own
-distributions; `augment_batch` applies given decisions.  cv2 decoding / resizing stays on the host (out of scope).
+distributions; `augment_batch` applies given decisions.  `resize_crop` is the step in front of it -- cv2.resize to 960x320
+and the column crop (:621-640) -- and `val_batch` the whole of ThermalTestDataLoader.__getitem__ after decoding (:777-814).
+Image decoding (cv2.imread) stays on the host.
 """
 import ctypes
 import math
@@ -114,3 +116,46 @@ def augment_batch(rgb_u8, ir_u16, label_u8, out_hw, params, drop_target=None, cl
                                          ptr(cs), h, w, ptr(rgb), ptr(ir), ptr(lab),
                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "hn_thermal_augment")
     return rgb.permute(0, 3, 1, 2), ir.permute(0, 3, 1, 2), lab
+
+
+TRAIN_COLS, VAL_COLS, NET_RES = (150, 850), (148, 852), (960, 320)  # thermal_loader.py:635-640, 789-791, 622 / 784
+
+
+def resize_crop(rgb_u8, ir_u16, label_u8, cols=TRAIN_COLS, res=NET_RES):
+    """Decoded samples -> loader resolution: rgb_u8 [N,H0,W0,3] uint8 (RGB order), ir_u16 [N,H0,W0] uint16, label_u8
+    [N,H0,W0] uint8 or None (GPU tensors) -> the same three at [N, res[1], cols[1]-cols[0]]: cv2.resize(INTER_LINEAR /
+    INTER_NEAREST for the labels) to `res` = (width, height) and the column crop (cm/thermal_loader.py:621-640)."""
+    if not rgb_u8.is_cuda:
+        raise RuntimeError("resize_crop runs on the MI355X only; there is no CPU fallback")
+    if rgb_u8.dtype != torch.uint8 or ir_u16.dtype not in (torch.uint16, torch.int16):
+        raise RuntimeError("resize_crop: rgb must be uint8 and ir uint16 (raw thermal counts)")
+    n, h0, w0, _ = rgb_u8.shape
+    dw, dh = res
+    c0, c1 = cols
+    dev = rgb_u8.device
+    rgb = torch.empty((n, dh, c1 - c0, 3), device=dev, dtype=torch.uint8)
+    ir = torch.empty((n, dh, c1 - c0), device=dev, dtype=ir_u16.dtype)
+    lab = torch.empty((n, dh, c1 - c0), device=dev, dtype=torch.uint8) if label_u8 is not None else None
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    check(_lib.load().hn_thermal_resize(ptr(rgb_u8.contiguous()), ptr(ir_u16.contiguous()),
+                                        ptr(label_u8.contiguous()) if label_u8 is not None else None, n, h0, w0, dh, dw, c0, c1,
+                                        ptr(rgb), ptr(ir), ptr(lab),
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "hn_thermal_resize")
+    return rgb, ir, lab
+
+
+def val_batch(rgb_u8, ir_u16, label_u8, normalize=True):
+    """ThermalTestDataLoader.__getitem__ (cm/thermal_loader.py:777-814) for a batch of decoded samples on the GPU: resize to
+    960x320, columns 148:852, thermal clip / scale, to_tensor, normalisation.  Returns the loader's dict: `rgb` [N,3,320,704],
+    `ir` [N,1,320,704] (normalised to [-1, 1] when `normalize`), `rgb_org`, `ir_org` (the [0, 1] tensors the loader keeps for
+    visualisation) and `label` [N,320,704] int64."""
+    rgb_c, ir_c, lab_c = resize_crop(rgb_u8, ir_u16, label_u8, cols=VAL_COLS)
+    n, h, w, _ = rgb_c.shape
+    identity = [dict(crop=(0, 0), flip=False, angle=None)] * n
+    rgb, ir, lab = augment_batch(rgb_c, ir_c, lab_c, (h, w), identity)  # clip / scale / to_tensor / (x - 0.5) / 0.5
+    # the un-normalised copies are display data: x_org = the same [0, 1] values before (x - 0.5) / 0.5
+    rgb_org = rgb_c.permute(0, 3, 1, 2).float() / 255.0
+    ir_org = ((ir_c.to(torch.int32) & 0xFFFF).clamp(21800, 25000).double() - 21800.0).div(3200.0).float().unsqueeze(1)
+    if not normalize:
+        rgb, ir = rgb_org.clone(), ir_org.clone()
+    return {"rgb": rgb, "rgb_org": rgb_org, "ir": ir, "ir_org": ir_org, "label": lab}

@@ -117,3 +117,99 @@ extern "C" int hn_thermal_augment(const uint8_t* rgb, const uint16_t* ir, const 
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
+
+
+// ---- decoded image -> 960 x 320 -> column crop (cm/thermal_loader.py:621-640, 783-791) -----------------------------------
+// cv2.resize(INTER_LINEAR) for the uint8 RGB image and the uint16 thermal image, cv2.resize(INTER_NEAREST) for the label
+// map, followed by the loaders' column crop -- only the cropped columns are computed.  Arithmetic restated from OpenCV 4.x
+// (modules/imgproc/src/resize.cpp; oracle/thermal_resize_ref.py states it in numpy): uint8 in 11-bit fixed point, uint16
+// in float32 (multiply, then add: no contraction), an exact 2 x 2 shrink through the INTER_AREA fast path.  PARITY
+// UNPINNED against cv2 itself (not installed in the build container); bit-exact against the oracle.
+namespace {
+
+struct LinTap {
+    int s0, s1;
+    float frac;
+};
+
+__device__ __forceinline__ LinTap lin_tap(int d, int dsize, int ssize) {
+    const double scale = (double)ssize / (double)dsize;
+    const float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    float frac = f - (float)s;
+    if (s < 0) { s = 0; frac = 0.f; }
+    if (s >= ssize - 1) { s = ssize - 1; frac = 0.f; }
+    LinTap t;
+    t.s0 = s;
+    t.s1 = min(s + 1, ssize - 1);
+    t.frac = frac;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void thermal_resize_kernel(const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ ir,
+                                                            const uint8_t* __restrict__ label, int N, int H0, int W0, int dh,
+                                                            int dw, int c0, int cw, uint8_t* __restrict__ rgb_out,
+                                                            uint16_t* __restrict__ ir_out, uint8_t* __restrict__ label_out) {
+#pragma clang fp contract(off)
+    const int64_t total = (int64_t)N * dh * cw;
+    const bool area2 = (W0 == 2 * dw) && (H0 == 2 * dh);
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int xo = (int)(idx % cw), yo = (int)((idx / cw) % dh), n = (int)(idx / ((int64_t)cw * dh));
+        const int dx = xo + c0;
+        const int64_t img = (int64_t)n * H0 * W0;
+        if (area2) {
+            const int64_t p00 = img + (int64_t)(2 * yo) * W0 + 2 * dx, p10 = p00 + W0;
+            if (rgb != nullptr)
+                for (int c = 0; c < 3; ++c)
+                    rgb_out[idx * 3 + c] = (uint8_t)(((int)rgb[p00 * 3 + c] + rgb[(p00 + 1) * 3 + c] + rgb[p10 * 3 + c] +
+                                                      rgb[(p10 + 1) * 3 + c] + 2) >> 2);
+            if (ir != nullptr) ir_out[idx] = (uint16_t)(((int)ir[p00] + ir[p00 + 1] + ir[p10] + ir[p10 + 1] + 2) >> 2);
+        } else {
+            const LinTap tx = lin_tap(dx, dw, W0), ty = lin_tap(yo, dh, H0);
+            const int64_t r0 = img + (int64_t)ty.s0 * W0, r1 = img + (int64_t)ty.s1 * W0;
+            if (rgb != nullptr) {
+                const int a0 = (int)rintf((1.f - tx.frac) * 2048.f), a1 = (int)rintf(tx.frac * 2048.f);
+                const int b0 = (int)rintf((1.f - ty.frac) * 2048.f), b1 = (int)rintf(ty.frac * 2048.f);
+                for (int c = 0; c < 3; ++c) {
+                    const int h0 = rgb[(r0 + tx.s0) * 3 + c] * a0 + rgb[(r0 + tx.s1) * 3 + c] * a1;
+                    const int h1 = rgb[(r1 + tx.s0) * 3 + c] * a0 + rgb[(r1 + tx.s1) * 3 + c] * a1;
+                    int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                    rgb_out[idx * 3 + c] = (uint8_t)min(max(v, 0), 255);
+                }
+            }
+            if (ir != nullptr) {
+                const float a0 = 1.f - tx.frac, a1 = tx.frac, b0 = 1.f - ty.frac, b1 = ty.frac;
+                const float m00 = (float)ir[r0 + tx.s0] * a0, m01 = (float)ir[r0 + tx.s1] * a1;
+                const float m10 = (float)ir[r1 + tx.s0] * a0, m11 = (float)ir[r1 + tx.s1] * a1;
+                const float h0 = m00 + m01, h1 = m10 + m11;
+                const float v0 = h0 * b0, v1 = h1 * b1;
+                const float v = rintf(v0 + v1);
+                ir_out[idx] = (uint16_t)fminf(fmaxf(v, 0.f), 65535.f);
+            }
+        }
+        if (label != nullptr) {
+            const int sx = min((int)floor((double)dx * ((double)W0 / (double)dw)), W0 - 1);
+            const int sy = min((int)floor((double)yo * ((double)H0 / (double)dh)), H0 - 1);
+            label_out[idx] = label[img + (int64_t)sy * W0 + sx];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int hn_thermal_resize(const uint8_t* rgb, const uint16_t* ir, const uint8_t* label, int N, int H0, int W0, int dh,
+                                 int dw, int col0, int col1, uint8_t* rgb_out, uint16_t* ir_out, uint8_t* label_out,
+                                 void* stream) {
+    if ((rgb == nullptr && ir == nullptr && label == nullptr) || N <= 0 || H0 <= 0 || W0 <= 0 || dh <= 0 || dw <= 0)
+        return HN_EINVAL;
+    if (col0 < 0 || col1 > dw || col0 >= col1) return HN_ESHAPE;
+    if ((rgb != nullptr && rgb_out == nullptr) || (ir != nullptr && ir_out == nullptr) || (label != nullptr && label_out == nullptr))
+        return HN_EINVAL;
+    const int cw = col1 - col0;
+    const int64_t total = (int64_t)N * dh * cw;
+    const int64_t blocks = (total + 255) / 256;
+    HN_LAUNCH(thermal_resize_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0,
+              static_cast<hipStream_t>(stream), rgb, ir, label, N, H0, W0, dh, dw, col0, cw, rgb_out, ir_out, label_out);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}

@@ -341,6 +341,15 @@ int hn_thermal_augment(const uint8_t* rgb, const uint16_t* ir, const uint8_t* la
                        const HnAugSample* params, const float* class_scale, int h, int w, float* rgb_out, float* ir_out,
                        int64_t* label_out, void* stream);
 
+/* Decoded sample -> network-resolution arrays: cv2.resize(.., (dw, dh), INTER_LINEAR) of the uint8 RGB image [N][H0][W0][3]
+ * and the uint16 thermal image [N][H0][W0], cv2.resize(INTER_NEAREST) of the uint8 label map, then the loaders' column crop
+ * [:, col0:col1] (cm/thermal_loader.py:621-640: (960, 320) and 150:850; :783-791: 148:852).  Outputs are
+ * [N][dh][col1-col0](x3) in the input types -- what hn_thermal_augment takes.  Any of the three images may be NULL.
+ * OpenCV's arithmetic is restated (uint8: 11-bit fixed point; uint16: float32; exact 2x2 shrink: area average); parity
+ * against cv2 itself is unpinned (cv2 is not available to the build), bit-exact against oracle/thermal_resize_ref.py. */
+int hn_thermal_resize(const uint8_t* rgb, const uint16_t* ir, const uint8_t* label, int N, int H0, int W0, int dh, int dw,
+                      int col0, int col1, uint8_t* rgb_out, uint16_t* ir_out, uint8_t* label_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

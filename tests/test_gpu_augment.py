@@ -80,3 +80,48 @@ def test_augment_without_labels_and_argument_checks(dev):
         augment.augment_batch(torch.from_numpy(rgb), torch.from_numpy(ir), None, (16, 20), params)       # CPU tensors
     with pytest.raises(RuntimeError, match="invalid argument"):
         augment.augment_batch(torch.from_numpy(rgb).to(dev), torch.from_numpy(ir).to(dev), None, (32, 20), params)  # h > H0
+
+
+@pytest.mark.parametrize("src", [(650, 1920), (640, 1920), (512, 1280), (320, 960), (301, 977)], ids=str)
+@pytest.mark.parametrize("cols", [(150, 850), (148, 852)], ids=str)
+def test_resize_crop_matches_oracle_bit_exact(dev, src, cols):
+    """hn_thermal_resize == oracle/thermal_resize_ref.py (OpenCV's INTER_LINEAR / INTER_NEAREST restated; parity against
+    cv2 itself is unpinned): integer results, compared exactly -- uint8 fixed-point path, uint16 float path, the 2x2 area
+    fast path (640x1920), identity (320x960) and ragged source sizes."""
+    from heatnet_amd import augment
+    from oracle import thermal_resize_ref as T
+    h0, w0 = src
+    rgb, ir, lab = _sample_batch(2, h0, w0, seed=h0 + w0)
+    got_rgb, got_ir, got_lab = augment.resize_crop(torch.from_numpy(rgb).to(dev), torch.from_numpy(ir).to(dev),
+                                                   torch.from_numpy(lab).to(dev), cols=cols)
+    assert got_rgb.shape == (2, 320, cols[1] - cols[0], 3) and got_ir.shape == (2, 320, cols[1] - cols[0])
+    for k in range(2):
+        er, ei, el = T.prepare_sample(rgb[k], ir[k], lab[k], cols=cols)
+        assert np.array_equal(got_rgb[k].cpu().numpy(), er)
+        assert np.array_equal(got_ir[k].cpu().numpy().astype(np.uint16), ei)
+        assert np.array_equal(got_lab[k].cpu().numpy(), el)
+
+
+def test_validation_loader_batch(dev):
+    """augment.val_batch == ThermalTestDataLoader.__getitem__ after decoding (cm/thermal_loader.py:777-814), restated in
+    oracle/thermal_resize_ref.py: 960x320, columns 148:852, thermal clip / scale, /255, (x - 0.5) / 0.5."""
+    from heatnet_amd import augment
+    from oracle import thermal_resize_ref as T
+    rgb, ir, lab = _sample_batch(3, 650, 1920, seed=77)
+    out = augment.val_batch(torch.from_numpy(rgb).to(dev), torch.from_numpy(ir).to(dev), torch.from_numpy(lab).to(dev))
+    assert out["rgb"].shape == (3, 3, 320, 704) and out["ir"].shape == (3, 1, 320, 704) and out["label"].dtype == torch.int64
+    for k in range(3):
+        er, ei, el = T.prepare_sample(rgb[k], ir[k], lab[k], cols=(148, 852))
+        r, r_org, i, i_org = T.val_tensors(er, ei)
+        assert np.array_equal(out["label"][k].cpu().numpy(), el.astype(np.int64))
+        assert np.array_equal(out["rgb"][k].cpu().numpy(), r)
+        assert np.array_equal(out["rgb_org"][k].cpu().numpy(), r_org)
+        assert np.abs(out["ir"][k].cpu().numpy() - i).max() <= 2.5e-7
+        assert np.abs(out["ir_org"][k].cpu().numpy() - i_org).max() <= 1.2e-7
+
+
+def test_resize_rejects_bad_windows(dev):
+    from heatnet_amd import augment
+    rgb, ir, lab = _sample_batch(1, 64, 96, seed=1)
+    with pytest.raises(RuntimeError, match="hn_thermal_resize"):
+        augment.resize_crop(torch.from_numpy(rgb).to(dev), torch.from_numpy(ir).to(dev), None, cols=(900, 1000))
