@@ -115,7 +115,7 @@ def test_validation_loader_batch(dev):
         r, r_org, i, i_org = T.val_tensors(er, ei)
         assert np.array_equal(out["label"][k].cpu().numpy(), el.astype(np.int64))
         assert np.array_equal(out["rgb"][k].cpu().numpy(), r)
-        assert np.array_equal(out["rgb_org"][k].cpu().numpy(), r_org)
+        assert np.abs(out["rgb_org"][k].cpu().numpy() - r_org).max() <= 6e-8  # display copy: a stock-torch division
         assert np.abs(out["ir"][k].cpu().numpy() - i).max() <= 2.5e-7
         assert np.abs(out["ir_org"][k].cpu().numpy() - i_org).max() <= 1.2e-7
 
