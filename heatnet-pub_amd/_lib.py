@@ -47,6 +47,8 @@ SIGNATURES = {
     "hn_act_bwd": [P, c_int, P, c_int, P, c_int, c_i64, c_int, c_int, c_float, P],
     "hn_scale_nc": [P, c_int, P, P, c_int, c_int, c_i64, c_int, P],
     "hn_add": [P, c_int, P, c_int, P, c_int, c_i64, c_int, P],
+    "hn_dropout_mask": [P, c_int, c_float, ctypes.c_uint64, P],
+    "hn_nchw_to_nhwc": [P, P, c_int, c_int, c_i64, c_int, P],
     "hn_copy": [P, c_int, P, c_int, c_i64, c_int, P],
     "hn_maxpool3x3s2_fwd": [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_maxpool3x3s2_bwd": [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],

@@ -320,6 +320,7 @@ int launch_conv2(const ConvArgs& a, bool tall, bool wide, int ns, hipStream_t st
         return launch2_tile<3, 32>(a, tall, wide, stream);
     }
     if (ns == MATH2_BF16) {
+        // (K step 128 -- half the barriers -- measured 15-30 % slower: 192 staging registers per producer thread)
         if (a.C % 64 == 0) return launch2_tile<1, 64>(a, tall, wide, stream);
         if (a.C % 32 == 0) return launch2_tile<1, 32>(a, tall, wide, stream);
         return 1;

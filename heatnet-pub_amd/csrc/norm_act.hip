@@ -599,6 +599,60 @@ extern "C" int hn_add(const float* a, int lda, const float* b, int ldb, float* y
     return HN_OK;
 }
 
+namespace {
+// nn.Dropout2d's per-(image, channel) factors: 0 with probability p, else 1/(1-p).  Counter-based generator (two rounds
+// of a 64-bit mix of seed and element index): the mask of a step is a pure function of (seed, index).
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ mask, int n, float p, float keep_scale,
+                                                          unsigned long long seed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);  // 24 random bits -> [0, 1)
+    mask[i] = u < p ? 0.f : keep_scale;
+}
+
+// logical NCHW tensor stored channel-planar (torch's default layout) -> NHWC: tiles of 32 pixels x C channels through LDS
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int64_t hw,
+                                                          int ldy) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int64_t p0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {  // r = channel inside the tile, tx = pixel
+        const int c = c0 + r;
+        const int64_t p = p0 + tx;
+        tile[r][tx] = (c < C && p < hw) ? x[((int64_t)n * C + c) * hw + p] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {  // r = pixel, tx = channel
+        const int c = c0 + tx;
+        const int64_t p = p0 + r;
+        if (c < C && p < hw) y[((int64_t)n * hw + p) * ldy + c] = tile[tx][r];
+    }
+}
+}  // namespace
+
+extern "C" int hn_dropout_mask(float* mask, int n, float p, uint64_t seed, void* stream) {
+    if (!mask || n <= 0 || !(p >= 0.f) || !(p < 1.f)) return HN_EINVAL;
+    HN_LAUNCH(dropout_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), mask, n, p,
+              1.0f / (1.0f - p), (unsigned long long)seed);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_nchw_to_nhwc(const float* x, float* y, int N, int C, int64_t hw, int ldy, void* stream) {
+    if (!x || !y || N <= 0 || C <= 0 || hw <= 0 || ldy < C) return HN_EINVAL;
+    if ((hw + 31) / 32 > 0x7fffffffll || N > 65535 || (C + 31) / 32 > 65535) return HN_ESHAPE;
+    HN_LAUNCH(nchw_to_nhwc_kernel, dim3((unsigned)((hw + 31) / 32), (C + 31) / 32, N), dim3(256), 0,
+              static_cast<hipStream_t>(stream), x, y, C, hw, ldy);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
 extern "C" int hn_copy(const float* x, int ldx, float* y, int ldy, int64_t npix, int C, void* stream) {
     if (!x || !y || bad_rows(npix, C, {ldx, ldy})) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);

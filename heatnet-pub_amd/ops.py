@@ -65,10 +65,14 @@ def as_nhwc(t):
     _require_gpu(t)
     ld = nhwc_ld(t)
     if ld is None:
+        n, c, h, w = t.shape
+        if t.is_contiguous() and not (torch.is_grad_enabled() and t.requires_grad):  # plain NCHW: our own transposing kernel
+            out = new_nhwc(n, c, h, w, t.device)
+            check(_lib.load().hn_nchw_to_nhwc(_ptr(t), _ptr(out), n, c, h * w, c, _stream()), "hn_nchw_to_nhwc")
+            return out, c
         t = t.contiguous(memory_format=torch.channels_last)
         ld = nhwc_ld(t)
         if ld is None:  # degenerate sizes for which torch reports ambiguous strides
-            n, c, h, w = t.shape
             t = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
             ld = c
     return t, ld
@@ -85,6 +89,11 @@ def weight_ohwi(w):
     expect = (kh * kw * i, 1, kw * i, i)
     ok = all(w.shape[d] == 1 or w.stride(d) == expect[d] for d in range(4))
     if not ok:
+        if kh == 1 and kw == 1 and w.stride(1) == 1 and w.stride(0) >= i and not (torch.is_grad_enabled() and w.requires_grad):
+            # an input-channel slice of a wider 1x1 weight (the pyramid bottleneck's columns): rows of i floats, stride ld
+            out = torch.empty((o, 1, 1, i), device=w.device, dtype=w.dtype).permute(0, 3, 1, 2)
+            check(_lib.load().hn_copy(_ptr(w), w.stride(0), _ptr(out), i, o, i, _stream()), "hn_copy")
+            return out
         w = w.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
     return w
 
@@ -818,8 +827,13 @@ def concat_batch(xs):
 
 
 def drop_mask(n, c, p, device):
-    """nn.Dropout2d's per-(image, channel) factor: 0 with probability p, else 1/(1-p)."""
-    return torch.bernoulli(torch.full((n, c), 1.0 - p, device=device, dtype=torch.float32)) / (1.0 - p)
+    """nn.Dropout2d's per-(image, channel) factor: 0 with probability p, else 1/(1-p).  Drawn by hn_dropout_mask from a
+    64-bit seed taken from torch's CPU generator (so torch.manual_seed reproduces a run)."""
+    mask = torch.empty((n, c), device=device, dtype=torch.float32)
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    check(_lib.load().hn_dropout_mask(_ptr(mask), n * c, float(p), ctypes.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), _stream()),
+          "hn_dropout_mask")
+    return mask
 
 
 # ------------------------------------------------------------------------------------------------------

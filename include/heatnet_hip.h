@@ -234,6 +234,14 @@ int hn_act_bwd(const float* dy, int lddy, const float* out, int ldo, float* dx, 
  * keep/(1-p) mask, cm/models/pspnet.py:49,55,63-72. */
 int hn_scale_nc(const float* x, int ldx, const float* mask, float* y, int ldy, int N, int64_t hw, int C, void* stream);
 
+/* mask[i] = 0 with probability p, else 1/(1-p), i < n = N*C: the Dropout2d factors hn_bn_act_fwd / hn_scale_nc take, drawn on
+ * the device by a counter-based generator (a pure function of seed and i). */
+int hn_dropout_mask(float* mask, int n, float p, uint64_t seed, void* stream);
+
+/* Layout conversion at the network boundary: x [N][C][hw] (torch's default contiguous NCHW) -> y [N][hw] pixels of ldy
+ * floats (NHWC), what callers hand to the first convolutions (scripts/main.py:238-244 feeds NCHW batches). */
+int hn_nchw_to_nhwc(const float* x, float* y, int N, int C, int64_t hw, int ldy, void* stream);
+
 /* y = a + b (elementwise over npix x C): gradient accumulation where two branches meet. */
 int hn_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int64_t npix, int C, void* stream);
 

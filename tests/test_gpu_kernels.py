@@ -721,3 +721,25 @@ def test_weighted_cross_entropy_and_teacher_certainty(dev):
     loss.backward()
     assert abs(loss.item() - loss_ref.item()) < 1e-5
     close(ld.grad, lr.grad, atol=1e-7, rtol=1e-4, what="dlogits")
+
+
+def test_dropout_mask_and_layout_conversion(dev):
+    """hn_dropout_mask: factors in {0, 1/(1-p)}, keep rate ~ 1-p, reproducible from torch's CPU seed; hn_nchw_to_nhwc: a
+    plain NCHW batch reaches the kernels through our own transposing kernel, values unchanged."""
+    ops = _ops()
+    torch.manual_seed(123)
+    m1 = ops.drop_mask(64, 1024, 0.3, dev)
+    torch.manual_seed(123)
+    m2 = ops.drop_mask(64, 1024, 0.3, dev)
+    assert torch.equal(m1, m2)
+    vals = torch.unique(m1).cpu()
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1.0 / 0.7) < 1e-6
+    keep = float((m1 > 0).float().mean())
+    assert abs(keep - 0.7) < 0.01, keep
+    assert abs(float((m1 > 0).float().mean(1).std()) - np.sqrt(0.21 / 1024)) < 0.005  # rows are independent draws
+    x = rnd(3, 5, 7, 11, seed=90).to(dev)  # NCHW-contiguous, odd sizes
+    t, ld = ops.as_nhwc(x)
+    assert ld == 5 and t.stride(1) == 1 and torch.equal(t.contiguous(), x)
+    x = rnd(2, 64, 33, 47, seed=91).to(dev)
+    t, ld = ops.as_nhwc(x)
+    assert torch.equal(t.contiguous(), x)
