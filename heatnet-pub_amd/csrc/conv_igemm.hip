@@ -555,7 +555,7 @@ void plan_name(const ConvPlan& pl, char* buf, int n) {
     const int tm = pl.tall ? 2 : 1, tn = pl.wide ? 2 : 1;
     if (pl.family == FAM_V2) snprintf(buf, n, "conv_igemm2_kernel<%d, %d, %d, %d, false>", tm, tn, pl.math, pl.bk);
     else if (pl.math == MATH_X3) snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 1>", tm, tn, pl.mode, pl.bk);
-    else snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d>", tm, tn, pl.mode, pl.bk);
+    else snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 0>", tm, tn, pl.mode, pl.bk);
 }
 
 // Split-K plan: K steps (of 32) per split, or 0.  Used when the output has so few tiles that the chip would idle

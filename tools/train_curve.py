@@ -1,5 +1,6 @@
 """Diagnostic (GPU box): the same 30 RMSprop iterations (fixed mini-batch, Dropout off) on the CPU oracle, on the HIP path
-under the fp32-MFMA arithmetic and under bf16x3 -- do the three loss curves track each other?
+under the fp32-MFMA arithmetic, under bf16x3 and under the mixed-precision bf16 arithmetic (configs[4]) -- do the loss
+curves track each other?
 
 usage: python tools/train_curve.py [steps]"""
 import os
@@ -34,7 +35,7 @@ def main():
         loss.backward()
         opt.step()
         curves["cpu fp32 oracle"].append(float(loss.detach()))
-    for math in ("f32", "bf16x3"):
+    for math in ("f32", "bf16x3", "bf16"):
         ops.set_conv_math(math)
         net = PSPNet(backend="resnet50", pretrained=False, late_fusion=True, in_channels=4)
         net.load_state_dict(state)
@@ -44,10 +45,11 @@ def main():
         d = [t.to(dev) for t in (rgb, ir, lab)]
         curves["hip " + math] = [float(train_step.segmentation_step(net, opt, d[0], d[1], d[2])) for _ in range(steps)]
     names = list(curves)
-    print("step  " + "  ".join("%-16s" % n for n in names) + "  |hip f32 - cpu|  |hip bf16x3 - cpu|")
+    print("step  " + "  ".join("%-16s" % n for n in names) + "  |hip f32 - cpu|  |hip bf16x3 - cpu|  |hip bf16 - cpu|")
     for i in range(steps):
         v = [curves[n][i] for n in names]
-        print("%4d  " % i + "  ".join("%-16.6f" % x for x in v) + "  %.2e        %.2e" % (abs(v[1] - v[0]), abs(v[2] - v[0])))
+        print("%4d  " % i + "  ".join("%-16.6f" % x for x in v) + "  %.2e        %.2e           %.2e"
+              % (abs(v[1] - v[0]), abs(v[2] - v[0]), abs(v[3] - v[0])))
 
 
 if __name__ == "__main__":
