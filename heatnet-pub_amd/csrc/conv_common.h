@@ -134,10 +134,10 @@ __device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[T
 // The bias is loaded unconditionally (clamped index) and folded in BEFORE any store is issued, and full tiles take a
 // branch-free path: a conditional load inside the store loop makes hipcc wait vmcnt(0) -- i.e. for the previous store --
 // in front of every store.
-template <int TM, int TN, bool S16>
+template <int TM, int TN, bool S16, int BM = 64 * TM, int BN = 64 * TN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], const AccMap<TM, TN, S16>& am,
                                               const int* rowinfo, int m0, int tile_m, int split) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, NC = AccMap<TM, TN, S16>::NC;
+    constexpr int NC = AccMap<TM, TN, S16>::NC;
     const int lane = am.lane, n0 = am.n0;
     if (p.cps > 0) {  // split-K partial
 #pragma unroll

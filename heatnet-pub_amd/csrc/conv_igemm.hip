@@ -57,23 +57,29 @@ enum : int { MATH_F32 = 0, MATH_X3 = 1 };
 
 // STRIDED = the gathered tensor is "dilated" by in_dil > 1 (data gradient of a strided convolution): taps must
 // land on multiples of in_dil.  Kept out of the common instantiation because it costs integer divisions per tap.
-template <int TM, int TN, int MODE, int BK, int MATH = MATH_F32>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
-    constexpr int LDK = KStep<BK>::LDK, PR = KStep<BK>::PR, VROWS = KStep<BK>::VROWS, SROWS = KStep<BK>::SROWS;
+// WN = waves along the column (output channel) axis: 2 -> four waves in a 2 x 2 grid, block tile 64*TM x 64*TN, two
+// workgroups per CU; 4 (bf16x3 only) -> EIGHT waves in a 2 x 4 grid, block tile 64*TM x 128*TN (128 x 256), ONE workgroup
+// per CU whose eight waves run the split/store and MFMA phases in lockstep: the A operand is split once per 256 output
+// columns (half the split arithmetic per MFMA) and every SIMD's MFMA phase is two waves long against one staging phase.
+template <int TM, int TN, int MODE, int BK, int MATH = MATH_F32, int WN = 2>
+__global__ __launch_bounds__(128 * WN, 2) void conv_igemm_kernel(const ConvArgs p) {
+    constexpr int NT = 128 * WN;  // threads
+    constexpr int LDK = KStep<BK>::LDK, PR = KStep<BK>::PR, VROWS = NT / PR, SROWS = NT / BK;
     constexpr bool VEC = MODE >= MODE_VEC;
     constexpr bool STRIDED = MODE == MODE_SCALAR_STRIDED || MODE == MODE_VEC_STRIDED;
     constexpr bool BUF = MODE == MODE_VEC_BUF;
     constexpr bool X3 = MATH == MATH_X3;
     constexpr bool S16 = X3;  // bf16x3 runs on v_mfma_f32_16x16x32_bf16: accumulators hold 16x16 sub-blocks (acc_row / acc_col)
     static_assert(!X3 || (BUF && BK == 32), "bf16x3 math is built for the buffer loaders at K step 32");
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+    static_assert(WN == 2 || X3, "the eight-wave tile exists for the bf16x3 arithmetic only");
+    constexpr int BM = 64 * TM, BN = 32 * WN * TN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                        // f32: [2][BM][LDK]     bf16x3: [3][BM][X3_ROW bytes]
     float* Bs = smem + (X3 ? 3 * BM * X3_ROW / 4 : 2 * BM * LDK);  // f32: [2][BN][LDK]  bf16x3: [3][BN][X3_ROW bytes]
     int* rowinfo = reinterpret_cast<int*>(Bs + (X3 ? 3 * BN * X3_ROW / 4 : 2 * BN * LDK));  // [BM][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int logical = hn_xcd_remap(blockIdx.x, gridDim.x);
     const int ntiles = p.ntm * p.ntn;
     const int split = logical / ntiles, tile = logical - split * ntiles;
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     // ---- operand staging -------------------------------------------------------------------------------
     constexpr int RA = VEC ? BM / VROWS : BM / SROWS;
     // bf16x3 stages B from the pre-split planes: BN rows x 3 planes x 4 pieces of 16 B (8 bf16) per K step
-    constexpr int RB = X3 ? BN * 12 / 256 : (VEC ? BN / VROWS : BN / SROWS);
+    constexpr int RB = X3 ? BN * 12 / NT : (VEC ? BN / VROWS : BN / SROWS);
     f32x4 va[VEC ? RA : 1], vb[VEC ? RB : 1];
     f32x4 va1[X3 ? RA : 1], vb1[X3 ? RB : 1];  // bf16x3: second staging set (two K steps of loads in flight)
     float sa[VEC ? 1 : RA], sb[VEC ? 1 : RB];
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
             rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.wx3), 0, b_records, 0x00020000);
 #pragma unroll
             for (int q = 0; q < RB; ++q) {
-                const int id = tid + 256 * q, plane = id / (BN * 4), rem = id % (BN * 4);
+                const int id = tid + NT * q, plane = id / (BN * 4), rem = id % (BN * 4);
                 const int co = n0 + (rem >> 2);
                 boff32[q] = co < p.K ? (unsigned)((plane * p.wx3_plane + (long long)co * p.Kdim + (rem & 3) * 8) * 2)
                                      : b_records;  // rows past Cout: out of range -> zero-filled
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
             }
 #pragma unroll
             for (int q = 0; q < RB; ++q) {  // already split: piece id -> (plane, row, 16-B piece), see boff32
-                const int id = tid + 256 * q;
+                const int id = tid + NT * q;
                 *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Bs) + (id >> 2) * X3_ROW +
                                           ((id & 3) ^ x3_kflip(id >> 2)) * 16) = svb[q];
             }
@@ -428,16 +434,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     k_step(kc & 1, std::false_type{}, std::false_type{});
     }
 
-    conv_epilogue<TM, TN, S16>(p, acc, am, rowinfo, m0, tile_m, split);
+    conv_epilogue<TM, TN, S16, BM, BN>(p, acc, am, rowinfo, m0, tile_m, split);
 }
 
-template <int TM, int TN, int MODE, int BK, int MATH = MATH_F32>
+template <int TM, int TN, int MODE, int BK, int MATH = MATH_F32, int WN = 2>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int BM = 64 * TM, BN = 32 * WN * TN;
     constexpr int lds = MATH != MATH_F32 ? 3 * (BM + BN) * X3_ROW + BM * 16
                                         : (2 * (BM + BN) * KStep<BK>::LDK + BM * 4) * (int)sizeof(float);
     static std::atomic<unsigned long long> configured{0};
-    if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_kernel<TM, TN, MODE, BK, MATH>), lds, configured) != HN_OK)
+    if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_kernel<TM, TN, MODE, BK, MATH, WN>), lds, configured) != HN_OK)
         return HN_ELAUNCH;
     ConvArgs p = a;
     p.ntm = (a.M + BM - 1) / BM;
@@ -453,13 +459,16 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
         p.cps = a.cps * 32 / BK;
         splits = (total + p.cps - 1) / p.cps;
     }
-    HN_LAUNCH((conv_igemm_kernel<TM, TN, MODE, BK, MATH>), dim3(p.ntm * p.ntn * splits), dim3(256), lds, stream, p);
+    HN_LAUNCH((conv_igemm_kernel<TM, TN, MODE, BK, MATH, WN>), dim3(p.ntm * p.ntn * splits), dim3(128 * WN), lds, stream, p);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
 
 template <int MODE, int BK, int MATH = MATH_F32>
-int dispatch_tile(const ConvArgs& a, bool tall, bool wide, hipStream_t stream) {
+int dispatch_tile(const ConvArgs& a, bool tall, bool wide, hipStream_t stream, int wn = 2) {
+    if constexpr (MATH == MATH_X3) {
+        if (wn == 4) return launch_conv<2, 2, MODE, BK, MATH, 4>(a, stream);  // 128 x 256, eight waves
+    }
     if (tall) return wide ? launch_conv<2, 2, MODE, BK, MATH>(a, stream) : launch_conv<2, 1, MODE, BK, MATH>(a, stream);
     return wide ? launch_conv<1, 2, MODE, BK, MATH>(a, stream) : launch_conv<1, 1, MODE, BK, MATH>(a, stream);
 }
@@ -472,6 +481,7 @@ enum : int { FAM_V1 = 0, FAM_V2 = 1 };
 struct ConvPlan {
     int family;      // FAM_V1: conv_igemm_kernel (this file); FAM_V2: conv_igemm2_kernel (conv_igemm2.hip)
     bool tall, wide;
+    int wn;          // FAM_V1 bf16x3: 4 = the eight-wave 128 x 256 tile (tn_sel 3), else 2
     int mode, bk;    // FAM_V1: loader variant and K step
     int math;        // FAM_V1: MATH_F32 / MATH_X3; FAM_V2: bf16 planes per operand (3 = bf16x3, 1 = bf16)
 };
@@ -480,16 +490,16 @@ struct ConvPlan {
 //   math_sel 1 -> fp32 MFMA, 2 -> bf16x3, 3 -> bf16 (0: library default, hn_set_conv_math)
 //   bk_sel   fp32 MFMA: 1 -> K step 32, 2 -> 16.  bf16x3: 1 -> first schedule (two workgroups per CU, phases
 //            separated by barriers), 2 -> second schedule (producer / consumer waves, conv_igemm2.hip); 0 = the first.
-//   tm_sel / tn_sel 1 -> 64-wide, 2 -> 128-wide tile side.
+//   tm_sel / tn_sel 1 -> 64-wide, 2 -> 128-wide tile side; tn_sel 3 (bf16x3, first schedule): the 128 x 256 eight-wave tile.
 // Within one math mode all variants give bitwise identical results: the per-element accumulation order does not depend
 // on the tiling or the schedule.
 int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
     if (variant < 0 || variant >= 256) return HN_EINVAL;
     const int bk_sel = variant & 3, tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3, math_sel = variant >> 6;
-    if (bk_sel == 3 || tm_sel == 3 || tn_sel == 3) return HN_EINVAL;
+    if (bk_sel == 3 || tm_sel == 3) return HN_EINVAL;
     const bool vec = (a.C % 32 == 0) && (a.ldx % 4 == 0) && hn_aligned16(a.x) && hn_aligned16(a.w);
     bool wide = a.K > 64;
-    if (tn_sel) wide = tn_sel == 2;
+    if (tn_sel) wide = tn_sel >= 2;
     const long blocks128 = (long)((a.M + 127) / 128) * ((a.K + (wide ? 127 : 63)) / (wide ? 128 : 64));
     bool tall = blocks128 >= 256;  // enough 128-row tiles to cover the chip; else halve the tile
     if (tm_sel) tall = tm_sel == 2;
@@ -506,6 +516,7 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
                            a.wx3_plane % 8 == 0 && 6 * a.wx3_plane < (1ll << 32);
     pl.tall = tall;
     pl.wide = wide;
+    pl.wn = 2;
     pl.bk = 32;
     if (math == HN_MATH_BF16 && planes_ok) {
         pl.family = FAM_V2; pl.math = MATH2_BF16; pl.mode = MODE_VEC_BUF;
@@ -515,7 +526,10 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
         // default: the first schedule -- measured 2-10 % faster than the wave-specialised one on every layer shape of the
         // network (profiles/r02_conv_schedules.txt)
         if (bk_sel == 2) { pl.family = FAM_V2; pl.math = MATH2_X3; }
-        else { pl.family = FAM_V1; pl.math = MATH_X3; }
+        else {
+            pl.family = FAM_V1; pl.math = MATH_X3;
+            if (tn_sel == 3 && a.cps == 0) { pl.wn = 4; pl.tall = pl.wide = true; }  // 128 x 256 tile, eight waves
+        }
     } else {
         pl.family = FAM_V1; pl.math = MATH_F32;
         if (vec && !strided && buf_ok) { pl.mode = MODE_VEC_BUF; pl.bk = bk_sel == 2 ? 16 : 32; }
@@ -531,7 +545,7 @@ int run_conv(const ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
         const int rc = launch_conv2(a, pl.tall, pl.wide, pl.math, stream);
         return rc == 1 ? HN_ESHAPE : rc;
     }
-    if (pl.math == MATH_X3) return dispatch_tile<MODE_VEC_BUF, 32, MATH_X3>(a, pl.tall, pl.wide, stream);
+    if (pl.math == MATH_X3) return dispatch_tile<MODE_VEC_BUF, 32, MATH_X3>(a, pl.tall, pl.wide, stream, pl.wn);
     switch (pl.mode) {
         case MODE_VEC_BUF:
             return pl.bk == 16 ? dispatch_tile<MODE_VEC_BUF, 16>(a, pl.tall, pl.wide, stream)
@@ -554,8 +568,8 @@ int dispatch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
 void plan_name(const ConvPlan& pl, char* buf, int n) {
     const int tm = pl.tall ? 2 : 1, tn = pl.wide ? 2 : 1;
     if (pl.family == FAM_V2) snprintf(buf, n, "conv_igemm2_kernel<%d, %d, %d, %d, false>", tm, tn, pl.math, pl.bk);
-    else if (pl.math == MATH_X3) snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 1>", tm, tn, pl.mode, pl.bk);
-    else snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 0>", tm, tn, pl.mode, pl.bk);
+    else if (pl.math == MATH_X3) snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 1, %d>", tm, tn, pl.mode, pl.bk, pl.wn);
+    else snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 0, 2>", tm, tn, pl.mode, pl.bk);
 }
 
 // Split-K plan: K steps (of 32) per split, or 0.  Used when the output has so few tiles that the chip would idle
