@@ -26,7 +26,11 @@ def weights_init_normal(m):
 def create_critic(disc_arch, input_num):
     if disc_arch == "cyclegan":
         return FCDiscriminator(input_num)
-    raise NotImplementedError("critic architecture %r is outside the MI355X hot path (only 'cyclegan')" % disc_arch)
+    # cm/models/critic_resnet.py: a ResNet with a one-logit fc head.  Its [N, 1] output cannot pass the trainer's own
+    # train_seg phase (`c_a.size(2)` at cm/train_trgb_segnet_conf.py:534 raises IndexError -- verified by running the
+    # reference), so only the fully-convolutional critic is a working configuration of the path.
+    raise NotImplementedError("critic architecture %r: only 'cyclegan' (FCDiscriminator) is built; the reference's ResNet "
+                              "critics cannot complete its own train_seg phase (2-D critic output)" % disc_arch)
 
 
 class conv_segnet(nn.Module):
@@ -35,8 +39,13 @@ class conv_segnet(nn.Module):
         super().__init__()
         if arch != "pspnet":
             raise NotImplementedError("arch=%r: only the PSPNet path is built for MI355X" % arch)
-        if input_adapter or cert_branch:
-            raise NotImplementedError("input_adapter / cert_branch are outside the MI355X hot path")
+        if input_adapter:
+            # cm/models/conf_segnet.py:108-112 hands the [rgb, ir] LIST to the UNet adapter: with arch='pspnet' the
+            # reference raises TypeError in its first conv (verified by running it); there is nothing to be compatible with
+            raise NotImplementedError("input_adapter: the reference's adapter takes a single tensor (arch='custom'); with the "
+                                      "PSPNet path's [rgb, ir] inputs its own forward raises TypeError")
+        if cert_branch:
+            raise NotImplementedError("cert_branch belongs to the ResNeXt 'custom' arch (PSPNet returns cert = None)")
         num_input_channels = (3 if "rgb" in modalities else 0) + (1 if "ir" in modalities else 0)
         self.trgb_segnet = build_net.build_network(None, "resnet50", in_channels=num_input_channels,
                                                    late_fusion=late_fusion)
