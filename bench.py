@@ -289,6 +289,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timing under the other conv arithmetic")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the extra timings of the bf16 and confusion-maximisation workloads (default run, N=1, seg only)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -385,6 +387,46 @@ def main():
                    "ms_per_step": round(1e3 * alt_elapsed / args.steps, 3), "steps": args.steps, "roofline": alt_roof}
         finally:
             ops.set_conv_math(main_math)
+    others = None
+    if world == 1 and args.workload == "seg" and not args.no_other_workloads:
+        # the other BASELINE configurations, timed in the same process so that one default run records them all (N=1
+        # only; reference figures beside the headline, never part of `value`): configs[4] = the same step under the
+        # mixed-precision bf16 arithmetic, configs[2] = the two confusion-maximisation iterations (an image = a pair)
+        others = {}
+        n_other = max(2, min(args.steps, 10))
+
+        def timed(fn, images):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n_other):
+                fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            return {"value": round(images * n_other / dt, 3), "ms_per_step": round(1e3 * dt / n_other, 3), "steps": n_other}
+
+        main_math = ops.set_conv_math("bf16")
+        try:
+            others["seg_bf16"] = dict(timed(step, args.batch), unit="images/s", dtype="bf16",
+                                      workload="configs[4] arithmetic: the configs[1] step on the mixed-precision bf16 conv path")
+        finally:
+            ops.set_conv_math(main_math)
+        del step, opt, arenas, model
+        torch.cuda.empty_cache()
+        for wl in ("confmax_seg", "confmax_critic"):
+            if min(args.height, args.width) < 256:
+                break  # the critics' five stride-2 convolutions need >= 32 pixels at 1/8 scale
+            m2 = build(wl, dev)
+            a2 = optim.arenas_for(m2)
+            o2 = optim.FlatRMSprop(a2, lr=1e-4)
+            s2 = make_step(wl, m2, o2, batch, None)
+            s2()  # priming (kernel-variant lookups, allocator growth)
+            others[wl] = dict(timed(s2, args.batch), unit="pairs/s", dtype="f32",
+                              workload="configs[2]: confusion-maximisation %s iteration (day+night passes, 6 critics)"
+                                       % ("train_seg" if wl == "confmax_seg" else "train_critic"))
+            del s2, o2, a2, m2
+            torch.cuda.empty_cache()
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline(args.workload)
@@ -403,7 +445,7 @@ def main():
                           "width": args.width,
                           "parallelism": "dp%d" % world, "optimizer": "RMSprop lr=1e-4 (fused, flat arena)", "weights": "random init",
                           "conv_math": CONV_MATH_NOTE[ops.CONV_MATH]},
-               "roofline": roof, "cpu_baseline": base, "alt_conv_math": alt}
+               "roofline": roof, "cpu_baseline": base, "alt_conv_math": alt, "other_workloads": others}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -23,7 +23,7 @@ def test_bench_prints_one_contract_line():
     assert len(lines) == 1, out.stdout[-2000:]
     j = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "alt_conv_math"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "alt_conv_math", "other_workloads"):
         assert key in j, key
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True
     assert j["scaling"] == "weak" and j["unit"] == "images/s" and j["data"] == "synthetic" and j["vs_baseline"] is None
@@ -39,6 +39,8 @@ def test_bench_prints_one_contract_line():
     assert j["cpu_baseline"] is None  # --no-cpu-baseline
     alt = j["alt_conv_math"]
     assert alt["conv_math"] in ("f32", "bf16x3") and alt["conv_math"] != r["conv_math"] and alt["value"] > 0
+    ow = j["other_workloads"]  # configs[4] arithmetic always; configs[2] only from 256 x 256 up (critics)
+    assert ow["seg_bf16"]["dtype"] == "bf16" and ow["seg_bf16"]["value"] > 0 and "confmax_seg" not in ow
 
 
 def test_bench_self_launches_its_workers():
