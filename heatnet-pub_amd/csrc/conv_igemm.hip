@@ -477,9 +477,9 @@ bool g_deterministic = false;  // hn_set_deterministic: no split-K float atomics
 int g_conv_math = 0;  // HN_MATH_* default for variant codes that leave the math field 0 (hn_set_conv_math)
 
 // What a launch will run: the kernel family, its tile and arithmetic.
-enum : int { FAM_V1 = 0, FAM_V2 = 1 };
+enum : int { FAM_V1 = 0, FAM_V2 = 1, FAM_V3 = 2 };
 struct ConvPlan {
-    int family;      // FAM_V1: conv_igemm_kernel (this file); FAM_V2: conv_igemm2_kernel (conv_igemm2.hip)
+    int family;      // FAM_V1: conv_igemm_kernel (this file); FAM_V2: conv_igemm2_kernel (conv_igemm2.hip); FAM_V3: conv_igemm3_kernel
     bool tall, wide;
     int wn;          // FAM_V1 bf16x3: 4 = the eight-wave 128 x 256 tile (tn_sel 3), else 2
     int mode, bk;    // FAM_V1: loader variant and K step
@@ -489,14 +489,15 @@ struct ConvPlan {
 // variant: 0 = heuristics; otherwise (bk_sel) + 4 * (tm_sel) + 16 * (tn_sel) + 64 * (math_sel).
 //   math_sel 1 -> fp32 MFMA, 2 -> bf16x3, 3 -> bf16 (0: library default, hn_set_conv_math)
 //   bk_sel   fp32 MFMA: 1 -> K step 32, 2 -> 16.  bf16x3: 1 -> first schedule (two workgroups per CU, phases
-//            separated by barriers), 2 -> second schedule (producer / consumer waves, conv_igemm2.hip); 0 = the first.
+//            separated by barriers), 2 -> second schedule (producer / consumer waves, conv_igemm2.hip), 3 -> third
+//            schedule (128 x 256 tile, weights by LDS-DMA, conv_igemm3.hip; where it does not cover: the first); 0 = the first.
 //   tm_sel / tn_sel 1 -> 64-wide, 2 -> 128-wide tile side; tn_sel 3 (bf16x3, first schedule): the 128 x 256 eight-wave tile.
 // Within one math mode all variants give bitwise identical results: the per-element accumulation order does not depend
 // on the tiling or the schedule.
 int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
     if (variant < 0 || variant >= 256) return HN_EINVAL;
     const int bk_sel = variant & 3, tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3, math_sel = variant >> 6;
-    if (bk_sel == 3 || tm_sel == 3) return HN_EINVAL;
+    if (tm_sel == 3) return HN_EINVAL;
     const bool vec = (a.C % 32 == 0) && (a.ldx % 4 == 0) && hn_aligned16(a.x) && hn_aligned16(a.w);
     bool wide = a.K > 64;
     if (tn_sel) wide = tn_sel >= 2;
@@ -526,6 +527,7 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
         // default: the first schedule -- measured 2-10 % faster than the wave-specialised one on every layer shape of the
         // network (profiles/r02_conv_schedules.txt)
         if (bk_sel == 2) { pl.family = FAM_V2; pl.math = MATH2_X3; }
+        else if (bk_sel == 3 && conv3_covers(a)) { pl.family = FAM_V3; pl.math = MATH_X3; pl.tall = pl.wide = true; }
         else {
             pl.family = FAM_V1; pl.math = MATH_X3;
             if (tn_sel == 3 && a.cps == 0) { pl.wn = 4; pl.tall = pl.wide = true; }  // 128 x 256 tile, eight waves
@@ -541,6 +543,7 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
 }
 
 int run_conv(const ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
+    if (pl.family == FAM_V3) return launch_conv3(a, stream);
     if (pl.family == FAM_V2) {
         const int rc = launch_conv2(a, pl.tall, pl.wide, pl.math, stream);
         return rc == 1 ? HN_ESHAPE : rc;
@@ -567,7 +570,8 @@ int dispatch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
 // the kernel's name as rocprofv3 prints it (tools/pmc_aggregate.py keys), for per-instantiation accounting
 void plan_name(const ConvPlan& pl, char* buf, int n) {
     const int tm = pl.tall ? 2 : 1, tn = pl.wide ? 2 : 1;
-    if (pl.family == FAM_V2) snprintf(buf, n, "conv_igemm2_kernel<%d, %d, %d, %d, false>", tm, tn, pl.math, pl.bk);
+    if (pl.family == FAM_V3) snprintf(buf, n, "conv_igemm3_kernel");
+    else if (pl.family == FAM_V2) snprintf(buf, n, "conv_igemm2_kernel<%d, %d, %d, %d, false>", tm, tn, pl.math, pl.bk);
     else if (pl.math == MATH_X3) snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 1, %d>", tm, tn, pl.mode, pl.bk, pl.wn);
     else snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 0, 2>", tm, tn, pl.mode, pl.bk);
 }

@@ -367,14 +367,24 @@ def _tune_scratch(like):
     return buf
 
 
-def _igemm_candidates(cout, kind):
+# bf16x3 schedules offered to the tuner (HEATNET_X3_SCHEDULES=1,3 adds the LDS-DMA one: measured 140.7 / 141.0 images/s with
+# it against 141.2 / 141.5 without, profiles/r02_conv_schedules.txt run G -- so only the first by default)
+_X3_SCHEDULES = tuple(int(v) for v in os.environ.get("HEATNET_X3_SCHEDULES", "1").split(","))
+
+
+def _igemm_candidates(cout, kind, cred=0):
+    """Variant codes to time for an implicit-GEMM launch with `cout` output and `cred` reduction channels."""
     tiles = [(0, 0), (1, 2), (2, 1)] if cout > 64 else [(0, 0), (1, 1)]
     math = _MATH_CODES[_math(kind)]
     # the `bk` field: K step 32 / 16 of the fp32-MFMA kernels; schedule of the bf16x3 kernels (1 = two-phase,
     # conv_igemm.hip; 2 = wave-specialised, conv_igemm2.hip -- slower on every shape of this network, so it is not a
-    # tuning candidate); the bf16 kernels have one schedule
+    # tuning candidate; 3 = 128 x 256 tile with the weight planes by LDS-DMA, conv_igemm3.hip -- a few per cent faster on
+    # some of the 3x3 and wide 1x1 layers in isolation, slower on others, no gain over a step); the bf16 kernels have one
     bks = {"f32": (1, 2), "bf16x3": (1,), "bf16": (0,)}[_math(kind)]
-    return [_variant(bk, tm, tn, math) for tm, tn in tiles for bk in bks]
+    cands = [_variant(bk, tm, tn, math) for tm, tn in tiles for bk in bks]
+    if _math(kind) == "bf16x3" and 3 in _X3_SCHEDULES and cout >= 192 and cred % 32 == 0 and cred > 0:
+        cands.append(_variant(3, 0, 0, math))  # (conv3_covers; a launch it does not cover runs the first schedule)
+    return cands
 
 
 def _wgrad_candidates(cout, cin):
@@ -540,7 +550,7 @@ class _Conv2d(torch.autograd.Function):
             elif leaf is not None:
                 _prep_registry.touch(leaf, (stride, pad, dil), prep[1], prep[2], prep[3])
             _, wx3, ctx.wt, ctx.wtx3 = prep
-        var = _pick(_kind("fwd"), d, _igemm_candidates(cout, "fwd"), lambda v: check(
+        var = _pick(_kind("fwd"), d, _igemm_candidates(cout, "fwd", cin), lambda v: check(
             lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), None, ctypes.byref(d), act, slope, v, s),
             "hn_conv2d_fwd"))
         with _ConvTimer("fwd", d, lambda: _plan_name(0, d, wx3 is not None, var)):
@@ -596,7 +606,7 @@ class _Conv2d(torch.autograd.Function):
                                                    s), "hn_weight_flip_transpose")
             dx = new_nhwc(n, cin, h, wd, x.device)
             dd = _desc(n, h, wd, cin, cin, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
-            var = _pick(_kind("dgrad"), dd, _igemm_candidates(cin, "dgrad"), lambda v: check(
+            var = _pick(_kind("dgrad"), dd, _igemm_candidates(cin, "dgrad", cout), lambda v: check(
                 lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(wtx3), _ptr(dx), None, 0, ctypes.byref(dd), v, s),
                 "hn_conv2d_dgrad"))
             add, ldadd = (None, 0) if dskip is None else as_nhwc(dskip)

@@ -747,3 +747,21 @@ def test_dropout_mask_and_layout_conversion(dev):
     x = rnd(2, 64, 33, 47, seed=91).to(dev)
     t, ld = ops.as_nhwc(x)
     assert torch.equal(t.contiguous(), x)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 40, 44, 256, 1, 1, 0, 1), (2, 256, 32, 40, 256, 3, 1, 2, 2), (2, 128, 33, 47, 320, 3, 1, 1, 1),
+                                  (3, 128, 64, 96, 512, 3, 2, 1, 1), (2, 32, 40, 48, 192, 3, 1, 4, 4)], ids=str)  # > 2048 output pixels: no split-K
+def test_bf16x3_lds_dma_schedule_agrees_bitwise(dev, case):
+    """Third schedule (variant bk = 3: 128 x 256 tile, weight planes by LDS-DMA into a double-buffered stage, raw barriers)
+    against the first: bit-identical outputs incl. ragged M / Cout tails, bias, statistics."""
+    ops = _ops()
+    n, cin, h, w, cout, k, stride, pad, dil = case
+    x = rnd(n, cin, h, w, seed=47)
+    wt = rnd(cout, cin, k, k, seed=48, scale=1.0 / np.sqrt(cin * k * k))
+    b = rnd(cout, seed=49)
+    y1, s1 = _abi_conv(dev, x, wt, stride, pad, dil, ops._variant(1, 2, 2, 2), bias=b, want_stats=True)
+    for _ in range(3):  # (repeat: a missing wait would show up as an occasional stale tile)
+        y3, s3 = _abi_conv(dev, x, wt, stride, pad, dil, ops._variant(3, 0, 0, 2), bias=b, want_stats=True)
+        assert torch.equal(y1, y3)
+    t1, t3 = s1.view(ops.STAT_REPLICAS, 2, cout).sum(0).cpu(), s3.view(ops.STAT_REPLICAS, 2, cout).sum(0).cpu()
+    assert float((t1 - t3).abs().max()) <= 1e-6 * float(t1.abs().max())
