@@ -304,9 +304,21 @@ def main():
     if os.environ.get("HN_BENCH_SHARE_GPU"):
         local = 0
     backend = os.environ.get("HN_BENCH_BACKEND", "nccl")
+    # HN_BENCH_FORCE_DIST=1: the N=1 run goes through the whole N>1 path on RCCL (process group of one rank, bucketed
+    # all-reduces on the communication stream, barriers, max over ranks) -- the rehearsal a one-GPU box allows
+    force_dist = world == 1 and os.environ.get("HN_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            sock = socket.socket()
+            sock.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+            sock.close()
+        os.environ.update(RANK="0", WORLD_SIZE="1")
+    distributed = world > 1 or force_dist
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -319,11 +331,11 @@ def main():
     if args.workload == "seg_bf16":
         ops.set_conv_math("bf16")  # reduced-precision arithmetic: a separate workload, never the headline
     model = build(args.workload, dev)
-    if world > 1:
+    if distributed:
         ddp.broadcast_module_state(model)
     arenas = optim.arenas_for(model)          # flat parameter / gradient storage per training phase
     opt = optim.FlatRMSprop(arenas, lr=1e-4)  # one fused kernel launch per step (cm/train_trgb_segnet_conf.py:270)
-    buckets = ddp.GradBuckets(arenas=arenas) if world > 1 else None
+    buckets = ddp.GradBuckets(arenas=arenas, always_exchange=force_dist) if distributed else None
     batch = synthetic_batch(rank, dev, args.batch, args.height, args.width)
     step = make_step(args.workload, model, opt, batch, buckets)
 
@@ -332,18 +344,18 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -360,7 +372,7 @@ def main():
             for _ in range(nprof):
                 step()
             torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     alt = None
     if world == 1 and not args.no_alt and args.workload != "seg_bf16":
@@ -446,8 +458,12 @@ def main():
                           "parallelism": "dp%d" % world, "optimizer": "RMSprop lr=1e-4 (fused, flat arena)", "weights": "random init",
                           "conv_math": CONV_MATH_NOTE[ops.CONV_MATH]},
                "roofline": roof, "cpu_baseline": base, "alt_conv_math": alt, "other_workloads": others}
+        if force_dist:
+            out["rehearsal"] = {"backend": backend, "world_size": 1, "collectives_issued": buckets.launched,
+                                "note": "HN_BENCH_FORCE_DIST=1: the N>1 path (process group, bucketed all-reduce on the "
+                                        "communication stream, barriers) on one rank"}
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

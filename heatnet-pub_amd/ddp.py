@@ -24,12 +24,18 @@ class GradBuckets:
     50 / 500 iterations, cm/train_trgb_segnet_conf.py:577-592): buckets and hooks are built ONCE for every arena, and
     `begin_step()` arms exactly the buckets whose arena takes part in the current phase -- nothing has to be rebuilt
     at a phase switch, and a frozen arena's stale gradients are never exchanged.  With plain `params` there is one
-    fixed set: `begin_step()` raises if the set of trainable parameters no longer matches it."""
+    fixed set: `begin_step()` raises if the set of trainable parameters no longer matches it.
 
-    def __init__(self, params=None, bucket_bytes=64 << 20, process_group=None, average=True, arenas=None):
+    `always_exchange`: issue the collectives at world size 1 as well (an all-reduce over one rank leaves the gradients
+    unchanged) -- the rehearsal of the RCCL path, its communication stream and its event ordering on a one-GPU box."""
+
+    def __init__(self, params=None, bucket_bytes=64 << 20, process_group=None, average=True, arenas=None,
+                 always_exchange=False):
         self.group = process_group
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.exchange = self.world > 1 or (always_exchange and dist.is_initialized())
+        self.launched = 0  # collectives issued so far (diagnostics / tests)
         self.buckets = []  # dicts: flat, params, pending, work
         self.arenas = list(arenas) if arenas is not None else None
         if arenas is not None:
@@ -144,8 +150,9 @@ class GradBuckets:
             self._launch(b)
 
     def _launch(self, b):
-        if self.world == 1:
+        if not self.exchange:
             return
+        self.launched += 1
         if self.on_gpu:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
@@ -171,7 +178,7 @@ class GradBuckets:
             if b["work"] is not None:
                 b["work"].wait()
                 b["work"] = None
-        if self.on_gpu and self.world > 1:
+        if self.on_gpu and self.exchange:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
 
     def remove(self):

@@ -61,6 +61,24 @@ def test_bench_self_launches_its_workers():
     assert j["value"] > 0 and j["scaling"] == "weak"
 
 
+def test_bench_rccl_rehearsal_on_one_rank():
+    """HN_BENCH_FORCE_DIST=1: the N=1 run takes the N>1 code path on the `nccl` (RCCL) backend -- process group, parameter
+    broadcast, bucketed all-reduces from the backward hooks, barriers, max-over-ranks -- and still prints the contract line."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HN_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "1",
+                          "--height", "256", "--width", "256", "--workload", "confmax_seg", "--no-cpu-baseline", "--no-alt"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["value"] > 0
+    assert j["rehearsal"]["backend"] == "nccl" and j["rehearsal"]["collectives_issued"] > 0
+
+
 def test_bench_worker_failure_is_reported():
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")

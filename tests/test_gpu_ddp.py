@@ -1,6 +1,7 @@
 """GPU, world_size 2 over gloo with both ranks on the one MI355X: the data-parallel step as bench.py runs it -- HIP model,
 flat arenas, gradient slots, ddp.GradBuckets hooks, fused RMSprop -- checked against a single-process computation of the
-same thing (mean of the two ranks' gradients).  RCCL itself cannot be exercised with one GPU; everything above it is."""
+same thing (mean of the two ranks' gradients).  RCCL needs one GPU per rank: it is exercised over ONE rank (`nccl` backend, collectives are
+the identity) -- initialisation, stream and event ordering, not the reduction itself."""
 import os
 import socket
 import sys
@@ -116,6 +117,65 @@ def test_two_ranks_on_one_gpu_match_single_process():
     scale = float(last.abs().max())
     assert float((g0 - last).abs().max()) <= 2e-5 * scale, float((g0 - last).abs().max()) / scale
     assert float((w0 - arenas[0].flat.detach().cpu()).abs().max()) <= 1e-4
+
+
+# ---- RCCL itself, as far as one GPU allows: a process group of ONE rank on the `nccl` backend ---------------------------
+
+def _rccl_worker(port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)  # as bench.py initialises it
+    from heatnet_amd import ddp, ops, optim, train_step
+    ops.set_deterministic(True)  # bitwise comparison below
+    x, lab = _data(0)
+    x = x.to(dev).contiguous(memory_format=torch.channels_last)
+    out = {}
+    for exchange in (False, True):
+        net = _build().to(dev).train()
+        ddp.broadcast_module_state(net)
+        arenas = optim.arenas_for(net)
+        opt = optim.FlatRMSprop(arenas, lr=1e-3)
+        buckets = ddp.GradBuckets(arenas=arenas, bucket_bytes=32 << 10, always_exchange=exchange)
+        for _ in range(3):
+            opt.zero_grad()
+            buckets.begin_step()
+            train_step.segmentation_loss(net(x), lab.to(dev)).backward()
+            buckets.finish_step()
+            grad = arenas[0].grad.detach().clone()
+            opt.step()
+        torch.cuda.synchronize()
+        out[exchange] = (grad.cpu(), arenas[0].flat.detach().cpu().clone(), buckets.launched, len(buckets.buckets))
+        buckets.remove()
+    t = torch.tensor([3.0], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)  # bench.py's max-over-ranks reduction and barrier on the same backend
+    dist.barrier()
+    ret["out"] = out
+    ret["max"] = float(t.item())
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_one_rank_buckets_leave_gradients_unchanged():
+    """The collective path on the real backend (`nccl` = RCCL): process group with `device_id`, bucketed async all-reduces
+    issued from autograd hooks on the communication stream behind an event, the compute stream waiting for them before the
+    optimizer.  Over one rank an all-reduce is the identity, so gradients and weights after three steps must be those of a
+    run that never exchanges (up to the run-to-run spread of the f64 statistics atomics, ~1e-7 relative)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), ret))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    out = ret["out"]
+    (g0, w0, n0, _), (g1, w1, n1, nb) = out[False], out[True]
+    assert n0 == 0 and nb >= 2 and n1 == 3 * nb  # every bucket exchanged once per step
+    scale = float(g0.abs().max())
+    assert float((g0 - g1).abs().max()) <= 2e-5 * scale, float((g0 - g1).abs().max()) / scale
+    assert float((w0 - w1).abs().max()) <= 1e-4, float((w0 - w1).abs().max())
+    assert ret["max"] == 3.0
 
 
 # ---- confusion-maximisation pattern under data parallelism (BASELINE configs[3]) ----------------------------------------
