@@ -42,15 +42,20 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # MI355X_MICROARCH.md, dense peaks: v_mfma_f32_32x32x2_f32 157.3 TFLOP/s; bf16 MFMA ~2500 TFLOP/s, of which one fp32
 # product costs six MFMAs under bf16x3
-PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 6.0, "bf16": 2500.0}
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 6.0, "bf16": 2500.0, "f16x2": 2500.0 / 3.0}  # (fp16 MFMA peak = bf16's)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured by a streaming copy)
 KERNEL_LABEL = {"f32": "conv_igemm_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32)",
                 "bf16x3": "conv_igemm_kernel<..,MATH_X3> / conv_wgrad_x3_kernel (6 x v_mfma_f32_16x16x32_bf16 per fp32 "
                           "product; peak = dense bf16 MFMA peak / 6)",
-                "bf16": "conv_igemm2_kernel<..,1,..> / conv_wgrad_x3_kernel<..,1> (one v_mfma_f32_16x16x32_bf16 per product)"}
+                "bf16": "conv_igemm2_kernel<..,1,..> / conv_wgrad_x3_kernel<..,1> (one v_mfma_f32_16x16x32_bf16 per product)",
+                "f16x2": "conv_igemm_kernel<..,MATH_H2> / conv_wgrad_x3_kernel<..,2> (3 x v_mfma_f32_16x16x32_f16 per fp32 "
+                         "product; peak = dense fp16 MFMA peak / 3)"}
 CONV_MATH_NOTE = {"f32": "f32: v_mfma_f32_32x32x2_f32 on the fp32 operands",
                   "bf16x3": "bf16x3: fp32 operands split exactly into 3 bf16 terms in-kernel, 6 bf16 MFMAs per product, fp32 "
                             "accumulate; error vs fp64 equal to the fp32 MFMA's (profiles/r01_bf16x3_probe.txt)",
+                  "f16x2": "f16x2: fp32 operands scaled per tensor by a power of two and split into 2 fp16 terms in-kernel, 3 "
+                           "fp16 MFMAs per product, fp32 accumulate; error vs fp64 at or below the fp32 MFMA's "
+                           "(profiles/r02_f16x2_accuracy.txt); Cin % 32 != 0 layers on the fp32 MFMA",
                   "bf16": "bf16 (REDUCED precision, BASELINE configs[4]): conv operands rounded to nearest bf16 in the "
                           "loaders, one bf16 MFMA per product, fp32 accumulate; activations in HBM, BatchNorm statistics, "
                           "master weights and optimizer fp32; stems / 13-class head (Cin % 32 != 0) on the fp32 MFMA"}
@@ -379,7 +384,7 @@ def main():
         # the same step under the other conv arithmetic, timed the same way (N=1 only: like cpu_baseline, it is a
         # reference figure printed beside the headline, not part of it)
         main_math = ops.CONV_MATH
-        other = "f32" if main_math == "bf16x3" else "bf16x3"
+        other = "f32" if main_math in ("bf16x3", "f16x2") else "bf16x3"
         ops.set_conv_math(other)
         try:
             for _ in range(max(2, args.warmup)):

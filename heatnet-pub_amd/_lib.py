@@ -25,7 +25,7 @@ DP = ctypes.POINTER(HnConvDesc)
 
 class HnWeightPrepItem(ctypes.Structure):
     _fields_ = [("w", ctypes.c_void_p), ("w_x3", ctypes.c_void_p), ("wt", ctypes.c_void_p), ("wt_x3", ctypes.c_void_p)] + \
-               [(n, ctypes.c_int32) for n in ("Cout", "KH", "KW", "Cin", "stride", "pad", "dil", "reserved")]
+               [(n, ctypes.c_int32) for n in ("Cout", "KH", "KW", "Cin", "stride", "pad", "dil", "format")]
 
 
 # name -> argtypes, exactly the prototypes of include/heatnet_hip.h
@@ -39,11 +39,11 @@ SIGNATURES = {
     "hn_channel_stats": [P, c_int, c_i64, c_int, P, P],
     "hn_bn_finalize": [P, c_i64, P, P, P, P, c_float, c_float, P, P, P, P, c_int, P],
     "hn_bn_eval_params": [P, P, P, P, c_float, P, P, P, P, c_int, P],
-    "hn_bn_act_fwd": [P, c_int, P, P, P, c_int, P, c_int, c_i64, c_int, c_int, P, c_float, P, c_i64, P],
+    "hn_bn_act_fwd": [P, c_int, P, P, P, c_int, P, c_int, c_i64, c_int, c_int, P, c_float, P, c_i64, P, P],
     "hn_bn_act_bwd_reduce": [P, c_int, P, c_int, P, c_int, P, P, P, P, c_i64, c_int, c_int, P, c_float, P, P, P, P, P,
                              c_int, P, c_i64, P],
     "hn_bn_act_bwd_apply": [P, c_int, P, c_int, P, c_int, P, P, P, P, P, P, c_i64, c_int, P, c_int, P, c_int,
-                            c_i64, c_int, c_int, P, c_float, P, c_i64, P],
+                            c_i64, c_int, c_int, P, c_float, P, c_i64, P, P],
     "hn_act_bwd": [P, c_int, P, c_int, P, c_int, c_i64, c_int, c_int, c_float, P],
     "hn_scale_nc": [P, c_int, P, P, c_int, c_int, c_i64, c_int, P],
     "hn_add": [P, c_int, P, c_int, P, c_int, c_i64, c_int, P],
@@ -58,8 +58,15 @@ SIGNATURES = {
     "hn_bilinear_bwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_pyramid_merge_fwd": [P, c_int, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_split_bf16x3": [P, P, c_i64, P],
+    "hn_split_f16x2": [P, P, c_i64, P],
+    "hn_absmax_scale": [P, c_int, c_i64, c_int, P, P],
+    "hn_conv2d_fwd_scaled": [P, P, P, P, P, P, P, DP, c_int, c_float, c_int, P],
+    "hn_conv2d_dgrad_scaled": [P, P, P, P, P, P, c_int, DP, c_int, P],
     "hn_weight_prep_table_fill": [P, c_int, P, P],
-    "hn_weight_prepare_batch": [P, c_int, c_int, P],
+    "hn_weight_prepare_batch": [P, c_int, c_int, c_int, P],
+    "hn_weight_flip_transpose_h2": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "hn_conv2d_wgrad_scaled": [P, P, P, P, P, DP, c_int, c_int, c_int, P],
+    "hn_conv2d_wgrad_det_scaled": [P, P, P, P, P, DP, c_int, c_int, c_int, P, P],
     "hn_thermal_augment": [P, P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P, P],
     "hn_thermal_resize": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "hn_set_conv_math": [c_int],

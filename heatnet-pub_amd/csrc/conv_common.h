@@ -7,6 +7,8 @@
 
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace hnconv {
 
@@ -42,6 +44,10 @@ struct ConvArgs {
     // whose only consumer is this convolution); taps that fall into the zero padding stay zero.  NULL = plain gather.
     const float* in_scale;
     const float* in_shift;
+    // f16x2: the gathered tensor's scale slot (bit pattern of its max |x|, hn_absmax_scale) and the weight planes' {s, 1/s}
+    // (stored behind the two f16 planes, hn_split_f16x2); NULL for the other arithmetics
+    const float* a_scale;
+    const float* w_scale;
 };
 
 // bf16x3 LDS image: [split][row][32 k] bf16 with 80-byte rows (64 B of data + 16 B pad: 16 consecutive rows start in
@@ -66,6 +72,18 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16
         h[e] = hh;
         m[e] = mm;
         l[e] = (__bf16)r2;
+    }
+}
+
+// two-way split of four consecutive-k fp32 values, pre-scaled by the power of two `s`, into packed fp16 (hi, lo):
+// x * s = hi + lo + e with |e| <= 2^-23 |x * s| while lo stays a normal fp16 number (|x * s| >= 2^-3)
+__device__ __forceinline__ void split2h(const f32x4 v, float s, f16x4& h, f16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float xs = v[e] * s;  // exact
+        const _Float16 hh = (_Float16)xs;
+        h[e] = hh;
+        l[e] = (_Float16)(xs - (float)hh);  // the difference is exact in fp32
     }
 }
 
@@ -102,9 +120,10 @@ struct AccMap {
 // Accumulators start at zero -- or at the addend (a gradient that reached this tensor through another branch): its
 // loads are issued ahead of the operand prologue and their latency disappears behind the first K steps, so the
 // epilogue stays a pure store loop.  The addend never overlaps the output (header contract).
+// `iscale` (f16x2: the product of the operand scales, a power of two): the accumulators live in the scaled domain.
 template <int TM, int TN, bool S16>
 __device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[TM][TN], const AccMap<TM, TN, S16>& am,
-                                              const int* rowinfo, int m0) {
+                                              const int* rowinfo, int m0, float iscale = 1.f) {
     if (p.addend != nullptr && p.cps == 0) {
         const float* __restrict__ add = p.addend;
 #pragma unroll
@@ -116,7 +135,7 @@ __device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[T
                     const int row = am.row(i, r), col = am.col(j, am.c2_of(r));
                     float v = 0.f;
                     if (m0 + row < p.M && col < p.K) v = add[(size_t)rowinfo[row * 4 + 3] * p.ldadd + col];
-                    acc[i][j][r] = v;
+                    acc[i][j][r] = v * iscale;
                 }
             }
         }
@@ -134,11 +153,20 @@ __device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[T
 // The bias is loaded unconditionally (clamped index) and folded in BEFORE any store is issued, and full tiles take a
 // branch-free path: a conditional load inside the store loop makes hipcc wait vmcnt(0) -- i.e. for the previous store --
 // in front of every store.
-template <int TM, int TN, bool S16, int BM = 64 * TM, int BN = 64 * TN>
+// `oscale` (f16x2: 1 / (operand scales), a power of two) takes the accumulators back to the tensor's own scale first.
+template <int TM, int TN, bool S16, int BM = 64 * TM, int BN = 64 * TN, bool SCALED = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], const AccMap<TM, TN, S16>& am,
-                                              const int* rowinfo, int m0, int tile_m, int split) {
+                                              const int* rowinfo, int m0, int tile_m, int split, float oscale = 1.f) {
     constexpr int NC = AccMap<TM, TN, S16>::NC;
     const int lane = am.lane, n0 = am.n0;
+    if constexpr (SCALED) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= oscale;
+    }
     if (p.cps > 0) {  // split-K partial
 #pragma unroll
         for (int j = 0; j < TN; ++j) {  // accumulate into the pre-initialised output

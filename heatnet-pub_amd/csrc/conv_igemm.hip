@@ -53,7 +53,7 @@ using namespace hnconv;
 // Loader variants.  BUF fetches through buffer descriptors: one SGPR resource per tile, 32-bit byte offsets, and
 // out-of-range taps / rows are zero-filled by the hardware range check instead of by selects.
 enum : int { MODE_SCALAR = 0, MODE_SCALAR_STRIDED = 1, MODE_VEC = 2, MODE_VEC_STRIDED = 3, MODE_VEC_BUF = 4 };
-enum : int { MATH_F32 = 0, MATH_X3 = 1 };
+enum : int { MATH_F32 = 0, MATH_X3 = 1, MATH_H2 = 2 };
 
 // STRIDED = the gathered tensor is "dilated" by in_dil > 1 (data gradient of a strided convolution): taps must
 // land on multiples of in_dil.  Kept out of the common instantiation because it costs integer divisions per tap.
@@ -68,15 +68,17 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_kernel(const ConvArgs 
     constexpr bool VEC = MODE >= MODE_VEC;
     constexpr bool STRIDED = MODE == MODE_SCALAR_STRIDED || MODE == MODE_VEC_STRIDED;
     constexpr bool BUF = MODE == MODE_VEC_BUF;
-    constexpr bool X3 = MATH == MATH_X3;
-    constexpr bool S16 = X3;  // bf16x3 runs on v_mfma_f32_16x16x32_bf16: accumulators hold 16x16 sub-blocks (acc_row / acc_col)
-    static_assert(!X3 || (BUF && BK == 32), "bf16x3 math is built for the buffer loaders at K step 32");
-    static_assert(WN == 2 || X3, "the eight-wave tile exists for the bf16x3 arithmetic only");
+    constexpr bool H2 = MATH == MATH_H2;         // f16x2: two fp16 planes per operand, three products
+    constexpr bool X3 = MATH == MATH_X3 || H2;   // the split arithmetics share loaders, LDS image and schedule
+    constexpr int NS = H2 ? 2 : 3;               // planes per operand
+    constexpr bool S16 = X3;  // they run on v_mfma_f32_16x16x32_{bf16,f16}: accumulators hold 16x16 sub-blocks (acc_row / acc_col)
+    static_assert(!X3 || (BUF && BK == 32), "the split arithmetics are built for the buffer loaders at K step 32");
+    static_assert(WN == 2 || MATH == MATH_X3, "the eight-wave tile exists for the bf16x3 arithmetic only");
     constexpr int BM = 64 * TM, BN = 32 * WN * TN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                        // f32: [2][BM][LDK]     bf16x3: [3][BM][X3_ROW bytes]
-    float* Bs = smem + (X3 ? 3 * BM * X3_ROW / 4 : 2 * BM * LDK);  // f32: [2][BN][LDK]  bf16x3: [3][BN][X3_ROW bytes]
-    int* rowinfo = reinterpret_cast<int*>(Bs + (X3 ? 3 * BN * X3_ROW / 4 : 2 * BN * LDK));  // [BM][4]
+    float* As = smem;                                        // f32: [2][BM][LDK]     split: [NS][BM][X3_ROW bytes]
+    float* Bs = smem + (X3 ? NS * BM * X3_ROW / 4 : 2 * BM * LDK);  // f32: [2][BN][LDK]  split: [NS][BN][X3_ROW bytes]
+    int* rowinfo = reinterpret_cast<int*>(Bs + (X3 ? NS * BN * X3_ROW / 4 : 2 * BN * LDK));  // [BM][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_kernel(const ConvArgs 
     // ---- operand staging -------------------------------------------------------------------------------
     constexpr int RA = VEC ? BM / VROWS : BM / SROWS;
     // bf16x3 stages B from the pre-split planes: BN rows x 3 planes x 4 pieces of 16 B (8 bf16) per K step
-    constexpr int RB = X3 ? BN * 12 / NT : (VEC ? BN / VROWS : BN / SROWS);
+    constexpr int RB = X3 ? BN * 4 * NS / NT : (VEC ? BN / VROWS : BN / SROWS);
     f32x4 va[VEC ? RA : 1], vb[VEC ? RB : 1];
     f32x4 va1[X3 ? RA : 1], vb1[X3 ? RB : 1];  // bf16x3: second staging set (two K steps of loads in flight)
     float sa[VEC ? 1 : RA], sb[VEC ? 1 : RB];
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_kernel(const ConvArgs 
         for (int q = 0; q < RA; ++q)
             aoff32[q] = (((anb[q] - nb0) + ahb[q] * p.W + awb[q]) * p.ldx + c4 * 4) * 4;
         if constexpr (X3) {
-            const unsigned b_records = (unsigned)(3 * p.wx3_plane * 2);
+            const unsigned b_records = (unsigned)(NS * p.wx3_plane * 2);
             rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.wx3), 0, b_records, 0x00020000);
 #pragma unroll
             for (int q = 0; q < RB; ++q) {
@@ -246,18 +248,34 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_kernel(const ConvArgs 
         st_k0 += BK;
     };
 
+    // f16x2: operand scales (powers of two): the gathered tensor is multiplied by a_s as it is split, the weight planes
+    // were made from w * w_s; accumulators hold a_s * w_s times the result
+    float a_s = 1.f, o_s = 1.f, i_s = 1.f;
+    if constexpr (H2) {
+        float a_inv;
+        hn_h2_scales_of_slot(p.a_scale, a_s, a_inv);  // from the tensor's max |x| bit patterns
+        o_s = a_inv * p.w_scale[1];
+        i_s = a_s * p.w_scale[0];
+    }
     auto store_lds = [&](int buf, const auto& sva, const auto& svb) {
         if constexpr (X3) {  // single LDS stage: split each staged 16 B (4 consecutive k) into 3 x 8 B of bf16
             char* a = reinterpret_cast<char*>(As) + (c4 & 1) * 8;  // + the (possibly flipped) 16-B k group of the row
 #pragma unroll
             for (int q = 0; q < RA; ++q) {
-                bf16x4 h, m, l;
-                split3(sva[q], h, m, l);
                 const int row = vrow + VROWS * q;
                 const int kg = ((c4 >> 1) ^ x3_kflip(row)) * 16;
-                *reinterpret_cast<bf16x4*>(a + (0 * BM + row) * X3_ROW + kg) = h;
-                *reinterpret_cast<bf16x4*>(a + (1 * BM + row) * X3_ROW + kg) = m;
-                *reinterpret_cast<bf16x4*>(a + (2 * BM + row) * X3_ROW + kg) = l;
+                if constexpr (H2) {
+                    f16x4 h, l;
+                    split2h(sva[q], a_s, h, l);
+                    *reinterpret_cast<f16x4*>(a + (0 * BM + row) * X3_ROW + kg) = h;
+                    *reinterpret_cast<f16x4*>(a + (1 * BM + row) * X3_ROW + kg) = l;
+                } else {
+                    bf16x4 h, m, l;
+                    split3(sva[q], h, m, l);
+                    *reinterpret_cast<bf16x4*>(a + (0 * BM + row) * X3_ROW + kg) = h;
+                    *reinterpret_cast<bf16x4*>(a + (1 * BM + row) * X3_ROW + kg) = m;
+                    *reinterpret_cast<bf16x4*>(a + (2 * BM + row) * X3_ROW + kg) = l;
+                }
             }
 #pragma unroll
             for (int q = 0; q < RB; ++q) {  // already split: piece id -> (plane, row, 16-B piece), see boff32
@@ -286,7 +304,7 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_kernel(const ConvArgs 
     const int lr = lane & 31, lh = lane >> 5;
     const AccMap<TM, TN, S16> am{wm, wn, lane, n0};
     f32x16 acc[TM][TN];
-    conv_init_acc<TM, TN, S16>(p, acc, am, rowinfo, m0);
+    conv_init_acc<TM, TN, S16>(p, acc, am, rowinfo, m0, i_s);
     const int total_chunks = (p.Kdim + BK - 1) / BK;
     const int kc_first = p.cps > 0 ? split * p.cps : 0;
     const int nchunks = p.cps > 0 ? min(p.cps, total_chunks - kc_first) : total_chunks;  // >= 1 by construction
@@ -358,27 +376,34 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_kernel(const ConvArgs 
             const int kg = ((lane >> 4) ^ x3_kflip(lane & 15)) * 16;  // every 16-row block starts at a multiple of 16 rows
             const char* a = reinterpret_cast<const char*>(As) + ((wm * TM * 32 + (lane & 15)) * X3_ROW + kg);
             const char* b = reinterpret_cast<const char*>(Bs) + ((wn * TN * 32 + (lane & 15)) * X3_ROW + kg);
-            bf16x8 fb[2 * TN][3];
+            using frag_t = std::conditional_t<H2, f16x8, bf16x8>;
+            frag_t fb[2 * TN][NS];
 #pragma unroll
             for (int bj = 0; bj < 2 * TN; ++bj)
 #pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) fb[bj][s3] = *reinterpret_cast<const bf16x8*>(b + (s3 * BN + bj * 16) * X3_ROW);
+                for (int s3 = 0; s3 < NS; ++s3) fb[bj][s3] = *reinterpret_cast<const frag_t*>(b + (s3 * BN + bj * 16) * X3_ROW);
 #pragma unroll
             for (int bi = 0; bi < 2 * TM; ++bi) {
-                bf16x8 fa[3];
+                frag_t fa[NS];
 #pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) fa[s3] = *reinterpret_cast<const bf16x8*>(a + (s3 * BM + bi * 16) * X3_ROW);
+                for (int s3 = 0; s3 < NS; ++s3) fa[s3] = *reinterpret_cast<const frag_t*>(a + (s3 * BM + bi * 16) * X3_ROW);
 #pragma unroll
                 for (int bj = 0; bj < 2 * TN; ++bj) {
                     const int sb = 4 * (2 * (bi & 1) + (bj & 1));
                     f32x16& blk = acc[bi >> 1][bj >> 1];
                     f32x4 c = {blk[sb], blk[sb + 1], blk[sb + 2], blk[sb + 3]};
+                    if constexpr (H2) {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[bj][0], c, 0, 0, 0);  // lo*hi
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][1], c, 0, 0, 0);  // hi*lo
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][0], c, 0, 0, 0);  // hi*hi
+                    } else {
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][1], c, 0, 0, 0);  // mid*mid
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][2], c, 0, 0, 0);  // hi*lo
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[bj][0], c, 0, 0, 0);  // lo*hi
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][1], c, 0, 0, 0);  // hi*mid
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][0], c, 0, 0, 0);  // mid*hi
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][0], c, 0, 0, 0);  // hi*hi
+                    }
                     blk[sb] = c[0];
                     blk[sb + 1] = c[1];
                     blk[sb + 2] = c[2];
@@ -434,13 +459,13 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_kernel(const ConvArgs 
     k_step(kc & 1, std::false_type{}, std::false_type{});
     }
 
-    conv_epilogue<TM, TN, S16, BM, BN>(p, acc, am, rowinfo, m0, tile_m, split);
+    conv_epilogue<TM, TN, S16, BM, BN, H2>(p, acc, am, rowinfo, m0, tile_m, split, o_s);
 }
 
 template <int TM, int TN, int MODE, int BK, int MATH = MATH_F32, int WN = 2>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 32 * WN * TN;
-    constexpr int lds = MATH != MATH_F32 ? 3 * (BM + BN) * X3_ROW + BM * 16
+    constexpr int lds = MATH != MATH_F32 ? (MATH == MATH_H2 ? 2 : 3) * (BM + BN) * X3_ROW + BM * 16
                                         : (2 * (BM + BN) * KStep<BK>::LDK + BM * 4) * (int)sizeof(float);
     static std::atomic<unsigned long long> configured{0};
     if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_kernel<TM, TN, MODE, BK, MATH, WN>), lds, configured) != HN_OK)
@@ -473,6 +498,7 @@ int dispatch_tile(const ConvArgs& a, bool tall, bool wide, hipStream_t stream, i
     return wide ? launch_conv<1, 2, MODE, BK, MATH>(a, stream) : launch_conv<1, 1, MODE, BK, MATH>(a, stream);
 }
 
+constexpr int VARIANT_F16X2 = 4 << 6;  // math_sel of the f16x2 arithmetic (variant codes, plan_conv)
 bool g_deterministic = false;  // hn_set_deterministic: no split-K float atomics in these kernels
 int g_conv_math = 0;  // HN_MATH_* default for variant codes that leave the math field 0 (hn_set_conv_math)
 
@@ -483,11 +509,11 @@ struct ConvPlan {
     bool tall, wide;
     int wn;          // FAM_V1 bf16x3: 4 = the eight-wave 128 x 256 tile (tn_sel 3), else 2
     int mode, bk;    // FAM_V1: loader variant and K step
-    int math;        // FAM_V1: MATH_F32 / MATH_X3; FAM_V2: bf16 planes per operand (3 = bf16x3, 1 = bf16)
+    int math;        // FAM_V1: MATH_F32 / MATH_X3 / MATH_H2; FAM_V2: bf16 planes per operand (3 = bf16x3, 1 = bf16)
 };
 
 // variant: 0 = heuristics; otherwise (bk_sel) + 4 * (tm_sel) + 16 * (tn_sel) + 64 * (math_sel).
-//   math_sel 1 -> fp32 MFMA, 2 -> bf16x3, 3 -> bf16 (0: library default, hn_set_conv_math)
+//   math_sel 1 -> fp32 MFMA, 2 -> bf16x3, 3 -> bf16, 4 -> f16x2 (0: library default, hn_set_conv_math)
 //   bk_sel   fp32 MFMA: 1 -> K step 32, 2 -> 16.  bf16x3: 1 -> first schedule (two workgroups per CU, phases
 //            separated by barriers), 2 -> second schedule (producer / consumer waves, conv_igemm2.hip), 3 -> third
 //            schedule (128 x 256 tile, weights by LDS-DMA, conv_igemm3.hip; where it does not cover: the first); 0 = the first.
@@ -495,7 +521,7 @@ struct ConvPlan {
 // Within one math mode all variants give bitwise identical results: the per-element accumulation order does not depend
 // on the tiling or the schedule.
 int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
-    if (variant < 0 || variant >= 256) return HN_EINVAL;
+    if (variant < 0 || variant >= 64 * 5) return HN_EINVAL;
     const int bk_sel = variant & 3, tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3, math_sel = variant >> 6;
     if (tm_sel == 3) return HN_EINVAL;
     const bool vec = (a.C % 32 == 0) && (a.ldx % 4 == 0) && hn_aligned16(a.x) && hn_aligned16(a.w);
@@ -513,13 +539,18 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
                         (long long)a.H * a.W >= 128;
     // the bf16 kernels need the pre-split weight planes and the buffer loaders; anything else runs on the fp32 MFMA
     const int math = math_sel ? math_sel - 1 : g_conv_math;  // HN_MATH_*
+    if (bk_sel == 3 && math != HN_MATH_BF16X3) return HN_EINVAL;  // the third schedule exists for bf16x3 only
     const bool planes_ok = a.wx3 != nullptr && vec && !strided && buf_ok && hn_aligned16(a.wx3) &&
                            a.wx3_plane % 8 == 0 && 6 * a.wx3_plane < (1ll << 32);
     pl.tall = tall;
     pl.wide = wide;
     pl.wn = 2;
     pl.bk = 32;
-    if (math == HN_MATH_BF16 && planes_ok) {
+    if (math == HN_MATH_F16X2) {
+        // the caller chose the operand format (fp16 planes + scales): there is no other kernel to fall back to
+        if (!planes_ok || a.a_scale == nullptr) return HN_ESHAPE;
+        pl.family = FAM_V1; pl.math = MATH_H2; pl.mode = MODE_VEC_BUF;
+    } else if (math == HN_MATH_BF16 && planes_ok) {
         pl.family = FAM_V2; pl.math = MATH2_BF16; pl.mode = MODE_VEC_BUF;
         pl.bk = a.C % 64 == 0 ? 64 : 32;
     } else if (math == HN_MATH_BF16X3 && planes_ok) {
@@ -549,6 +580,7 @@ int run_conv(const ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
         return rc == 1 ? HN_ESHAPE : rc;
     }
     if (pl.math == MATH_X3) return dispatch_tile<MODE_VEC_BUF, 32, MATH_X3>(a, pl.tall, pl.wide, stream, pl.wn);
+    if (pl.math == MATH_H2) return dispatch_tile<MODE_VEC_BUF, 32, MATH_H2>(a, pl.tall, pl.wide, stream);
     switch (pl.mode) {
         case MODE_VEC_BUF:
             return pl.bk == 16 ? dispatch_tile<MODE_VEC_BUF, 16>(a, pl.tall, pl.wide, stream)
@@ -573,6 +605,7 @@ void plan_name(const ConvPlan& pl, char* buf, int n) {
     if (pl.family == FAM_V3) snprintf(buf, n, "conv_igemm3_kernel");
     else if (pl.family == FAM_V2) snprintf(buf, n, "conv_igemm2_kernel<%d, %d, %d, %d, false>", tm, tn, pl.math, pl.bk);
     else if (pl.math == MATH_X3) snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 1, %d>", tm, tn, pl.mode, pl.bk, pl.wn);
+    else if (pl.math == MATH_H2) snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 2, 2>", tm, tn, pl.mode, pl.bk);
     else snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 0, 2>", tm, tn, pl.mode, pl.bk);
 }
 
@@ -683,42 +716,118 @@ __device__ __forceinline__ void split3_scalar(float v, unsigned short& h, unsign
     l = __builtin_bit_cast(unsigned short, ll);
 }
 
-// one 32x32 (co, ci) tile of one tap per block, transposed through LDS; `wt` (fp32) and `wx3` (three bf16 planes of
-// `plane` elements each, same element order) are both optional; `w_x3` (optional) receives the bf16 planes of the
-// UNtransposed matrix -- every source element passes through exactly one block, so the forward operand comes for free
-__global__ __launch_bounds__(256) void weight_taps_transpose_kernel(const float* __restrict__ w,
-                                                                   unsigned short* __restrict__ w_x3, float* __restrict__ wt,
-                                                                   unsigned short* __restrict__ wx3, long long plane,
-                                                                   int Cout, int T, int Cin, TapTable t) {
+__device__ __forceinline__ void split2h_scalar(float v, float s, unsigned short& h, unsigned short& l) {
+    const float xs = v * s;
+    const _Float16 hh = (_Float16)xs;
+    const _Float16 ll = (_Float16)(xs - (float)hh);
+    h = __builtin_bit_cast(unsigned short, hh);
+    l = __builtin_bit_cast(unsigned short, ll);
+}
+
+// ---- f16x2 operand preparation ------------------------------------------------------------------------------------
+// Weight planes in the f16x2 format: [hi plane][lo plane][area], plane = HN_X3_PLANE(n) fp16 elements; the area (the
+// bf16x3 format's third plane) holds the scale slot {s, 1/s, -, -} and H2_PARTS partial maxima.  Two passes without
+// atomics or persistent state: absmax over H2_PARTS chunks, then every block of the splitting kernel reduces the
+// partials itself (bitwise reproducible, nothing to zero).
+constexpr int H2_PARTS = 64;
+constexpr long long H2_MIN_ELEMS = 256;  // the area must hold 4 + H2_PARTS floats: plane * 2 bytes >= 272
+
+__device__ __forceinline__ float* h2_area(unsigned short* planes, long long plane) {
+    return reinterpret_cast<float*>(planes + 2 * plane);
+}
+
+// chunk `part` (of H2_PARTS) of a matrix of n floats -> area[4 + part] = max |w| as uint bits
+__device__ __forceinline__ void h2_absmax_part(const float* __restrict__ w, long long n, int part, float* area) {
+    const long long len = ((n + H2_PARTS - 1) / H2_PARTS + 3) & ~3ll;
+    const long long lo = part * len, hi = min(n, lo + len);
+    unsigned m = 0u;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) m = max(m, __float_as_uint(w[i]) & 0x7fffffffu);
+    __shared__ unsigned red[4];
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) reinterpret_cast<unsigned*>(area)[4 + part] = max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
+// every thread of the block gets the scale; `publish`: this block also writes the slot(s) the convolution kernels read
+__device__ __forceinline__ float h2_scale_of_parts(float* area, bool publish, float* also = nullptr) {
+    __shared__ float s_sh[2];
+    if (threadIdx.x < 64) {
+        unsigned m = reinterpret_cast<const unsigned*>(area)[4 + threadIdx.x];
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if (threadIdx.x == 0) {
+            hn_h2_scales(m, s_sh[0], s_sh[1]);
+            if (publish) {
+                area[0] = s_sh[0];
+                area[1] = s_sh[1];
+                if (also != nullptr && also != area) { also[0] = s_sh[0]; also[1] = s_sh[1]; }
+            }
+        }
+    }
+    __syncthreads();
+    return s_sh[0];
+}
+
+// One 32x32 (co, ci) tile of one tap, transposed through LDS.  `wt` (fp32) and `wt_x3` (planes of `plane` elements each,
+// same element order) are both optional; `w_x3` (optional) receives the planes of the UNtransposed matrix -- every source
+// element passes through exactly one block, so the forward operand comes for free.  H2: two fp16 planes of w * s instead
+// of three bf16 planes.
+template <bool H2>
+__device__ __forceinline__ void prep_tile(const float* __restrict__ w, unsigned short* __restrict__ w_x3, float* __restrict__ wt,
+                                          unsigned short* __restrict__ wt_x3, long long plane, int Cout, int T, int Cin, int src,
+                                          int dst, int rowstride, int ci0, int co0, float s) {
     __shared__ float tile[32][33];
-    const int z = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int src = t.src[z];
     for (int r = ty; r < 32; r += 8) {
         const int co = co0 + r, ci = ci0 + tx;
         float v = 0.f;
         if (co < Cout && ci < Cin) {
             const size_t o = ((size_t)co * T + src) * Cin + ci;
             v = w[o];
-            if (w_x3 != nullptr) split3_scalar(v, w_x3[o], w_x3[plane + o], w_x3[2 * plane + o]);
+            if (w_x3 != nullptr) {
+                if constexpr (H2) split2h_scalar(v, s, w_x3[o], w_x3[plane + o]);
+                else split3_scalar(v, w_x3[o], w_x3[plane + o], w_x3[2 * plane + o]);
+            }
         }
         tile[r][tx] = v;
     }
     __syncthreads();
-    const int rowstride = t.row[z];
+    if (wt == nullptr && wt_x3 == nullptr) return;
     for (int r = ty; r < 32; r += 8) {
         const int ci = ci0 + r, co = co0 + tx;
         if (ci < Cin && co < Cout) {
-            const size_t o = (size_t)t.dst[z] + (size_t)ci * rowstride + co;
+            const size_t o = (size_t)dst + (size_t)ci * rowstride + co;
             const float v = tile[tx][r];
             if (wt != nullptr) wt[o] = v;
-            if (wx3 != nullptr) split3_scalar(v, wx3[o], wx3[plane + o], wx3[2 * plane + o]);
+            if (wt_x3 != nullptr) {
+                if constexpr (H2) split2h_scalar(v, s, wt_x3[o], wt_x3[plane + o]);
+                else split3_scalar(v, wt_x3[o], wt_x3[plane + o], wt_x3[2 * plane + o]);
+            }
         }
     }
 }
 
-// All layers of a model in ONE launch: the same tile body as weight_taps_transpose_kernel, with the layer looked up from
-// the block index (a step prepares ~90 weight matrices; as separate launches they cost ~7 us each, mostly latency).
+// the scale area of a layer's f16x2 planes lives in the forward planes when there are any
+__device__ __forceinline__ float* h2_layer_area(unsigned short* w_x3, unsigned short* wt_x3, long long plane) {
+    return h2_area(w_x3 != nullptr ? w_x3 : wt_x3, plane);
+}
+
+__global__ __launch_bounds__(256) void weight_taps_transpose_kernel(const float* __restrict__ w,
+                                                                   unsigned short* __restrict__ w_x3, float* __restrict__ wt,
+                                                                   unsigned short* __restrict__ wx3, long long plane,
+                                                                   int Cout, int T, int Cin, int format, TapTable t) {
+    const int z = blockIdx.z;
+    if (format == 1) {
+        const bool first = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+        const float s = h2_scale_of_parts(h2_layer_area(w_x3, wx3, plane), first, wx3 != nullptr ? h2_area(wx3, plane) : nullptr);
+        prep_tile<true>(w, w_x3, wt, wx3, plane, Cout, T, Cin, t.src[z], t.dst[z], t.row[z], blockIdx.x * 32, blockIdx.y * 32, s);
+    } else {
+        prep_tile<false>(w, w_x3, wt, wx3, plane, Cout, T, Cin, t.src[z], t.dst[z], t.row[z], blockIdx.x * 32, blockIdx.y * 32, 1.f);
+    }
+}
+
+// All layers of a model in ONE launch: the same tile body, with the layer looked up from the block index (a step prepares
+// ~90 weight matrices; as separate launches they cost ~7 us each, mostly latency).
 struct PrepLayer {
     const float* w;
     unsigned short* w_x3;
@@ -727,11 +836,11 @@ struct PrepLayer {
     long long plane;
     int Cout, T, Cin;
     int first_block, gx, gy;  // this layer's blocks are [first_block, first_block + gx * gy * T)
+    int format;               // 0: three bf16 planes; 1: two fp16 planes + scale (f16x2)
     TapTable t;
 };
 
 __global__ __launch_bounds__(256) void weight_prepare_batch_kernel(const PrepLayer* __restrict__ layers, int n) {
-    __shared__ float tile[32][33];
     int lo = 0, hi = n - 1;  // last layer whose first_block <= blockIdx.x
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -741,34 +850,54 @@ __global__ __launch_bounds__(256) void weight_prepare_batch_kernel(const PrepLay
     const PrepLayer& L = layers[lo];
     const int local = blockIdx.x - L.first_block;
     const int bx = local % L.gx, by = (local / L.gx) % L.gy, z = local / (L.gx * L.gy);
-    const float* __restrict__ w = L.w;
-    const int Cout = L.Cout, T = L.T, Cin = L.Cin;
-    const long long plane = L.plane;
-    const int ci0 = bx * 32, co0 = by * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int src = L.t.src[z];
-    for (int r = ty; r < 32; r += 8) {
-        const int co = co0 + r, ci = ci0 + tx;
-        float v = 0.f;
-        if (co < Cout && ci < Cin) {
-            const size_t o = ((size_t)co * T + src) * Cin + ci;
-            v = w[o];
-            if (L.w_x3 != nullptr) split3_scalar(v, L.w_x3[o], L.w_x3[plane + o], L.w_x3[2 * plane + o]);
-        }
-        tile[r][tx] = v;
+    if (L.format == 1) {
+        const float s = h2_scale_of_parts(h2_layer_area(L.w_x3, L.wt_x3, L.plane), local == 0,
+                                          L.wt_x3 != nullptr ? h2_area(L.wt_x3, L.plane) : nullptr);
+        prep_tile<true>(L.w, L.w_x3, L.wt, L.wt_x3, L.plane, L.Cout, L.T, L.Cin, L.t.src[z], L.t.dst[z], L.t.row[z], bx * 32,
+                        by * 32, s);
+    } else {
+        prep_tile<false>(L.w, L.w_x3, L.wt, L.wt_x3, L.plane, L.Cout, L.T, L.Cin, L.t.src[z], L.t.dst[z], L.t.row[z], bx * 32,
+                         by * 32, 1.f);
     }
-    __syncthreads();
-    if (L.wt == nullptr && L.wt_x3 == nullptr) return;
-    const int rowstride = L.t.row[z];
-    for (int r = ty; r < 32; r += 8) {
-        const int ci = ci0 + r, co = co0 + tx;
-        if (ci < Cin && co < Cout) {
-            const size_t o = (size_t)L.t.dst[z] + (size_t)ci * rowstride + co;
-            const float v = tile[tx][r];
-            if (L.wt != nullptr) L.wt[o] = v;
-            if (L.wt_x3 != nullptr) split3_scalar(v, L.wt_x3[o], L.wt_x3[plane + o], L.wt_x3[2 * plane + o]);
+}
+
+// pass 1 of the f16x2 layers of a batch: H2_PARTS blocks per layer (block = layer * H2_PARTS + part)
+__global__ __launch_bounds__(256) void weight_absmax_batch_kernel(const PrepLayer* __restrict__ layers) {
+    const PrepLayer& L = layers[blockIdx.x / H2_PARTS];
+    if (L.format != 1) return;
+    h2_absmax_part(L.w, (long long)L.Cout * L.T * L.Cin, blockIdx.x % H2_PARTS, h2_layer_area(L.w_x3, L.wt_x3, L.plane));
+}
+
+__global__ __launch_bounds__(256) void weight_absmax_kernel(const float* __restrict__ w, long long n, float* area) {
+    h2_absmax_part(w, n, blockIdx.x, area);
+}
+
+__global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                         long long n, long long plane) {
+    const float s = h2_scale_of_parts(h2_area(dst, plane), blockIdx.x == 0);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        split2h_scalar(src[i], s, dst[i], dst[plane + i]);
+}
+
+__global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restrict__ x, int ld, long long npix, int C,
+                                                          float* __restrict__ slot) {
+    unsigned m = 0u;
+    if (ld == C && (C & 3) == 0) {  // dense: 16-B loads over the flat tensor
+        const long long n4 = npix * C / 4;
+        const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x);
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            const f32x4 v = x4[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = max(m, __float_as_uint(v[e]) & 0x7fffffffu);
+        }
+    } else {
+        const long long n = npix * C;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+            const long long pix = i / C;
+            m = max(m, __float_as_uint(x[pix * ld + (i - pix * C)]) & 0x7fffffffu);
         }
     }
+    hn_absmax_publish(m, slot);
 }
 
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
@@ -777,6 +906,13 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
         split3_scalar(src[i], dst[i], dst[plane + i], dst[2 * plane + i]);
 }
 
+}  // namespace
+
+namespace {
+// scale slot of an f16x2 plane buffer: behind the two planes
+inline const float* h2_scale_of(const void* planes, long long plane) {
+    return reinterpret_cast<const float*>(static_cast<const unsigned short*>(planes) + 2 * plane);
+}
 }  // namespace
 
 namespace {
@@ -796,6 +932,7 @@ ConvArgs fwd_args(const float* x, const float* w, const void* w_x3, const float*
     a.wx3 = static_cast<const unsigned short*>(w_x3);
     a.wx3_plane = hn_x3_plane((long long)d->Cout * a.Kdim);
     a.in_scale = a.in_shift = nullptr;
+    a.a_scale = a.w_scale = nullptr;
     return a;
 }
 }  // namespace
@@ -827,6 +964,7 @@ extern "C" int hn_conv2d_plan(int kind, const HnConvDesc* d, int has_planes, int
     // operand pointers only enter the plan through their alignment: stand-ins with the alignment the host guarantees
     const float* al = reinterpret_cast<const float*>(uintptr_t(256));
     ConvArgs a = fwd_args(al, al, has_planes ? al : nullptr, nullptr, const_cast<float*>(al), nullptr, d, HN_ACT_NONE, 0.f);
+    if (variant >= VARIANT_F16X2) a.a_scale = a.w_scale = al;
     bool can_split = d->ldy == d->Cout;
     if (kind == 1) {  // data gradient: the gathered tensor is dY, the produced one dX (first parity class when strided)
         const bool classes = parity_decomposable(d->KH, d->KW, d->stride, d->dil);
@@ -846,13 +984,22 @@ extern "C" int hn_conv2d_plan(int kind, const HnConvDesc* d, int has_planes, int
     return pl.family == FAM_V2 ? 1 : 0;
 }
 
-extern "C" int hn_conv2d_fwd(const float* x, const float* w, const void* w_x3, const float* bias, float* y, double* stats,
-                             const HnConvDesc* d, int act, float slope, int variant, void* stream) {
+namespace {
+int conv2d_fwd_impl(const float* x, const float* x_scale, const float* w, const void* w_x3, const float* bias, float* y,
+                    double* stats, const HnConvDesc* d, int act, float slope, int variant, void* stream) {
     if (x == nullptr || w == nullptr || y == nullptr) return HN_EINVAL;
     if (act < HN_ACT_NONE || act > HN_ACT_LEAKY) return HN_EINVAL;
     const int rc = check_desc(d);
     if (rc != HN_OK) return rc;
     ConvArgs a = fwd_args(x, w, w_x3, bias, y, stats, d, act, slope);
+    if (x_scale != nullptr) {
+        if (w_x3 == nullptr || variant < 0) return HN_EINVAL;
+        a.a_scale = x_scale;
+        a.w_scale = h2_scale_of(w_x3, a.wx3_plane);
+        variant = (variant & 63) | VARIANT_F16X2;
+    } else if (variant >= VARIANT_F16X2) {
+        return HN_EINVAL;  // f16x2 needs the operand scales: hn_conv2d_fwd_scaled
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     a.cps = (d->ldy == d->Cout && !g_deterministic) ? plan_split_k(a.M, a.K, a.Kdim) : 0;
     if (a.cps == 0) return dispatch_conv(a, variant, s);
@@ -872,6 +1019,19 @@ extern "C" int hn_conv2d_fwd(const float* x, const float* w, const void* w_x3, c
     }
     return HN_OK;
 }
+}  // namespace
+
+extern "C" int hn_conv2d_fwd(const float* x, const float* w, const void* w_x3, const float* bias, float* y, double* stats,
+                             const HnConvDesc* d, int act, float slope, int variant, void* stream) {
+    return conv2d_fwd_impl(x, nullptr, w, w_x3, bias, y, stats, d, act, slope, variant, stream);
+}
+
+extern "C" int hn_conv2d_fwd_scaled(const float* x, const float* x_scale, const float* w, const void* w_h2, const float* bias,
+                                    float* y, double* stats, const HnConvDesc* d, int act, float slope, int variant,
+                                    void* stream) {
+    if (x_scale == nullptr || w_h2 == nullptr) return HN_EINVAL;
+    return conv2d_fwd_impl(x, x_scale, w, w_h2, bias, y, stats, d, act, slope, variant, stream);
+}
 
 namespace {
 // dX = addend, or zero: what the accumulating (split-K / partially covered) data-gradient paths start from
@@ -884,9 +1044,16 @@ int init_output(float* dx, int ldx, const float* addend, int ldadd, int64_t npix
 }
 }  // namespace
 
-extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, const void* wt_x3, float* dx, const float* addend, int ldadd,
-                               const HnConvDesc* d, int variant, void* stream) {
+namespace {
+int conv2d_dgrad_impl(const float* dy, const float* dy_scale, const float* wt, const void* wt_x3, float* dx, const float* addend,
+                      int ldadd, const HnConvDesc* d, int variant, void* stream) {
     if (dy == nullptr || wt == nullptr || dx == nullptr) return HN_EINVAL;
+    if (dy_scale != nullptr) {
+        if (wt_x3 == nullptr || variant < 0) return HN_EINVAL;
+        variant = (variant & 63) | VARIANT_F16X2;
+    } else if (variant >= VARIANT_F16X2) {
+        return HN_EINVAL;
+    }
     if (addend != nullptr && (d == nullptr || ldadd < d->Cin)) return HN_EINVAL;
     const int rc = check_desc(d);
     if (rc != HN_OK) return rc;
@@ -903,6 +1070,8 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, const void* wt_
     a.wx3 = static_cast<const unsigned short*>(wt_x3);
     a.wx3_plane = hn_x3_plane((long long)d->Cin * d->KH * d->KW * d->Cout);
     a.in_scale = a.in_shift = nullptr;
+    a.a_scale = dy_scale;
+    a.w_scale = dy_scale != nullptr && wt_x3 != nullptr ? h2_scale_of(wt_x3, a.wx3_plane) : nullptr;
     a.gm = 1;
 
     if (!parity_decomposable(d->KH, d->KW, d->stride, d->dil)) {
@@ -971,21 +1140,83 @@ extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, const void* wt_
         }
     return HN_OK;
 }
+}  // namespace
 
-extern "C" int hn_weight_flip_transpose(const float* w, void* w_x3, float* wt, void* wt_x3, int Cout, int KH, int KW, int Cin,
-                                        int stride, int pad, int dil, void* stream) {
+extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, const void* wt_x3, float* dx, const float* addend, int ldadd,
+                               const HnConvDesc* d, int variant, void* stream) {
+    return conv2d_dgrad_impl(dy, nullptr, wt, wt_x3, dx, addend, ldadd, d, variant, stream);
+}
+
+extern "C" int hn_conv2d_dgrad_scaled(const float* dy, const float* dy_scale, const float* wt, const void* wt_h2, float* dx,
+                                      const float* addend, int ldadd, const HnConvDesc* d, int variant, void* stream) {
+    if (dy_scale == nullptr || wt_h2 == nullptr) return HN_EINVAL;
+    return conv2d_dgrad_impl(dy, dy_scale, wt, wt_h2, dx, addend, ldadd, d, variant, stream);
+}
+
+extern "C" int hn_absmax_scale(const float* x, int ld, int64_t npix, int C, float* scale, void* stream) {
+    if (x == nullptr || scale == nullptr || npix <= 0 || C <= 0 || ld < C) return HN_EINVAL;
+    const bool dense = ld == C && (C & 3) == 0;
+    if (dense && !hn_aligned16(x)) return HN_EALIGN;
+    const long long work = dense ? npix * C / 4 : npix * C;
+    long long blocks = (work + 256 * 8 - 1) / (256 * 8);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    HN_LAUNCH(absmax_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld,
+              (long long)npix, C, scale);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_split_f16x2(const float* src, void* dst, int64_t n, void* stream) {
+    if (src == nullptr || dst == nullptr || n <= 0) return HN_EINVAL;
+    if (n < H2_MIN_ELEMS) return HN_ESHAPE;
+    if (!hn_aligned16(dst)) return HN_EALIGN;
+    const long long plane = hn_x3_plane(n);
+    unsigned short* planes = static_cast<unsigned short*>(dst);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HN_LAUNCH(weight_absmax_kernel, dim3(H2_PARTS), dim3(256), 0, s, src, (long long)n,
+              reinterpret_cast<float*>(planes + 2 * plane));
+    HN_CHECK_LAUNCH();
+    const long long blocks = (n + 255) / 256;
+    HN_LAUNCH(split_f16x2_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, src, planes, (long long)n,
+              plane);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+namespace {
+int weight_flip_transpose_impl(const float* w, void* w_x3, float* wt, void* wt_x3, int Cout, int KH, int KW, int Cin, int stride,
+                               int pad, int dil, int format, void* stream) {
     if (w == nullptr || (wt == nullptr && wt_x3 == nullptr) || Cout <= 0 || KH <= 0 || KW <= 0 || Cin <= 0 || stride <= 0 ||
         pad < 0 || dil <= 0)
         return HN_EINVAL;
     if (KH * KW > 64) return HN_ESHAPE;
+    const long long n = (long long)Cout * KH * KW * Cin, plane = hn_x3_plane(n);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (format == 1) {
+        if (w_x3 == nullptr && wt_x3 == nullptr) return HN_EINVAL;
+        if (n < H2_MIN_ELEMS) return HN_ESHAPE;
+        unsigned short* planes = static_cast<unsigned short*>(w_x3 != nullptr ? w_x3 : wt_x3);
+        HN_LAUNCH(weight_absmax_kernel, dim3(H2_PARTS), dim3(256), 0, s, w, n, reinterpret_cast<float*>(planes + 2 * plane));
+        HN_CHECK_LAUNCH();
+    }
     TapTable t;
     build_tap_table(t, Cout, KH, KW, Cin, stride, pad, dil);
     const dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, KH * KW);
-    HN_LAUNCH(weight_taps_transpose_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w,
-              static_cast<unsigned short*>(w_x3), wt, static_cast<unsigned short*>(wt_x3),
-              hn_x3_plane((long long)Cout * KH * KW * Cin), Cout, KH * KW, Cin, t);
+    HN_LAUNCH(weight_taps_transpose_kernel, grid, dim3(256), 0, s, w, static_cast<unsigned short*>(w_x3), wt,
+              static_cast<unsigned short*>(wt_x3), plane, Cout, KH * KW, Cin, format, t);
     HN_CHECK_LAUNCH();
     return HN_OK;
+}
+}  // namespace
+
+extern "C" int hn_weight_flip_transpose(const float* w, void* w_x3, float* wt, void* wt_x3, int Cout, int KH, int KW, int Cin,
+                                        int stride, int pad, int dil, void* stream) {
+    return weight_flip_transpose_impl(w, w_x3, wt, wt_x3, Cout, KH, KW, Cin, stride, pad, dil, 0, stream);
+}
+
+extern "C" int hn_weight_flip_transpose_h2(const float* w, void* w_h2, float* wt, void* wt_h2, int Cout, int KH, int KW, int Cin,
+                                           int stride, int pad, int dil, void* stream) {
+    return weight_flip_transpose_impl(w, w_h2, wt, wt_h2, Cout, KH, KW, Cin, stride, pad, dil, 1, stream);
 }
 
 extern "C" size_t hn_weight_prep_table_bytes(int n) { return (size_t)(n > 0 ? n : 0) * sizeof(PrepLayer); }
@@ -1000,7 +1231,11 @@ extern "C" int hn_weight_prep_table_fill(const HnWeightPrepItem* items, int n, v
             it.KW <= 0 || it.Cin <= 0 || it.stride <= 0 || it.pad < 0 || it.dil <= 0)
             return HN_EINVAL;
         if (it.KH * it.KW > 64) return HN_ESHAPE;
+        if (it.format != 0 && it.format != 1) return HN_EINVAL;
+        if (it.format == 1 && (it.w_x3 == nullptr && it.wt_x3 == nullptr)) return HN_EINVAL;
+        if (it.format == 1 && (long long)it.Cout * it.KH * it.KW * it.Cin < H2_MIN_ELEMS) return HN_ESHAPE;
         PrepLayer& L = out[i];
+        L.format = it.format;
         L.w = it.w;
         L.w_x3 = static_cast<unsigned short*>(it.w_x3);
         L.wt = it.wt;
@@ -1017,8 +1252,13 @@ extern "C" int hn_weight_prep_table_fill(const HnWeightPrepItem* items, int n, v
     return HN_OK;
 }
 
-extern "C" int hn_weight_prepare_batch(const void* table_dev, int n, int total_blocks, void* stream) {
+extern "C" int hn_weight_prepare_batch(const void* table_dev, int n, int total_blocks, int has_f16x2, void* stream) {
     if (table_dev == nullptr || n <= 0 || total_blocks <= 0) return HN_EINVAL;
+    if (has_f16x2) {  // pass 1 of the f16x2 layers: partial maxima of |w|
+        HN_LAUNCH(weight_absmax_batch_kernel, dim3((unsigned)n * H2_PARTS), dim3(256), 0, static_cast<hipStream_t>(stream),
+                  static_cast<const PrepLayer*>(table_dev));
+        HN_CHECK_LAUNCH();
+    }
     HN_LAUNCH(weight_prepare_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
               static_cast<const PrepLayer*>(table_dev), n);
     HN_CHECK_LAUNCH();

@@ -45,6 +45,8 @@ struct WgradArgs {
     int accumulate; // dW += (always through atomics, never filled)
     float* slab;    // deterministic mode: split s stores its partial dW to slab + s*K*Kdim (no atomics); NULL otherwise
     long long x_bytes, dy_bytes;
+    const float* x_scale;   // f16x2: scale slots of x and of dy (hn_absmax_scale); NULL otherwise
+    const float* dy_scale;
 };
 
 __device__ __forceinline__ f32x4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
@@ -445,6 +447,20 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16
     }
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// f16x2: x * s = hi + lo (+ 2^-23 relative), s a power of two that puts the tensor's largest magnitude below 2^15
+__device__ __forceinline__ void split2h(const f32x4 v, float s, f16x4& h, f16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float xs = v[e] * s;
+        const _Float16 hh = (_Float16)xs;
+        h[e] = hh;
+        l[e] = (_Float16)(xs - (float)hh);
+    }
+}
+
 __device__ __forceinline__ bf16x4 round4(const f32x4 v) {
     bf16x4 h;
 #pragma unroll
@@ -470,7 +486,8 @@ __device__ __forceinline__ int x3_off(int k, int c) {
 }
 
 // NS = 3: bf16x3 as described above.  NS = 1: plain bf16 (HN_MATH_BF16, reduced precision) -- operands rounded to nearest
-// bf16 when staged, one MFMA per product.
+// bf16 when staged, one MFMA per product.  NS = 2: f16x2 -- both operands scaled by their tensor's power-of-two scale and
+// split into two fp16 terms, three products (lo*hi, hi*lo, hi*hi) on v_mfma_f32_16x16x32_f16, result scaled back.
 template <int TM, int TN, int NS = 3>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p) {
     constexpr int BKP = 32;
@@ -496,6 +513,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
     constexpr int RA = (BKP * CA) / 256, RB = (BKP * CB) / 256;
     constexpr int ROWS_A = 256 / CA, ROWS_B = 256 / CB;   // pixel rows covered by one pass of the 256 threads
     f32x4 va[2][RA], vb[2][RB];                           // two staging sets: two reduction steps of loads in flight
+    float s_dy = 1.f, s_x = 1.f, o_s = 1.f;
+    if constexpr (NS == 2) {
+        float i_dy, i_x;
+        hn_h2_scales_of_slot(p.dy_scale, s_dy, i_dy);  // from the tensors' max |.| bit patterns
+        hn_h2_scales_of_slot(p.x_scale, s_x, i_x);
+        o_s = i_dy * i_x;
+    }
 
     const int tap = n0 / p.C, ci0 = n0 - tap * p.C;       // a tile's column range lies inside one tap (C % BN == 0)
     const int vkh = tap / p.KW, vkw = tap - vkh * p.KW;
@@ -570,6 +594,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
                 *reinterpret_cast<bf16x4*>(dst) = h;
                 *reinterpret_cast<bf16x4*>(dst + PLANE_A) = m;
                 *reinterpret_cast<bf16x4*>(dst + 2 * PLANE_A) = l;
+            } else if constexpr (NS == 2) {
+                f16x4 h, l;
+                split2h(sa[q], s_dy, h, l);
+                *reinterpret_cast<f16x4*>(dst) = h;
+                *reinterpret_cast<f16x4*>(dst + PLANE_A) = l;
             } else {
                 *reinterpret_cast<bf16x4*>(dst) = round4(sa[q]);
             }
@@ -583,6 +612,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
                 *reinterpret_cast<bf16x4*>(dst) = h;
                 *reinterpret_cast<bf16x4*>(dst + PLANE_B) = m;
                 *reinterpret_cast<bf16x4*>(dst + 2 * PLANE_B) = l;
+            } else if constexpr (NS == 2) {
+                f16x4 h, l;
+                split2h(sb[q], s_x, h, l);
+                *reinterpret_cast<f16x4*>(dst) = h;
+                *reinterpret_cast<f16x4*>(dst + PLANE_B) = l;
             } else {
                 *reinterpret_cast<bf16x4*>(dst) = round4(sb[q]);
             }
@@ -634,6 +668,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
                 const int sb = 4 * (2 * (bi & 1) + (bj & 1));
                 f32x16& blk = acc[bi >> 1][bj >> 1];
                 f32x4 c = {blk[sb], blk[sb + 1], blk[sb + 2], blk[sb + 3]};
+                if constexpr (NS == 2) {
+                    const f16x8 ah = __builtin_bit_cast(f16x8, fa[0]), al = __builtin_bit_cast(f16x8, fa[1]);
+                    const f16x8 bh = __builtin_bit_cast(f16x8, fb[bj][0]), bl = __builtin_bit_cast(f16x8, fb[bj][1]);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);  // lo*hi
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);  // hi*lo
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);  // hi*hi
+                }
                 if constexpr (NS == 3) {
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][1], c, 0, 0, 0);  // mid*mid
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][2], c, 0, 0, 0);  // hi*lo
@@ -641,7 +682,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][1], c, 0, 0, 0);  // hi*mid
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][0], c, 0, 0, 0);  // mid*hi
                 }
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][0], c, 0, 0, 0);  // hi*hi
+                if constexpr (NS != 2) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][0], c, 0, 0, 0);  // hi*hi
                 blk[sb] = c[0];
                 blk[sb + 1] = c[1];
                 blk[sb + 2] = c[2];
@@ -686,8 +727,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
                     const int n = n0 + (wn * TN + j) * 32 + 16 * ((r >> 2) & 1) + (lane & 15);
                     if (FULL || (n < p.Kdim && row < p.K)) {
                         float* dst = out + (size_t)row * p.Kdim + n;
-                        if constexpr (ATOMIC) atomicAdd(dst, acc[i][j][r]);
-                        else *dst = acc[i][j][r];
+                        const float v = NS == 2 ? acc[i][j][r] * o_s : acc[i][j][r];
+                        if constexpr (ATOMIC) atomicAdd(dst, v);
+                        else *dst = v;
                     }
                 }
             }
@@ -702,7 +744,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
     }
 }
 
-// X3: 0 = fp32 MFMA kernel, 3 = bf16x3, 1 = bf16 (planes per operand of conv_wgrad_x3_kernel)
+// X3: 0 = fp32 MFMA kernel, 3 = bf16x3, 1 = bf16, 2 = f16x2 (planes per operand of conv_wgrad_x3_kernel)
 template <int TM, int TN, int MODE, int BKP, int X3 = 0>
 int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -757,10 +799,12 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
     }
 }
 
-static thread_local float* g_wgrad_slab = nullptr;  // set by hn_conv2d_wgrad_det around its call of hn_conv2d_wgrad
+namespace {
+int wgrad_impl(const float* x, const float* x_scale, const float* dy, const float* dy_scale, float* dw, const HnConvDesc* d,
+               int split_k, int variant, int flags, float* slab, void* stream);
 
-extern "C" int hn_conv2d_wgrad_det(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant,
-                                   int flags, float* workspace, void* stream) {
+int wgrad_det_impl(const float* x, const float* x_scale, const float* dy, const float* dy_scale, float* dw, const HnConvDesc* d,
+                   int split_k, int variant, int flags, float* workspace, void* stream) {
     if (d == nullptr || workspace == nullptr || split_k <= 0) return HN_EINVAL;
     if (d->N <= 0 || d->Hout <= 0 || d->Wout <= 0) return HN_EINVAL;
     const long long total_chunks = ((long long)d->N * d->Hout * d->Wout + 31) / 32;  // reduction steps of 32 pixels
@@ -769,10 +813,8 @@ extern "C" int hn_conv2d_wgrad_det(const float* x, const float* dy, float* dw, c
     s = (total_chunks + cps - 1) / cps;  // what launch_wgrad arrives at for this request
     const int accumulate = (flags & HN_WGRAD_ACCUMULATE) != 0;
     variant = (variant & ~3) | 1;        // 32-pixel reduction step (the split arithmetic above)
-    if (s == 1 && !accumulate) return hn_conv2d_wgrad(x, dy, dw, d, 1, variant, 0, stream);  // single store pass
-    g_wgrad_slab = workspace;
-    const int rc = hn_conv2d_wgrad(x, dy, dw, d, (int)s, variant, flags, stream);
-    g_wgrad_slab = nullptr;
+    if (s == 1 && !accumulate) return wgrad_impl(x, x_scale, dy, dy_scale, dw, d, 1, variant, 0, nullptr, stream);  // single store pass
+    const int rc = wgrad_impl(x, x_scale, dy, dy_scale, dw, d, (int)s, variant, flags, workspace, stream);
     if (rc != HN_OK) return rc;
     const long long n = (long long)d->Cout * d->KH * d->KW * d->Cin;
     const long long blocks = (n + 255) / 256;
@@ -782,13 +824,15 @@ extern "C" int hn_conv2d_wgrad_det(const float* x, const float* dy, float* dw, c
     return HN_OK;
 }
 
-extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant,
-                               int flags, void* stream) {
+int wgrad_impl(const float* x, const float* x_scale, const float* dy, const float* dy_scale, float* dw, const HnConvDesc* d,
+               int split_k, int variant, int flags, float* slab, void* stream) {
     if (x == nullptr || dy == nullptr || dw == nullptr || d == nullptr) return HN_EINVAL;
+    if ((x_scale == nullptr) != (dy_scale == nullptr) || variant < 0) return HN_EINVAL;
+    if (x_scale != nullptr) variant = (variant & 63) | (4 << 6);  // f16x2
+    else if (variant >= (4 << 6)) return HN_EINVAL;                // ... needs the operand scales
     if (d->N <= 0 || d->Hin <= 0 || d->Win <= 0 || d->Cin <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0 ||
         d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->dil <= 0 || d->pad < 0 || d->ldx < d->Cin || d->ldy < d->Cout)
         return HN_EINVAL;
-    if (variant < 0 || variant >= 256) return HN_EINVAL;
     // same encoding as hn_conv2d_fwd; the K-step field selects the pixel step (1 -> 32, 2 -> 16; fp32 MFMA only)
     const int bk_sel = variant & 3, tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3, math_sel = variant >> 6;
     if (bk_sel == 3 || tm_sel == 3 || tn_sel == 3) return HN_EINVAL;
@@ -800,7 +844,9 @@ extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const
     a.M = d->N * d->Hout * d->Wout;
     a.Kdim = d->KH * d->KW * d->Cin;
     a.ntm = a.ntn = a.chunks_per_split = a.atomic = 0;
-    a.slab = g_wgrad_slab;
+    a.slab = slab;
+    a.x_scale = x_scale;
+    a.dy_scale = dy_scale;
     a.dw_zeroed = (flags & HN_WGRAD_DW_ZEROED) != 0;
     a.accumulate = (flags & HN_WGRAD_ACCUMULATE) != 0;
     a.x_bytes = (((long long)d->N * d->Hin * d->Win - 1) * d->ldx + d->Cin) * 4;
@@ -818,9 +864,11 @@ extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const
         const int math = math_sel ? math_sel - 1 : hn_get_conv_math();  // HN_MATH_*
         if (math != HN_MATH_F32 && buf_ok && d->Cout % 64 == 0) {
             if (d->Cout % 128 != 0) wide_m = false;
+            if (math == HN_MATH_F16X2) return dispatch_wgrad<WG_VEC_BUF, 32, 2>(a, wide_m, wide_n, split_k, s);
             return math == HN_MATH_BF16 ? dispatch_wgrad<WG_VEC_BUF, 32, 1>(a, wide_m, wide_n, split_k, s)
                                         : dispatch_wgrad<WG_VEC_BUF, 32, 3>(a, wide_m, wide_n, split_k, s);
         }
+        if (math == HN_MATH_F16X2) return HN_ESHAPE;  // the caller chose the operand format: no other kernel takes the scales
 #ifdef HN_WG_DMA
         if (buf_ok) return dispatch_wgrad<WG_VEC_DMA, 32>(a, wide_m, wide_n, split_k, s);  // experiment: LDS-DMA staging
 #endif
@@ -829,7 +877,32 @@ extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const
                        : dispatch_wgrad<WG_VEC_BUF, 32>(a, wide_m, wide_n, split_k, s);
         return dispatch_wgrad<WG_VEC, 32>(a, wide_m, wide_n, split_k, s);
     }
+    if (x_scale != nullptr) return HN_ESHAPE;
     bool wide_n = a.Kdim > 64;
     if (tn_sel) wide_n = tn_sel == 2;
     return dispatch_wgrad<WG_SCALAR, 32>(a, wide_m, wide_n, split_k, s);
+}
+}  // namespace
+
+extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant,
+                               int flags, void* stream) {
+    return wgrad_impl(x, nullptr, dy, nullptr, dw, d, split_k, variant, flags, nullptr, stream);
+}
+
+extern "C" int hn_conv2d_wgrad_scaled(const float* x, const float* x_scale, const float* dy, const float* dy_scale, float* dw,
+                                      const HnConvDesc* d, int split_k, int variant, int flags, void* stream) {
+    if (x_scale == nullptr || dy_scale == nullptr) return HN_EINVAL;
+    return wgrad_impl(x, x_scale, dy, dy_scale, dw, d, split_k, variant, flags, nullptr, stream);
+}
+
+extern "C" int hn_conv2d_wgrad_det(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant,
+                                   int flags, float* workspace, void* stream) {
+    return wgrad_det_impl(x, nullptr, dy, nullptr, dw, d, split_k, variant, flags, workspace, stream);
+}
+
+extern "C" int hn_conv2d_wgrad_det_scaled(const float* x, const float* x_scale, const float* dy, const float* dy_scale,
+                                          float* dw, const HnConvDesc* d, int split_k, int variant, int flags,
+                                          float* workspace, void* stream) {
+    if (x_scale == nullptr || dy_scale == nullptr) return HN_EINVAL;
+    return wgrad_det_impl(x, x_scale, dy, dy_scale, dw, d, split_k, variant, flags, workspace, stream);
 }

@@ -49,3 +49,46 @@ __device__ __forceinline__ float hn_apply_act(float v, int act, float slope) {
     if (act == HN_ACT_PRELU || act == HN_ACT_LEAKY) return v > 0.f ? v : v * slope;
     return v;
 }
+
+// ---- f16x2 tensor scales (include/heatnet_hip.h) ----------------------------------------------------------------------
+// A tensor's scale slot is HN_SCALE_WORDS 32-bit words, HN_SCALE_STRIDE words apart (one per 128-B line), each the bit
+// pattern of the largest magnitude seen by the blocks that hash to it (as an unsigned integer the pattern is monotonic in
+// the magnitude; the words spread the producers' atomics over 64 lines).  Consumers
+// take the maximum over the words and derive s = 2^(14 - floor(log2 max|x|)), which puts that magnitude into
+// [2^14, 2^15) -- below fp16's 65504, and every element within 2^-18 of it keeps a normal `lo` term (22 significant
+// bits).  All-zero, infinite or NaN: s = 1.
+__device__ __forceinline__ void hn_h2_scales(unsigned bits, float& s, float& inv) {
+    const int e = (int)(bits >> 23);  // biased exponent of the maximum (sign bit already cleared)
+    s = 1.f;
+    inv = 1.f;
+    if (e > 0 && e < 255) {
+        int se = 127 + 14 - (e - 127);      // biased exponent of s
+        se = se < 1 ? 1 : (se > 253 ? 253 : se);
+        s = __uint_as_float((unsigned)se << 23);
+        inv = __uint_as_float((unsigned)(254 - se) << 23);
+    }
+}
+
+// wave-uniform: every lane of the calling wave takes part (one word per lane, six cross-lane steps)
+__device__ __forceinline__ void hn_h2_scales_of_slot(const float* slot, float& s, float& inv) {
+    const int lane = (threadIdx.y * blockDim.x + threadIdx.x) & (HN_SCALE_WORDS - 1);
+    unsigned m = reinterpret_cast<const unsigned*>(slot)[lane * HN_SCALE_STRIDE];
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    hn_h2_scales((unsigned)__builtin_amdgcn_readfirstlane((int)m), s, inv);
+}
+
+// Every thread of a 256-thread block (1-D or 2-D) calls this with the largest |value| bit pattern it produced (0 if none):
+// ONE no-return atomic max per block into word (block % HN_SCALE_WORDS).  Device-scope atomics on one word serialise at
+// ~11 ns each (MI355X_MICROARCH.md, fan-in): the words sit on 64 different 128-B lines.
+__device__ __forceinline__ void hn_absmax_publish(unsigned local, float* slot) {
+    __shared__ unsigned red[4];
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    for (int o = 32; o > 0; o >>= 1) local = max(local, (unsigned)__shfl_xor((int)local, o));
+    if ((t & 63) == 0) red[t >> 6] = local;
+    __syncthreads();
+    if (t == 0) {
+        const unsigned m = max(max(red[0], red[1]), max(red[2], red[3]));
+        const unsigned w = (blockIdx.y * gridDim.x + blockIdx.x) & (HN_SCALE_WORDS - 1);
+        if (m != 0u) atomicMax(reinterpret_cast<unsigned*>(slot) + w * HN_SCALE_STRIDE, m);
+    }
+}

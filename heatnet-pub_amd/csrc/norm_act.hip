@@ -83,27 +83,32 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ res, int ldr, float* __restrict__ z,
                                                         int ldz, int64_t npix, int C, int act, const float* slope_p,
-                                                        float leaky, const float* __restrict__ mask, int64_t hw) {
+                                                        float leaky, const float* __restrict__ mask, int64_t hw,
+                                                        float* __restrict__ z_scale) {
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
-    if (c >= C) return;
-    float sc[V], sh[V];
-    ldv<V>(scale + c, sc);
-    ldv<V>(shift + c, sh);
-    const float slope = act == HN_ACT_PRELU ? *slope_p : leaky;
-    for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
-        float v[V], r[V], o[V], m[V];
-        ldv<V>(y + pix * ldy + c, v);
-        if (res != nullptr) ldv<V>(res + pix * ldr + c, r);
-        if (mask != nullptr) ldv<V>(mask + (pix / hw) * C + c, m);  // Dropout2d keep/(1-p) factor of (image, channel)
+    unsigned amax = 0u;  // largest |z| written by this thread (f16x2 scale of the output, optional)
+    if (c < C) {
+        float sc[V], sh[V];
+        ldv<V>(scale + c, sc);
+        ldv<V>(shift + c, sh);
+        const float slope = act == HN_ACT_PRELU ? *slope_p : leaky;
+        for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
+            float v[V], r[V], o[V], m[V];
+            ldv<V>(y + pix * ldy + c, v);
+            if (res != nullptr) ldv<V>(res + pix * ldr + c, r);
+            if (mask != nullptr) ldv<V>(mask + (pix / hw) * C + c, m);  // Dropout2d keep/(1-p) factor of (image, channel)
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            float u = v[i] * sc[i] + sh[i];
-            if (res != nullptr) u += r[i];
-            o[i] = hn_apply_act(u, act, slope);
-            if (mask != nullptr) o[i] *= m[i];
+            for (int i = 0; i < V; ++i) {
+                float u = v[i] * sc[i] + sh[i];
+                if (res != nullptr) u += r[i];
+                o[i] = hn_apply_act(u, act, slope);
+                if (mask != nullptr) o[i] *= m[i];
+                amax = max(amax, __float_as_uint(o[i]) & 0x7fffffffu);
+            }
+            stv<V>(z + pix * ldz + c, o);
         }
-        stv<V>(z + pix * ldz + c, o);
     }
+    if (z_scale != nullptr) hn_absmax_publish(amax, z_scale);
 }
 
 // sums[0:C] += sum du ; sums[C:2C] += sum du*xhat ; sums[2C] += dslope   (double accumulation throughout)
@@ -236,9 +241,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
                                                               float inv_count, int training, float* __restrict__ dy, int lddy,
                                                               float* __restrict__ dres, int lddr, int64_t npix, int C, int act,
                                                               const float* slope_p, float leaky, const float* __restrict__ mask,
-                                                              int64_t hw) {
+                                                              int64_t hw, float* __restrict__ dy_scale) {
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
-    if (c >= C) return;
+    unsigned amax = 0u;  // largest |dy| written by this thread (f16x2 scale of the output, optional)
+    if (c < C) {
     float sc[V], sh[V], mu[V], is[V], ga[V], m1[V], m2[V];
     ldv<V>(scale + c, sc);
     ldv<V>(shift + c, sh);
@@ -272,10 +278,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
         }
         act_grad<V>(g, zz, yy, sc, sh, act, slope, zmask, du, unused);
 #pragma unroll
-        for (int i = 0; i < V; ++i) o[i] = ga[i] * (du[i] - m1[i] - (yy[i] - mu[i]) * is[i] * m2[i]);
+        for (int i = 0; i < V; ++i) {
+            o[i] = ga[i] * (du[i] - m1[i] - (yy[i] - mu[i]) * is[i] * m2[i]);
+            amax = max(amax, __float_as_uint(o[i]) & 0x7fffffffu);
+        }
         stv<V>(dy + pix * lddy + c, o);
         if (dres != nullptr) stv<V>(dres + pix * lddr + c, du);
     }
+    }
+    if (dy_scale != nullptr) hn_absmax_publish(amax, dy_scale);
 }
 
 __global__ void bn_finalize_kernel(double* __restrict__ stats, double inv_count, double unbias,
@@ -478,14 +489,14 @@ extern "C" int hn_bn_eval_params(const float* gamma, const float* beta, const fl
 
 extern "C" int hn_bn_act_fwd(const float* y, int ldy, const float* scale, const float* shift, const float* residual,
                              int ldr, float* z, int ldz, int64_t npix, int C, int act, const float* slope,
-                             float leaky_slope, const float* mask, int64_t hw, void* stream) {
+                             float leaky_slope, const float* mask, int64_t hw, float* z_scale, void* stream) {
     if (!y || !scale || !shift || !z || act < 0 || act > 3 || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
     if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
     if (bad_rows(npix, C, {ldy, ldz}) || (residual && ldr < C)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const RowLaunch pl = plan_rows(npix, C, {y, z, residual, scale, shift, mask}, {ldy, ldz, residual ? ldr : 4});
     HN_LAUNCH_V(pl, bn_act_fwd_kernel, y, ldy, scale, shift, residual, ldr, z, ldz, npix, C, act, slope, leaky_slope, mask,
-                hw);
+                hw, z_scale);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -541,7 +552,7 @@ extern "C" int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, in
                                    const float* mean, const float* invstd, const float* gamma, const float* scale,
                                    const float* shift, const float* dparams, int64_t count, int training, float* dy,
                                    int lddy, float* dres, int lddr, int64_t npix, int C, int act, const float* slope,
-                                   float leaky_slope, const float* mask, int64_t hw, void* stream) {
+                                   float leaky_slope, const float* mask, int64_t hw, float* dy_scale, void* stream) {
     if (!dz || !y || !mean || !invstd || !gamma || !scale || !shift || !dy || act < 0 || act > 3) return HN_EINVAL;
     if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
     if ((training && (!dparams || count <= 0)) || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
@@ -553,7 +564,7 @@ extern "C" int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, in
                   {lddz, ldy, lddy, dres ? lddr : 4, zmask ? ldz : 4});
     const float inv_count = training ? (float)(1.0 / (double)count) : 0.f;
     HN_LAUNCH_V(pl, bn_act_bwd_apply_kernel, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, dparams, inv_count,
-                training, dy, lddy, dres, lddr, npix, C, act, slope, leaky_slope, mask, hw);
+                training, dy, lddy, dres, lddr, npix, C, act, slope, leaky_slope, mask, hw, dy_scale);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

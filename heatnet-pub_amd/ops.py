@@ -8,6 +8,7 @@ allocation, autograd bookkeeping and streams only -- no arithmetic of the hot pa
 """
 import ctypes
 import os
+import sys
 import weakref
 
 import torch
@@ -165,8 +166,14 @@ if AUTOTUNE:
 # "bf16":   REDUCED precision (BASELINE configs[4]): operands rounded to nearest bf16 as they are staged, one bf16 MFMA
 #           per product, fp32 accumulation; tensors in memory, BatchNorm statistics, master weights and the optimizer
 #           stay fp32.  Never the default; bench.py reports it as a separate workload with dtype "bf16".
-_MATH_CODES = {"f32": 1, "bf16x3": 2, "bf16": 3}
-_PLANE_MATHS = ("bf16x3", "bf16")  # arithmetics that take the weight operand as pre-made bf16 planes
+# "f16x2":  fp32 results from TWO fp16 terms per operand: every operand tensor is scaled by a power of two (its largest
+#           magnitude -> [2^14, 2^15)) and split into hi + lo fp16 terms, three products per fp32 product, fp32 accumulate
+#           (include/heatnet_hip.h).  As accurate as the fp32 MFMA against fp64 where the reduction is long (the 2^-23
+#           representation error of a product is below the accumulation error); layers whose reduction is shorter than
+#           H2_MIN_K terms run on bf16x3, shapes neither covers on f32.
+_MATH_CODES = {"f32": 1, "bf16x3": 2, "bf16": 3, "f16x2": 4}
+_PLANE_MATHS = ("bf16x3", "bf16", "f16x2")  # arithmetics that take the weight operand as pre-made 16-bit planes
+H2_MIN_K = int(os.environ.get("HEATNET_F16X2_MIN_K", "0"))
 CONV_MATH = os.environ.get("HEATNET_CONV_MATH", "bf16x3")
 if CONV_MATH not in _MATH_CODES:
     raise RuntimeError("HEATNET_CONV_MATH must be one of %s" % sorted(_MATH_CODES))
@@ -178,8 +185,17 @@ def _math(kind):
     return "f32" if kind in _MATH_F32_KINDS else CONV_MATH
 
 
+def _layer_math(kind, cin, cout, kh, kw):
+    """Arithmetic of one launch kind of one layer: "f16x2" only where both reductions of the layer (forward: KH*KW*Cin,
+    data gradient: KH*KW*Cout) have at least H2_MIN_K terms, else "bf16x3" -- one format of weight planes per layer."""
+    m = _math(kind)
+    if m == "f16x2" and (kh * kw * min(cin, cout) < H2_MIN_K or cin % 32 != 0 or cin * cout * kh * kw < 256):
+        return "bf16x3"
+    return m
+
+
 def set_conv_math(name):
-    """Select the conv arithmetic ("f32" | "bf16x3" | "bf16") for subsequent launches; returns the previous setting."""
+    """Select the conv arithmetic ("f32" | "bf16x3" | "f16x2" | "bf16") for subsequent launches; returns the previous setting."""
     global CONV_MATH
     if name not in _MATH_CODES:
         raise ValueError("conv math must be one of %s" % sorted(_MATH_CODES))
@@ -256,7 +272,7 @@ class _WeightPrepRegistry:
         self.entries = {}      # (id(param), stride, pad, dil) -> dict(ref, geom, wx3, wt, wtx3, last_scope)
         self.signature = None  # what the device table was built for
         self.table = None
-        self.n = self.blocks = 0
+        self.n = self.blocks = self.has_h2 = 0
         # scope ids are not consecutive (weights_changed() -- every optimizer step -- bumps them too): remember which
         # id the layers of the previous frozen_weights() scope were touched under
         self.prev_touch = self.cur_touch = None
@@ -265,11 +281,11 @@ class _WeightPrepRegistry:
         if self.cur_touch is not None:
             self.prev_touch, self.cur_touch = self.cur_touch, None
 
-    def touch(self, leaf, geom, wx3, wt, wtx3):
+    def touch(self, leaf, geom, wx3, wt, wtx3, fmt=0):
         key = (id(leaf),) + geom
         e = self.entries.get(key)
         if e is None or e["ref"]() is not leaf or e["wx3"] is not wx3:
-            e = self.entries[key] = dict(ref=weakref.ref(leaf), geom=geom, wx3=wx3, wt=wt, wtx3=wtx3)
+            e = self.entries[key] = dict(ref=weakref.ref(leaf), geom=geom, wx3=wx3, wt=wt, wtx3=wtx3, fmt=fmt)
         e["last_scope"] = self.cur_touch = _frozen_scope
 
     def run(self):
@@ -284,7 +300,7 @@ class _WeightPrepRegistry:
             return
         lib = _lib.load()
         sig = tuple((w.data_ptr(), e["geom"], e["wx3"].data_ptr(), e["wt"].data_ptr() if e["wt"] is not None else 0,
-                     e["wtx3"].data_ptr() if e["wtx3"] is not None else 0) for w, e in live)
+                     e["wtx3"].data_ptr() if e["wtx3"] is not None else 0, e["fmt"]) for w, e in live)
         if sig != self.signature:  # first use, parameters re-homed (arena), or another set of layers (phase switch)
             items = (HnWeightPrepItem * len(live))()
             for it, (w, e) in zip(items, live):
@@ -294,15 +310,18 @@ class _WeightPrepRegistry:
                 it.wt = e["wt"].data_ptr() if e["wt"] is not None else None      # forward-only layers (frozen phase):
                 it.wt_x3 = e["wtx3"].data_ptr() if e["wtx3"] is not None else None  # planes of w only
                 it.Cout, it.KH, it.KW, it.Cin, it.stride, it.pad, it.dil = cout, kh, kw, cin, stride, pad, dil
+                it.format = e["fmt"]
             host = torch.empty(lib.hn_weight_prep_table_bytes(len(live)), dtype=torch.uint8)
             blocks = ctypes.c_int(0)
             check(lib.hn_weight_prep_table_fill(items, len(live), ctypes.c_void_p(host.data_ptr()), ctypes.byref(blocks)),
                   "hn_weight_prep_table_fill")
             self.table = host.to(live[0][0].device)
             self.n, self.blocks, self.signature = len(live), blocks.value, sig
-        check(lib.hn_weight_prepare_batch(_ptr(self.table), self.n, self.blocks, _stream()), "hn_weight_prepare_batch")
+            self.has_h2 = int(any(e["fmt"] == 1 for _, e in live))
+        check(lib.hn_weight_prepare_batch(_ptr(self.table), self.n, self.blocks, self.has_h2, _stream()),
+              "hn_weight_prepare_batch")
         for w, e in live:
-            w._hn_prep = ((w.data_ptr(), w._version, _frozen_scope) + e["geom"], e["wx3"], e["wt"], e["wtx3"])
+            w._hn_prep = ((w.data_ptr(), w._version, _frozen_scope) + e["geom"] + (e["fmt"],), e["wx3"], e["wt"], e["wtx3"])
             e["last_scope"] = self.cur_touch = _frozen_scope
 
 
@@ -323,9 +342,71 @@ def x3_plane(n):
     return (n + 7) & ~7
 
 
-def _kind(kind):
-    """Tune-cache key of a launch kind under the current arithmetic."""
-    return kind if _math(kind) == "f32" else kind + "." + _math(kind)
+def _kind(kind, math=None):
+    """Tune-cache key of a launch kind under an arithmetic (default: the current one)."""
+    math = math or _math(kind)
+    return kind if math == "f32" else kind + "." + math
+
+
+# ---- f16x2 operand scales ---------------------------------------------------------------------------------------------
+# One slot of 64 32-bit words (on 64 different lines: SCALE_SLOT_FLOATS floats) per tensor (bit patterns of its largest magnitude, accumulated by the producing pass or by
+# hn_absmax_scale; include/heatnet_hip.h), handed out from zero-filled chunks (one fill per 512 scales) and never reused; a
+# chunk is released by the allocator when the last tensor / autograd node holding one of its slots is gone.  A scale is
+# remembered on the tensor it was computed for (`_hn_scale`, with the tensor's version counter).
+_ABSMAX_TRACE = os.environ.get("HEATNET_ABSMAX_TRACE") == "1"  # diagnostics: who still needs a pass of its own
+SCALE_SLOT_FLOATS = 64 * 32  # HN_SCALE_SLOT_FLOATS: 64 words on 64 different 128-B lines
+_scale_chunks = {}
+absmax_launches = 0  # hn_absmax_scale passes made so far (diagnostics: scales not supplied by a producing kernel)
+
+
+def _new_scale_slot(device):
+    c = _scale_chunks.get(device)
+    if c is None or c[1] >= c[0].shape[0]:
+        c = _scale_chunks[device] = [torch.zeros((512, SCALE_SLOT_FLOATS), device=device, dtype=torch.float32), 0]
+    slot = c[0][c[1]]
+    c[1] += 1
+    return slot
+
+
+def tensor_scale(t, ld=None, owner=None):
+    """f16x2 scale of the NHWC tensor `t` (pixel stride `ld`); `owner`: the tensor object to remember it on (the caller's
+    original when `t` is a re-laid-out copy)."""
+    owner = t if owner is None else owner
+    hit = getattr(owner, "_hn_scale", None)
+    if hit is not None and hit[0] == owner._version and hit[1].device == t.device:
+        return hit[1]
+    global absmax_launches
+    absmax_launches += 1
+    if _ABSMAX_TRACE:
+        import traceback
+        print("absmax", tuple(t.shape), [f.name for f in traceback.extract_stack()[-6:-1]], file=sys.stderr)
+    n, c, h, w = t.shape
+    slot = _new_scale_slot(t.device)
+    check(_lib.load().hn_absmax_scale(_ptr(t), c if ld is None else ld, n * h * w, c, _ptr(slot), _stream()), "hn_absmax_scale")
+    owner._hn_scale = (owner._version, slot)
+    return slot
+
+
+def _inherit_scale(out, src):
+    """`out` holds no magnitude larger than `src` does (an alias, a max / average pooling, a bilinear resampling -- convex
+    combinations of src's elements): src's scale slot is a valid, at most slightly conservative, bound for it."""
+    hit = getattr(src, "_hn_scale", None)
+    if hit is not None and hit[0] == src._version:
+        out._hn_scale = (out._version, hit[1])
+    return out
+
+
+_h2_cover = {}
+
+
+def _h2_covers(kind_idx, d):
+    """Do the f16x2 kernels cover this forward (0) / data-gradient (1) geometry?"""
+    key = (kind_idx,) + tuple(getattr(d, f) for f, _ in HnConvDesc._fields_)
+    r = _h2_cover.get(key)
+    if r is None:
+        buf = ctypes.create_string_buffer(128)
+        r = _h2_cover[key] = _lib.load().hn_conv2d_plan(kind_idx, ctypes.byref(d), 1, _variant(0, 0, 0, 4), buf, 128) >= 0
+    return r
 
 
 def _pick(kind, d, candidates, launch):
@@ -372,26 +453,28 @@ def _tune_scratch(like):
 _X3_SCHEDULES = tuple(int(v) for v in os.environ.get("HEATNET_X3_SCHEDULES", "1").split(","))
 
 
-def _igemm_candidates(cout, kind, cred=0):
+def _igemm_candidates(cout, kind, cred=0, math_name=None):
     """Variant codes to time for an implicit-GEMM launch with `cout` output and `cred` reduction channels."""
     tiles = [(0, 0), (1, 2), (2, 1)] if cout > 64 else [(0, 0), (1, 1)]
-    math = _MATH_CODES[_math(kind)]
+    math_name = math_name or _math(kind)
+    math = _MATH_CODES[math_name]
     # the `bk` field: K step 32 / 16 of the fp32-MFMA kernels; schedule of the bf16x3 kernels (1 = two-phase,
     # conv_igemm.hip; 2 = wave-specialised, conv_igemm2.hip -- slower on every shape of this network, so it is not a
     # tuning candidate; 3 = 128 x 256 tile with the weight planes by LDS-DMA, conv_igemm3.hip -- a few per cent faster on
     # some of the 3x3 and wide 1x1 layers in isolation, slower on others, no gain over a step); the bf16 kernels have one
-    bks = {"f32": (1, 2), "bf16x3": (1,), "bf16": (0,)}[_math(kind)]
+    bks = {"f32": (1, 2), "bf16x3": (1,), "bf16": (0,), "f16x2": (0,)}[math_name]
     cands = [_variant(bk, tm, tn, math) for tm, tn in tiles for bk in bks]
-    if _math(kind) == "bf16x3" and 3 in _X3_SCHEDULES and cout >= 192 and cred % 32 == 0 and cred > 0:
+    if math_name == "bf16x3" and 3 in _X3_SCHEDULES and cout >= 192 and cred % 32 == 0 and cred > 0:
         cands.append(_variant(3, 0, 0, math))  # (conv3_covers; a launch it does not cover runs the first schedule)
     return cands
 
 
-def _wgrad_candidates(cout, cin):
+def _wgrad_candidates(cout, cin, math_name=None):
     tms = (0, 1) if cout > 64 else (0,)
     tns = (0, 1) if cin % 128 == 0 else (0,)
-    math = _MATH_CODES[_math("wgrad")]
-    bks = (1, 2) if _math("wgrad") == "f32" else (1,)  # (pixel step; the bf16 weight-gradient kernels have one)
+    math_name = math_name or _math("wgrad")
+    math = _MATH_CODES[math_name]
+    bks = (1, 2) if math_name == "f32" else (1,)  # (pixel step; the bf16 / fp16 weight-gradient kernels have one)
     return [(split, _variant(bk, tm, tn, math)) for tm in tms for tn in tns for bk in bks for split in (0, -2, -3, -4)]
 
 
@@ -523,14 +606,16 @@ class _Conv2d(torch.autograd.Function):
         s = _stream()
         ctx.wt = ctx.wtx3 = None
         wx3 = None
-        if _math("fwd") in _PLANE_MATHS:
-            # Weight operands of the bf16x3 / bf16 kernels: the bf16 planes of w for the forward and -- when a data gradient
-            # will follow -- the flipped / transposed weights (fp32 and planes) for dgrad, all made by ONE launch.  They
-            # are kept on the parameter and reused inside a frozen_weights() scope (second pass of a confusion-
+        lm = _layer_math("fwd", cin, cout, kh, kw)  # this layer's arithmetic (f16x2 layers: one plane format for all kinds)
+        fmt = 1 if lm == "f16x2" else 0
+        if lm in _PLANE_MATHS:
+            # Weight operands of the bf16x3 / bf16 / f16x2 kernels: the 16-bit planes of w for the forward and -- when a data
+            # gradient will follow -- the flipped / transposed weights (fp32 and planes) for dgrad, all made by ONE launch.
+            # They are kept on the parameter and reused inside a frozen_weights() scope (second pass of a confusion-
             # maximisation step, evaluation loops).
-            want_t = _math("dgrad") in _PLANE_MATHS and ctx.needs_input_grad[0]
+            want_t = _layer_math("dgrad", cin, cout, kh, kw) in _PLANE_MATHS and ctx.needs_input_grad[0]
             leaf = _leaf(w_in) if w is w_in else None
-            key = (w.data_ptr(), w._version, _frozen_scope, stride, pad, dil)
+            key = (w.data_ptr(), w._version, _frozen_scope, stride, pad, dil, fmt)
             prep = getattr(leaf, "_hn_prep", None) if (leaf is not None and _frozen_depth > 0) else None
             if prep is None or prep[0] != key or (want_t and prep[2] is None):
                 nw = w.numel()
@@ -538,24 +623,37 @@ class _Conv2d(torch.autograd.Function):
                 if want_t:
                     wt = torch.empty(nw, device=x.device, dtype=torch.float32)
                     wtx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16)
-                    check(lib.hn_weight_flip_transpose(_ptr(w), _ptr(wx3), _ptr(wt), _ptr(wtx3), cout, kh, kw, cin, stride,
-                                                       pad, dil, s), "hn_weight_flip_transpose")
+                    flip = lib.hn_weight_flip_transpose_h2 if fmt else lib.hn_weight_flip_transpose
+                    check(flip(_ptr(w), _ptr(wx3), _ptr(wt), _ptr(wtx3), cout, kh, kw, cin, stride, pad, dil, s),
+                          "hn_weight_flip_transpose")
                 else:
                     wt = wtx3 = None
-                    check(lib.hn_split_bf16x3(_ptr(w), _ptr(wx3), nw, s), "hn_split_bf16x3")
+                    check((lib.hn_split_f16x2 if fmt else lib.hn_split_bf16x3)(_ptr(w), _ptr(wx3), nw, s), "hn_split_planes")
                 prep = (key, wx3, wt, wtx3)
                 if leaf is not None and _frozen_depth > 0:
                     leaf._hn_prep = prep
-                    _prep_registry.touch(leaf, (stride, pad, dil), wx3, wt, wtx3)  # next scope: one batched launch
+                    _prep_registry.touch(leaf, (stride, pad, dil), wx3, wt, wtx3, fmt)  # next scope: one batched launch
             elif leaf is not None:
-                _prep_registry.touch(leaf, (stride, pad, dil), prep[1], prep[2], prep[3])
+                _prep_registry.touch(leaf, (stride, pad, dil), prep[1], prep[2], prep[3], fmt)
             _, wx3, ctx.wt, ctx.wtx3 = prep
-        var = _pick(_kind("fwd"), d, _igemm_candidates(cout, "fwd", cin), lambda v: check(
-            lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), None, ctypes.byref(d), act, slope, v, s),
-            "hn_conv2d_fwd"))
+        ctx.lm = lm
+        ctx.x_scale = None
+        if lm == "f16x2" and _h2_covers(0, d) and x.data_ptr() % 16 == 0:
+            xs = ctx.x_scale = tensor_scale(x, ldx, owner=x_in)
+
+            def launch(v, st):
+                check(lib.hn_conv2d_fwd_scaled(_ptr(x), _ptr(xs), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), _ptr(st),
+                                               ctypes.byref(d), act, slope, v, s), "hn_conv2d_fwd_scaled")
+        else:
+            if lm == "f16x2":
+                lm, wx3 = "f32", None  # a geometry the f16x2 kernels do not cover (the fp16 planes are of no use to the others)
+
+            def launch(v, st):
+                check(lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), _ptr(st), ctypes.byref(d), act, slope,
+                                        v, s), "hn_conv2d_fwd")
+        var = _pick(_kind("fwd", lm), d, _igemm_candidates(cout, "fwd", cin, lm), lambda v: launch(v, None))
         with _ConvTimer("fwd", d, lambda: _plan_name(0, d, wx3 is not None, var)):
-            check(lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), _ptr(stats), ctypes.byref(d), act, slope,
-                                    var, s), "hn_conv2d_fwd")
+            launch(var, stats)
         ctx.geom = (stride, pad, dil, act, slope)
         ctx.has_bias = b is not None
         ctx.w_leaf, ctx.b_leaf = _leaf(w_in), _leaf(b)
@@ -595,24 +693,38 @@ class _Conv2d(torch.autograd.Function):
         if OVERLAP and _conv_prof is None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             fork = torch.cuda.Event()
             fork.record()  # dy (and the activation backward that produced it) is complete up to here
+        lm = ctx.lm  # the layer's arithmetic as decided (and its weight planes made) at forward time
+        h2_layer = lm == "f16x2"
+        dy_scale = None
         if ctx.needs_input_grad[0]:
             nw = cin * kh * kw * cout
-            wt, wtx3 = ctx.wt, ctx.wtx3  # prepared by the forward (bf16x3), else made here
+            wt, wtx3 = ctx.wt, ctx.wtx3  # prepared by the forward (plane arithmetics), else made here
+            dm = lm if lm != "f16x2" else _layer_math("dgrad", cin, cout, kh, kw)
             if wt is None:
                 wt = torch.empty(nw, device=x.device, dtype=torch.float32)
-                wtx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16) \
-                    if _math("dgrad") in _PLANE_MATHS else None
-                check(lib.hn_weight_flip_transpose(_ptr(w), None, _ptr(wt), _ptr(wtx3), cout, kh, kw, cin, stride, pad, dil,
-                                                   s), "hn_weight_flip_transpose")
+                wtx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16) if dm in _PLANE_MATHS else None
+                flip = lib.hn_weight_flip_transpose_h2 if (h2_layer and wtx3 is not None) else lib.hn_weight_flip_transpose
+                check(flip(_ptr(w), None, _ptr(wt), _ptr(wtx3), cout, kh, kw, cin, stride, pad, dil, s),
+                      "hn_weight_flip_transpose")
             dx = new_nhwc(n, cin, h, wd, x.device)
             dd = _desc(n, h, wd, cin, cin, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
-            var = _pick(_kind("dgrad"), dd, _igemm_candidates(cin, "dgrad", cout), lambda v: check(
-                lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(wtx3), _ptr(dx), None, 0, ctypes.byref(dd), v, s),
-                "hn_conv2d_dgrad"))
             add, ldadd = (None, 0) if dskip is None else as_nhwc(dskip)
+            if h2_layer and wtx3 is not None and _h2_covers(1, dd) and dy.data_ptr() % 16 == 0:
+                dy_scale = tensor_scale(dy, lddy)
+
+                def launch(v, ad, ld):
+                    check(lib.hn_conv2d_dgrad_scaled(_ptr(dy), _ptr(dy_scale), _ptr(wt), _ptr(wtx3), _ptr(dx), _ptr(ad), ld,
+                                                     ctypes.byref(dd), v, s), "hn_conv2d_dgrad_scaled")
+            else:
+                if h2_layer:
+                    dm, wtx3 = "f32", None  # not covered: the fp32 MFMA on the fp32 copy of the operand
+
+                def launch(v, ad, ld):
+                    check(lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(wtx3), _ptr(dx), _ptr(ad), ld, ctypes.byref(dd), v, s),
+                          "hn_conv2d_dgrad")
+            var = _pick(_kind("dgrad", dm), dd, _igemm_candidates(cin, "dgrad", cout, dm), lambda v: launch(v, None, 0))
             with _ConvTimer("dgrad", dd, lambda: _plan_name(1, dd, wtx3 is not None, var)):
-                check(lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(wtx3), _ptr(dx), _ptr(add), ldadd, ctypes.byref(dd), var,
-                                          s), "hn_conv2d_dgrad")
+                launch(var, add, ldadd)
         elif dskip is not None:
             dx = dskip
         dw_out = None
@@ -625,32 +737,55 @@ class _Conv2d(torch.autograd.Function):
                 dw_out = dw if slot[1] else None  # a later use adds in place and reports no gradient of its own
             else:
                 dw_out = dw = torch.empty((cout, kh, kw, cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
+            # f16x2 layer: the weight gradient too where its kernel covers the geometry (whole 64-channel blocks both ways),
+            # with the input's scale from the forward and dY's from the data gradient above; elsewhere as under bf16x3
+            wm = lm if not h2_layer else _layer_math("wgrad", cin, cout, kh, kw)
+            h2_w = (h2_layer and wm == "f16x2" and cin % 64 == 0 and cout % 64 == 0 and ldx % 4 == 0 and lddy % 4 == 0 and
+                    x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and
+                    ((n * h * wd - 1) * ldx + cin) * 4 < 0xFFFF0000 and ((npix - 1) * lddy + cout + 64 * lddy) * 4 < 0xFFFF0000)
+            if h2_w:
+                x_scale = ctx.x_scale if ctx.x_scale is not None else tensor_scale(x, ldx)
+                dy_scale = dy_scale if dy_scale is not None else tensor_scale(dy, lddy)
+
+                def wgrad(dst, sp, v, fl, stream=s):
+                    check(lib.hn_conv2d_wgrad_scaled(_ptr(x), _ptr(x_scale), _ptr(dy), _ptr(dy_scale), _ptr(dst), ctypes.byref(d),
+                                                     sp, v, fl, stream), "hn_conv2d_wgrad_scaled")
+
+                def wgrad_det(sp, v, fl, wsp):
+                    check(lib.hn_conv2d_wgrad_det_scaled(_ptr(x), _ptr(x_scale), _ptr(dy), _ptr(dy_scale), _ptr(dw),
+                                                         ctypes.byref(d), sp, v, fl, _ptr(wsp), s), "hn_conv2d_wgrad_det_scaled")
+            else:
+                if h2_layer:
+                    wm = "bf16x3"  # (the library itself falls back to the fp32 MFMA where bf16x3 does not cover either)
+
+                def wgrad(dst, sp, v, fl, stream=s):
+                    check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dst), ctypes.byref(d), sp, v, fl, stream), "hn_conv2d_wgrad")
+
+                def wgrad_det(sp, v, fl, wsp):
+                    check(lib.hn_conv2d_wgrad_det(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), sp, v, fl, _ptr(wsp), s),
+                          "hn_conv2d_wgrad_det")
             if DETERMINISTIC:
                 # fixed plan: one reduction split per 4096 output pixels (at most 32), tile choice left to the library
                 splits = max(1, min(32, npix // 4096))
                 wsp = _det_workspace(x.device, splits * dw.numel())
-                var = _variant(1, 0, 0, _MATH_CODES[_math("wgrad")])
+                var = _variant(1, 0, 0, _MATH_CODES[wm])
                 with _ConvTimer("wgrad", d, "conv_wgrad_*"):
-                    check(lib.hn_conv2d_wgrad_det(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), splits, var, flags & 2,
-                                                  _ptr(wsp), s), "hn_conv2d_wgrad_det")
+                    wgrad_det(splits, var, flags & 2, wsp)
                 split = None
             else:
-                split, var = _pick(_kind("wgrad"), d, _wgrad_candidates(cout, cin), lambda sv: check(
-                    lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(_tune_scratch(dw) if flags else dw), ctypes.byref(d), sv[0], sv[1], 0, s),
-                    "hn_conv2d_wgrad"))
+                split, var = _pick(_kind("wgrad", wm), d, _wgrad_candidates(cout, cin, wm),
+                                   lambda sv: wgrad(_tune_scratch(dw) if flags else dw, sv[0], sv[1], 0))
             if split is None:
                 pass
             elif OVERLAP and _conv_prof is None and ctx.needs_input_grad[0]:
                 # the dgrad above is already queued on the main stream; wgrad runs beside it on the side stream
                 main, side = torch.cuda.current_stream(), _side_stream(x.device)
                 side.wait_event(fork)
-                check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), split, var, flags,
-                                          ctypes.c_void_p(side.cuda_stream)), "hn_conv2d_wgrad")
+                wgrad(dw, split, var, flags, ctypes.c_void_p(side.cuda_stream))
                 main.wait_stream(side)
             else:
                 with _ConvTimer("wgrad", d, "conv_wgrad_*"):
-                    check(lib.hn_conv2d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), split, var, flags, s),
-                          "hn_conv2d_wgrad")
+                    wgrad(dw, split, var, flags)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             slot = grad_slot(ctx.b_leaf, accumulate_ok=False) if ctx.b_leaf is not None else None
             db = slot[0] if slot is not None else None
@@ -673,8 +808,11 @@ def conv2d(x, w, b=None, stride=1, pad=0, dil=1, act=ACT_NONE, slope=0.0, want_s
     instead of the rounding noise a full reduction pass over dy would produce."""
     if passthrough and want_stats is True:
         raise ValueError("conv2d: passthrough cannot be combined with want_stats=True")
-    return _Conv2d.apply(x, w, b, int(stride), int(pad), int(dil), int(act), float(slope), want_stats, bool(passthrough),
-                         bool(zero_bias_grad))
+    out = _Conv2d.apply(x, w, b, int(stride), int(pad), int(dil), int(act), float(slope), want_stats, bool(passthrough),
+                        bool(zero_bias_grad))
+    if passthrough:
+        _inherit_scale(out[1], x)  # the alias of the input carries the input's f16x2 scale (found by this call at the latest)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -687,7 +825,7 @@ class _BnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, stats, gamma, beta, running_mean, running_var, residual, prelu_w, training, momentum, eps,
-                act, leaky, ws, drop_mask):
+                act, leaky, ws, drop_mask, z_scale=None):
         lib = _lib.load()
         y, ldy = as_nhwc(y)
         n, c, h, w = y.shape
@@ -720,7 +858,7 @@ class _BnAct(torch.autograd.Function):
         if drop_mask is not None:
             drop_mask = drop_mask.contiguous()
         check(lib.hn_bn_act_fwd(_ptr(y), ldy, _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(z), c, npix, c, act,
-                                _ptr(prelu_w), leaky, _ptr(drop_mask), h * w, s), "hn_bn_act_fwd")
+                                _ptr(prelu_w), leaky, _ptr(drop_mask), h * w, _ptr(z_scale), s), "hn_bn_act_fwd")
         ctx.drop_mask = drop_mask
         ctx.leaves = (_leaf(gamma), _leaf(beta), _leaf(prelu_w))
         ctx.cfg = (training, act, leaky, residual is not None)
@@ -769,10 +907,14 @@ class _BnAct(torch.autograd.Function):
         if dy is not None or dres is not None:
             if dy is None:
                 dy = new_nhwc(n, c, h, w, y.device)
+            # f16x2: the pass also publishes dy's scale (a pass of its own costs as much as this one's read of dz)
+            dy_scale = _new_scale_slot(y.device) if (CONV_MATH == "f16x2" and ctx.needs_input_grad[0]) else None
             check(lib.hn_bn_act_bwd_apply(_ptr(dz), lddz, _ptr(z), ldz, _ptr(y), ldy, _ptr(mean), _ptr(invstd),
                                           _ptr(gamma), _ptr(scale), _ptr(shift), _ptr(dpar), npix, int(training),
                                           _ptr(dy), c, _ptr(dres), c, npix, c, act, _ptr(prelu_w), leaky,
-                                          _ptr(ctx.drop_mask), h * w, s), "hn_bn_act_bwd_apply")
+                                          _ptr(ctx.drop_mask), h * w, _ptr(dy_scale), s), "hn_bn_act_bwd_apply")
+            if dy_scale is not None:
+                dy._hn_scale = (dy._version, dy_scale)  # rides with the tensor to the producing convolution's backward
         def out(slot, fallback, needed):  # first use: the slot view; later use: nothing (added in place); no slot: dpar
             if not needed:
                 return None
@@ -783,7 +925,7 @@ class _BnAct(torch.autograd.Function):
         dgamma = out(sg, dpar[c:2 * c], ctx.needs_input_grad[2])
         dbeta = out(sb, dpar[0:c], ctx.needs_input_grad[3])
         dprelu = out(sp, dpar[2 * c:2 * c + 1], prelu_w is not None and ctx.needs_input_grad[7])
-        return dy, None, dgamma, dbeta, None, None, dres, dprelu, None, None, None, None, None, None, None
+        return dy, None, dgamma, dbeta, None, None, dres, dprelu, None, None, None, None, None, None, None, None
 
 
 class BnWorkspace:
@@ -811,8 +953,13 @@ class BnWorkspace:
 def bn_act(y, stats, gamma, beta, running_mean, running_var, residual=None, prelu_weight=None, training=True,
            momentum=0.1, eps=1e-5, act=ACT_NONE, leaky=0.0, ws=None, drop_mask=None):
     """`drop_mask` [N, C]: Dropout2d keep/(1-p) factors applied to the output in the same pass (see `drop_mask()`)."""
-    return _BnAct.apply(y, stats, gamma, beta, running_mean, running_var, residual, prelu_weight, bool(training),
-                        float(momentum), float(eps), int(act), float(leaky), ws, drop_mask)
+    # f16x2: the pass also publishes the output's scale, remembered on the tensor for the convolution that consumes it
+    z_scale = _new_scale_slot(y.device) if (CONV_MATH == "f16x2" and y.is_cuda) else None
+    z = _BnAct.apply(y, stats, gamma, beta, running_mean, running_var, residual, prelu_weight, bool(training),
+                     float(momentum), float(eps), int(act), float(leaky), ws, drop_mask, z_scale)
+    if z_scale is not None:
+        z._hn_scale = (z._version, z_scale)
+    return z
 
 
 _in_consts = {}
@@ -878,7 +1025,7 @@ class _MaxPool3x3s2(torch.autograd.Function):
 
 
 def maxpool3x3s2(x):
-    return _MaxPool3x3s2.apply(x)
+    return _inherit_scale(_MaxPool3x3s2.apply(x), x)
 
 
 class _AdaptiveAvgPool(torch.autograd.Function):
@@ -906,7 +1053,7 @@ class _AdaptiveAvgPool(torch.autograd.Function):
 
 def adaptive_avg_pool(x, size):
     ho, wo = (size, size) if isinstance(size, int) else size
-    return _AdaptiveAvgPool.apply(x, int(ho), int(wo))
+    return _inherit_scale(_AdaptiveAvgPool.apply(x, int(ho), int(wo)), x)
 
 
 class _PyramidPool(torch.autograd.Function):
@@ -948,7 +1095,10 @@ class _PyramidPool(torch.autograd.Function):
 def pyramid_pool(x, sizes):
     """[adaptive_avg_pool(x, s) for s in sizes] with a single fused backward."""
     sizes = tuple((int(s), int(s)) if isinstance(s, int) else (int(s[0]), int(s[1])) for s in sizes)
-    return _PyramidPool.apply(x, *sizes)
+    outs = _PyramidPool.apply(x, *sizes)
+    for o in outs:
+        _inherit_scale(o, x)  # averages of x's elements
+    return outs
 
 
 class _Bilinear(torch.autograd.Function):
@@ -973,7 +1123,7 @@ class _Bilinear(torch.autograd.Function):
 
 
 def bilinear(x, size):
-    return _Bilinear.apply(x, int(size[0]), int(size[1]))
+    return _inherit_scale(_Bilinear.apply(x, int(size[0]), int(size[1])), x)
 
 
 class _PyramidMerge(torch.autograd.Function):

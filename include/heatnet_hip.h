@@ -90,6 +90,10 @@ int hn_conv2d_fwd(const float* x, const float* w, const void* w_x3, const float*
 #define HN_MATH_F32 0
 #define HN_MATH_BF16X3 1
 #define HN_MATH_BF16 2
+#define HN_SCALE_WORDS 64
+#define HN_SCALE_STRIDE 32 /* 32-bit words between the words of a slot: a slot is 64 x 128 B = 8 KB */
+#define HN_SCALE_SLOT_FLOATS (HN_SCALE_WORDS * HN_SCALE_STRIDE)
+#define HN_MATH_F16X2 3 /* per call only (the *_scaled entry points below); not a process-wide default */
 int hn_set_conv_math(int math);
 int hn_get_conv_math(void);
 
@@ -140,11 +144,49 @@ typedef struct HnWeightPrepItem {
     void* w_x3;
     float* wt;
     void* wt_x3;
-    int32_t Cout, KH, KW, Cin, stride, pad, dil, reserved;
+    int32_t Cout, KH, KW, Cin, stride, pad, dil;
+    int32_t format; /* of w_x3 / wt_x3: 0 = three bf16 planes (bf16x3, bf16), 1 = two fp16 planes + scale (f16x2, below) */
 } HnWeightPrepItem;
 size_t hn_weight_prep_table_bytes(int n);
 int hn_weight_prep_table_fill(const HnWeightPrepItem* items, int n, void* table_host, int* total_blocks);
-int hn_weight_prepare_batch(const void* table_dev, int n, int total_blocks, void* stream);
+/* has_f16x2: non-zero when any item has format 1 (adds the pass that finds those layers' max |w|). */
+int hn_weight_prepare_batch(const void* table_dev, int n, int total_blocks, int has_f16x2, void* stream);
+
+/* ---- f16x2: fp32 results from TWO fp16 terms per operand -----------------------------------------------------------
+ * HN_MATH_F16X2.  Every operand tensor t gets a power-of-two scale s_t = 2^(14 - floor(log2 max|t|)) (its largest magnitude
+ * lands in [2^14, 2^15), below fp16's range limit); t * s_t is split into hi = fp16(t * s_t) and lo = fp16(t * s_t - hi) --
+ * 22 significant bits for every element within 2^-18 of the tensor's maximum, fewer (gracefully) below that -- and the
+ * three products lo*hi, hi*lo, hi*hi are accumulated in fp32 on v_mfma_f32_16x16x32_f16; the result is multiplied by
+ * 1 / (s_a * s_b) on the way out (all scalings are exact).  Error against fp64: within 1.0-1.2x of the fp32 MFMA's for
+ * reductions of >= 512 terms (the products' 2^-23 representation error is below the fp32 accumulation error there) at
+ * half the matrix-core work of bf16x3; short reductions are better served by bf16x3 (tests/test_gpu_kernels.py,
+ * profiles/r02_f16x2_accuracy.txt).  Heavy-tailed tensors (max / typical magnitude > 2^18) lose bits on their small
+ * elements: the caller chooses per layer.
+ *
+ * Scale slots: HN_SCALE_SLOT_FLOATS floats (8 KB) per tensor, of which every HN_SCALE_STRIDE-th word is used: 64 words on 64
+ * different 128-B lines, each the bit pattern of the largest |t| seen by some of the producing blocks (as an unsigned
+ * integer it is monotonic in the magnitude; separate lines keep the producers' atomics from serialising).  hn_absmax_scale -- and the passes that take an optional slot (hn_bn_act_fwd,
+ * hn_bn_act_bwd_apply) -- ACCUMULATE into it: word = max(word, ...).  Zero the slot before the pass that produces t; the
+ * kernels that consume the tensor take the maximum over the words and derive s and 1/s themselves.  A slot may hold a
+ * BOUND instead (the slot of a tensor t' with max|t| <= max|t'|: a pooling or resampling of t').
+ * Weight planes: [hi plane][lo plane][area] with HN_X3_PLANE(n) fp16 elements per plane -- the buffer has the size of the
+ * bf16x3 planes, 3 * HN_X3_PLANE(n) * 2 bytes; the area holds the weight scale and scratch, nothing to initialise.
+ * n >= 256 elements.  hn_weight_flip_transpose_h2 / HnWeightPrepItem.format = 1 produce both operands (same scale).
+ * The *_scaled calls take the geometry, variant codes (tile fields only) and flags of their plain counterparts and
+ * return HN_ESHAPE where the f16x2 kernels do not cover the geometry (Cin % 32 != 0, unaligned, zero-dilated gathers;
+ * weight gradient: Cin % 64 != 0 or Cout % 64 != 0) -- the caller then uses another arithmetic for that launch. */
+int hn_absmax_scale(const float* x, int ld, int64_t npix, int C, float* scale, void* stream);
+int hn_split_f16x2(const float* src, void* dst, int64_t n, void* stream);
+int hn_weight_flip_transpose_h2(const float* w, void* w_h2, float* wt, void* wt_h2, int Cout, int KH, int KW, int Cin, int stride,
+                                int pad, int dil, void* stream);
+int hn_conv2d_fwd_scaled(const float* x, const float* x_scale, const float* w, const void* w_h2, const float* bias, float* y,
+                         double* stats, const HnConvDesc* d, int act, float slope, int variant, void* stream);
+int hn_conv2d_dgrad_scaled(const float* dy, const float* dy_scale, const float* wt, const void* wt_h2, float* dx,
+                           const float* addend, int ldadd, const HnConvDesc* d, int variant, void* stream);
+int hn_conv2d_wgrad_scaled(const float* x, const float* x_scale, const float* dy, const float* dy_scale, float* dw,
+                           const HnConvDesc* d, int split_k, int variant, int flags, void* stream);
+int hn_conv2d_wgrad_det_scaled(const float* x, const float* x_scale, const float* dy, const float* dy_scale, float* dw,
+                               const HnConvDesc* d, int split_k, int variant, int flags, float* workspace, void* stream);
 
 /* dx = conv_transpose(dy, w) [+ addend] for the forward geometry `d` (dy is N x Hout x Wout x Cout with pixel stride
  * d->ldy, dx is N x Hin x Win x Cin with pixel stride d->ldx); `wt` from hn_weight_flip_transpose.  `addend`
@@ -198,10 +240,12 @@ int hn_bn_eval_params(const float* gamma, const float* beta, const float* runnin
 /* z = act(y*scale[c] + shift[c] + residual) [* mask[n*C + c]].  residual may be NULL; `slope` is a device pointer for
  * HN_ACT_PRELU, ignored otherwise (HN_ACT_LEAKY uses leaky_slope).  `mask` (optional, with hw = pixels per image) is a
  * Dropout2d keep/(1-p) factor per (image, channel), cm/models/pspnet.py:55,66-72, applied in the same pass; the two
- * backward entry points take the same mask and fold it into dz. */
+ * backward entry points take the same mask and fold it into dz.  `z_scale` (optional): a scale slot as hn_absmax_scale
+ * takes; the pass then also publishes the f16x2 scale of z, so the convolution that consumes z needs no pass of its own. */
 int hn_bn_act_fwd(const float* y, int ldy, const float* scale, const float* shift,
                   const float* residual, int ldr, float* z, int ldz, int64_t npix, int C,
-                  int act, const float* slope, float leaky_slope, const float* mask, int64_t hw, void* stream);
+                  int act, const float* slope, float leaky_slope, const float* mask, int64_t hw, float* z_scale,
+                  void* stream);
 
 /* First backward pass.  du = dz * act'(u), u = y*scale+shift(+residual).  Accumulates into the double workspace
  * sums[HN_STAT_REPLICAS][2C+1] (must be all zero on entry; it is zero again on return) and writes
@@ -218,12 +262,14 @@ int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, con
 
 /* Second backward pass: dy = gamma*invstd*(du - dbeta/count - xhat*dgamma/count) when `training`,
  * dy = gamma*invstd*du otherwise; dres = du when dres != NULL (gradient of the residual input).
- * `dparams` is the fp32 output of hn_bn_act_bwd_reduce; `z` as there. */
+ * `dparams` is the fp32 output of hn_bn_act_bwd_reduce; `z` as there.  `dy_scale` (optional): publishes the f16x2 scale of
+ * dy (the gradient operand of the producing convolution's backward kernels), as z_scale above. */
 int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                         const float* mean, const float* invstd, const float* gamma, const float* scale,
                         const float* shift, const float* dparams, int64_t count, int training,
                         float* dy, int lddy, float* dres, int lddr, int64_t npix, int C,
-                        int act, const float* slope, float leaky_slope, const float* mask, int64_t hw, void* stream);
+                        int act, const float* slope, float leaky_slope, const float* mask, int64_t hw, float* dy_scale,
+                        void* stream);
 
 /* dx = dy * act'(y_out) for an activation applied in a conv epilogue (LeakyReLU / ReLU: the sign of the
  * output equals the sign of the pre-activation).  In place allowed (dx == dy). */

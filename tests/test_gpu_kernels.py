@@ -58,7 +58,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("conv_math", ["f32", "bf16x3"], indirect=True)
+@pytest.mark.parametrize("conv_math", ["f32", "bf16x3", "f16x2"], indirect=True)
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
 def test_conv2d_forward_backward(dev, case, conv_math):
     ops = _ops()
@@ -91,10 +91,11 @@ def test_conv2d_forward_backward(dev, case, conv_math):
 
 
 @pytest.mark.parametrize("case", [(2, 256, 24, 40, 256, 3, 1, 2, 2), (2, 1024, 20, 24, 256, 1, 1, 0, 1),
-                                  (2, 128, 32, 48, 128, 3, 2, 1, 1)], ids=str)
+                                  (2, 128, 32, 48, 128, 3, 2, 1, 1), (2, 64, 40, 48, 256, 1, 1, 0, 1)], ids=str)
 def test_conv2d_bf16x3_is_fp32_accurate(dev, case):
-    """The bf16x3 kernels (exact 3-way bf16 split, 6 MFMAs, fp32 accumulate) against an fp64 convolution: their error
-    must not exceed the fp32-MFMA kernels' (both are dominated by fp32 accumulation rounding)."""
+    """The bf16x3 kernels (exact 3-way bf16 split, 6 MFMAs, fp32 accumulate) and the f16x2 kernels (power-of-two tensor
+    scales, 2-way fp16 split, 3 MFMAs) against an fp64 convolution: their error must not exceed the fp32-MFMA kernels'
+    (all are dominated by fp32 accumulation rounding)."""
     ops = _ops()
     n, cin, h, w, cout, k, stride, pad, dil = case
     x = F.relu(rnd(n, cin, h, w, seed=31))                      # post-ReLU activations, as in the network
@@ -104,7 +105,7 @@ def test_conv2d_bf16x3_is_fp32_accurate(dev, case):
     gy = rnd(*yr.shape, seed=33)
     yr.backward(gy.double())
     errs = {}
-    for math in ("f32", "bf16x3"):
+    for math in ("f32", "bf16x3", "f16x2"):
         prev = ops.set_conv_math(math)
         try:
             xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
@@ -115,8 +116,9 @@ def test_conv2d_bf16x3_is_fp32_accurate(dev, case):
                                for a, b in ((y, yr), (xd.grad, xr.grad), (wd.grad, wr.grad)))
         finally:
             ops.set_conv_math(prev)
-    for what, e32, ex3 in zip(("y", "dx", "dw"), errs["f32"], errs["bf16x3"]):
-        assert ex3 <= 1.25 * e32 + 1e-9, "%s: rms error vs fp64 %.3e (bf16x3) > 1.25 x %.3e (fp32 MFMA)" % (what, ex3, e32)
+    for math in ("bf16x3", "f16x2"):
+        for what, e32, ex in zip(("y", "dx", "dw"), errs["f32"], errs[math]):
+            assert ex <= 1.25 * e32 + 1e-9, "%s: rms error vs fp64 %.3e (%s) > 1.25 x %.3e (fp32 MFMA)" % (what, ex, math, e32)
 
 
 def test_conv2d_fused_leaky_and_channel_slice_input(dev):
@@ -467,8 +469,8 @@ def test_c_abi_rejects_bad_arguments(dev):
     assert lib.hn_conv2d_fwd(P(x), P(w), None, None, P(y), None, ctypes.byref(bad_shape), 0, 0.0, 0, s) == -4  # HN_ESHAPE
     bad_ld = _lib.HnConvDesc(1, 8, 8, 64, 32, 8, 8, 64, 64, 1, 1, 1, 0, 1)                              # ldx < Cin
     assert lib.hn_conv2d_fwd(P(x), P(w), None, None, P(y), None, ctypes.byref(bad_ld), 0, 0.0, 0, s) == -1
-    assert lib.hn_bn_act_fwd(P(x), 64, None, None, None, 0, P(y), 64, 64, 64, 1, None, 0.0, None, 0, s) == -1
-    assert lib.hn_bn_act_fwd(P(x), 64, P(w), P(w), None, 0, P(y), 64, 64, 64, 1, None, 0.0, P(w), 48, s) == -1  # hw !| npix
+    assert lib.hn_bn_act_fwd(P(x), 64, None, None, None, 0, P(y), 64, 64, 64, 1, None, 0.0, None, 0, None, s) == -1
+    assert lib.hn_bn_act_fwd(P(x), 64, P(w), P(w), None, 0, P(y), 64, 64, 64, 1, None, 0.0, P(w), 48, None, s) == -1  # hw !| npix
     assert lib.hn_pyramid_pool_bwd(9, None, None, None, None, P(y), 64, 1, 8, 8, 64, s) == -1            # > 8 levels
     assert lib.hn_ce_fwd(P(x), 64, P(y), 64, 64, -100, P(y), s) == -1                                   # C > 32 classes
     with pytest.raises(RuntimeError, match="invalid argument"):
@@ -565,7 +567,7 @@ def test_bf16x3_schedules_agree_through_autograd(dev, case):
     try:
         ops.AUTOTUNE = False  # candidates[0] is used
         for bk in (1, 2):
-            ops._igemm_candidates = lambda cout_, kind, bk=bk: [ops._variant(bk, 0, 0, 2)]
+            ops._igemm_candidates = lambda cout_, kind, cred=0, math_name=None, bk=bk: [ops._variant(bk, 0, 0, 2)]
             xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
             wd = wt.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
             y = ops.conv2d(xd, wd, None, stride, pad, dil)
@@ -765,3 +767,187 @@ def test_bf16x3_lds_dma_schedule_agrees_bitwise(dev, case):
         assert torch.equal(y1, y3)
     t1, t3 = s1.view(ops.STAT_REPLICAS, 2, cout).sum(0).cpu(), s3.view(ops.STAT_REPLICAS, 2, cout).sum(0).cpu()
     assert float((t1 - t3).abs().max()) <= 1e-6 * float(t1.abs().max())
+
+
+# ---- f16x2: operand preparation, scales, the *_scaled entry points through the C ABI --------------------------------------
+
+def _slot_max(slot):
+    """largest magnitude recorded in a scale slot (the maximum over its words, as a float)"""
+    return float(slot.view(torch.int32).max().view(torch.float32))
+
+
+def _expected_scale(amax):
+    import math
+    return 1.0 if (amax == 0.0 or not math.isfinite(amax)) else 2.0 ** (14 - math.floor(math.log2(amax)))
+
+
+def test_f16x2_absmax_scale_slots(dev):
+    """hn_absmax_scale: the slot receives the exact bit pattern of max|x| (dense and channel-slice inputs, negative extreme),
+    ACCUMULATES over calls, and the BatchNorm passes publish the same value for their outputs."""
+    import ctypes
+    from heatnet_amd import _lib, ops
+    lib = _lib.load()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = rnd(2, 37, 41, 64, seed=70).to(dev)  # N H W C
+    x[1, 5, 7, 9] = -123.456
+    slot = torch.zeros(ops.SCALE_SLOT_FLOATS, device=dev)
+    _lib.check(lib.hn_absmax_scale(P(x), 64, 2 * 37 * 41, 64, P(slot), s), "absmax")
+    assert _slot_max(slot) == float(x.abs().max()) == float(np.float32(123.456))
+    sl = x[..., 8:40]  # channel slice: ld 64, C 32 (contains the extreme)
+    slot2 = torch.zeros(ops.SCALE_SLOT_FLOATS, device=dev)
+    _lib.check(lib.hn_absmax_scale(P(sl), 64, 2 * 37 * 41, 32, P(slot2), s), "absmax")
+    assert _slot_max(slot2) == float(sl.abs().max())
+    small = (x * 1e-3).contiguous()
+    _lib.check(lib.hn_absmax_scale(P(small), 64, 2 * 37 * 41, 64, P(slot2), s), "absmax")  # accumulates: the larger stays
+    assert _slot_max(slot2) == float(sl.abs().max())
+    # producers: z = relu(bn(y)) and the BatchNorm backward's dy carry their scale with them
+    prev = ops.set_conv_math("f16x2")
+    try:
+        y = rnd(2, 64, 20, 24, seed=71).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+        g, b = (1.0 + 0.1 * rnd(64, seed=72)).to(dev).requires_grad_(), rnd(64, seed=73).to(dev).requires_grad_()
+        z = ops.bn_act(y, None, g, b, torch.zeros(64, device=dev), torch.ones(64, device=dev), training=True, act=ops.ACT_RELU)
+        assert _slot_max(z._hn_scale[1]) == float(z.detach().abs().max())
+        before = ops.absmax_launches
+        assert ops.tensor_scale(z) is z._hn_scale[1] and ops.absmax_launches == before  # remembered, no pass
+        p = ops.maxpool3x3s2(z)
+        assert p._hn_scale[1] is z._hn_scale[1]  # a bound: max pooling cannot exceed its input
+        zd = z.detach().clone()
+        zd._hn_scale = (zd._version, z._hn_scale[1])
+        zd.add_(1.0)                             # in-place change: the remembered scale no longer applies
+        assert ops.tensor_scale(zd) is not z._hn_scale[1] and ops.absmax_launches == before + 1
+        assert _slot_max(zd._hn_scale[1]) == float(zd.abs().max())
+    finally:
+        ops.set_conv_math(prev)
+
+
+@pytest.mark.parametrize("scale", [1.0, 3e-7, 4e5])
+def test_f16x2_weight_planes(dev, scale):
+    """hn_split_f16x2 / hn_weight_flip_transpose_h2 / the batched preparation: hi + lo reproduces w * s to 2^-22 of the
+    tensor's maximum, s is the power of two that puts max|w| into [2^14, 2^15), all three routes give identical planes."""
+    import ctypes
+    from heatnet_amd import _lib, ops
+    lib = _lib.load()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    cout, kh, kw, cin = 96, 3, 3, 64
+    w = (rnd(cout, kh, kw, cin, seed=74) * scale).to(dev)
+    nw, plane = w.numel(), ops.x3_plane(w.numel())
+    h2 = torch.empty(3 * plane, device=dev, dtype=torch.int16)
+    _lib.check(lib.hn_split_f16x2(P(w), P(h2), nw, s), "split")
+    area = h2[2 * plane:].view(torch.float32)
+    sc, inv = float(area[0]), float(area[1])
+    assert sc == _expected_scale(float(w.abs().max())) and sc * inv == 1.0
+    hi, lo = h2[:nw].view(torch.float16).double(), h2[plane:plane + nw].view(torch.float16).double()
+    ws = w.double().flatten() * sc
+    assert 2.0 ** 14 <= float(ws.abs().max()) < 2.0 ** 15
+    assert float((hi + lo - ws).abs().max()) <= 2.0 ** -22 * float(ws.abs().max())
+    # the flip / transpose route: same forward planes, and the transposed planes hold the same values re-ordered
+    w2, wt, wt2 = torch.empty_like(h2), torch.empty(nw, device=dev), torch.empty_like(h2)
+    _lib.check(lib.hn_weight_flip_transpose_h2(P(w), P(w2), P(wt), P(wt2), cout, kh, kw, cin, 1, 1, 1, s), "flip")
+    assert torch.equal(w2[:2 * plane], h2[:2 * plane]) and torch.equal(w2[2 * plane:2 * plane + 4], h2[2 * plane:2 * plane + 4])
+    ref_t = w.flip(1, 2).permute(3, 1, 2, 0).contiguous().flatten()  # [Cin][KH][KW][Cout], taps flipped
+    assert torch.equal(wt, ref_t)
+    t_hi, t_lo = wt2[:nw].view(torch.float16).double(), wt2[plane:plane + nw].view(torch.float16).double()
+    assert float((t_hi + t_lo - ref_t.double() * sc).abs().max()) <= 2.0 ** -22 * float(ws.abs().max())
+    assert float(wt2[2 * plane:].view(torch.float32)[0]) == sc
+    # batched: one table with an f16x2 and a bf16x3 layer
+    w3 = torch.empty_like(h2)
+    wt3, wt4 = torch.empty(nw, device=dev), torch.empty_like(h2)
+    wb = rnd(64, 1, 1, 32, seed=75).to(dev)
+    xb, xb_ref = torch.empty(3 * ops.x3_plane(wb.numel()), device=dev, dtype=torch.int16), None
+    items = (_lib.HnWeightPrepItem * 2)()
+    items[0].w, items[0].w_x3, items[0].wt, items[0].wt_x3 = w.data_ptr(), w3.data_ptr(), wt3.data_ptr(), wt4.data_ptr()
+    items[0].Cout, items[0].KH, items[0].KW, items[0].Cin, items[0].stride, items[0].pad, items[0].dil, items[0].format = cout, kh, kw, cin, 1, 1, 1, 1
+    items[1].w, items[1].w_x3, items[1].wt, items[1].wt_x3 = wb.data_ptr(), xb.data_ptr(), None, None
+    items[1].Cout, items[1].KH, items[1].KW, items[1].Cin, items[1].stride, items[1].pad, items[1].dil, items[1].format = 64, 1, 1, 32, 1, 0, 1, 0
+    host = torch.empty(lib.hn_weight_prep_table_bytes(2), dtype=torch.uint8)
+    blocks = ctypes.c_int(0)
+    _lib.check(lib.hn_weight_prep_table_fill(items, 2, ctypes.c_void_p(host.data_ptr()), ctypes.byref(blocks)), "fill")
+    table = host.to(dev)
+    _lib.check(lib.hn_weight_prepare_batch(P(table), 2, blocks.value, 1, s), "batch")
+    assert torch.equal(w3[:2 * plane], h2[:2 * plane]) and torch.equal(wt4[:2 * plane], wt2[:2 * plane]) and torch.equal(wt3, wt)
+    assert float(w3[2 * plane:].view(torch.float32)[0]) == sc and float(wt4[2 * plane:].view(torch.float32)[0]) == sc
+    xb_ref = torch.empty_like(xb)
+    _lib.check(lib.hn_split_bf16x3(P(wb), P(xb_ref), wb.numel(), s), "split3")
+    assert torch.equal(xb, xb_ref)
+
+
+@pytest.mark.parametrize("mag", [(1.0, 1.0), (1e-12, 1e9), (3e7, 1e-20)], ids=str)
+def test_f16x2_scaled_entry_points(dev, mag):
+    """hn_conv2d_{fwd,dgrad,wgrad}_scaled through the C ABI on operands of very different magnitudes (the power-of-two
+    scales keep fp16 in range): against an fp64 convolution, as accurate as bf16x3 (relative to the result's own rms);
+    bias / ReLU / statistics epilogue, skip-gradient addend, deterministic weight gradient.  Refusals: no scale, planes of
+    the wrong call, uncovered geometry."""
+    import ctypes
+    from heatnet_amd import _lib, ops
+    lib = _lib.load()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    xm, wm = mag
+    n, cin, h, w_, cout, k, pad = 2, 128, 32, 40, 192, 3, 1  # (> 2048 pixels: no split-K, bitwise repeatable)
+    x = (F.relu(rnd(n, cin, h, w_, seed=76)) * xm)
+    wt = rnd(cout, cin, k, k, seed=77, scale=wm / np.sqrt(cin * k * k))
+    b = rnd(cout, seed=78) * (xm * wm)
+    gy = rnd(n, cout, h, w_, seed=79) * 1e-4
+    skip = rnd(n, cin, h, w_, seed=80) * (1e-4 * wm)
+    xr, wr = x.double().requires_grad_(), wt.double().requires_grad_()
+    yr = F.conv2d(xr, wr, b.double(), padding=pad)
+    yr.backward(gy.double())
+    xd, wd = x.to(dev).permute(0, 2, 3, 1).contiguous(), wt.to(dev).permute(0, 2, 3, 1).contiguous()
+    gyd, skd, bd = gy.to(dev).permute(0, 2, 3, 1).contiguous(), skip.to(dev).permute(0, 2, 3, 1).contiguous(), b.to(dev)
+    nw, plane = wd.numel(), ops.x3_plane(wd.numel())
+    wh, wth, wtf = (torch.empty(3 * plane, device=dev, dtype=torch.int16), torch.empty(3 * plane, device=dev, dtype=torch.int16),
+                    torch.empty(nw, device=dev))
+    _lib.check(lib.hn_weight_flip_transpose_h2(P(wd), P(wh), P(wtf), P(wth), cout, k, k, cin, 1, pad, 1, s), "flip")
+    xs, gs = torch.zeros(ops.SCALE_SLOT_FLOATS, device=dev), torch.zeros(ops.SCALE_SLOT_FLOATS, device=dev)
+    _lib.check(lib.hn_absmax_scale(P(xd), cin, n * h * w_, cin, P(xs), s), "absmax")
+    _lib.check(lib.hn_absmax_scale(P(gyd), cout, n * h * w_, cout, P(gs), s), "absmax")
+    d = _lib.HnConvDesc(n, h, w_, cin, cin, h, w_, cout, cout, k, k, 1, pad, 1)
+    y = torch.empty(n, h, w_, cout, device=dev)
+    stats = torch.zeros(ops.STAT_REPLICAS * 2 * cout, device=dev, dtype=torch.float64)
+    _lib.check(lib.hn_conv2d_fwd_scaled(P(xd), P(xs), P(wd), P(wh), P(bd), P(y), P(stats), ctypes.byref(d), 0, 0.0, 0, s), "fwd")
+    dx = torch.empty_like(xd)
+    _lib.check(lib.hn_conv2d_dgrad_scaled(P(gyd), P(gs), P(wtf), P(wth), P(dx), P(skd), cin, ctypes.byref(d), 0, s), "dgrad")
+    dw, dw_det = torch.empty_like(wd), torch.empty_like(wd)
+    _lib.check(lib.hn_conv2d_wgrad_scaled(P(xd), P(xs), P(gyd), P(gs), P(dw), ctypes.byref(d), 0, 0, 0, s), "wgrad")
+    wsp = torch.empty(4 * nw, device=dev)
+    _lib.check(lib.hn_conv2d_wgrad_det_scaled(P(xd), P(xs), P(gyd), P(gs), P(dw_det), ctypes.byref(d), 4, 0, 0, P(wsp), s), "wgrad_det")
+
+    def rel(a, ref):
+        ref = ref.detach()
+        return float((a.double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert rel(y.permute(0, 3, 1, 2), yr) < 4e-7
+    assert rel(dx.permute(0, 3, 1, 2), xr.grad + skip.double()) < 6e-7
+    assert rel(dw.permute(0, 3, 1, 2), wr.grad) < 4e-7 and rel(dw_det.permute(0, 3, 1, 2), wr.grad) < 4e-7
+    st = stats.view(ops.STAT_REPLICAS, 2, cout).sum(0).cpu()
+    ref_sum = yr.detach().sum((0, 2, 3))
+    assert float((st[0] - ref_sum).abs().max()) <= 1e-5 * float(yr.detach().abs().sum((0, 2, 3)).max())
+    # epilogue activation
+    y2 = torch.empty_like(y)
+    _lib.check(lib.hn_conv2d_fwd_scaled(P(xd), P(xs), P(wd), P(wh), P(bd), P(y2), None, ctypes.byref(d), 1, 0.0, 0, s), "fwd relu")
+    assert torch.equal(y2, torch.relu(y))
+    # refusals
+    assert lib.hn_conv2d_fwd_scaled(P(xd), None, P(wd), P(wh), None, P(y), None, ctypes.byref(d), 0, 0.0, 0, s) == -1  # HN_EINVAL
+    assert lib.hn_conv2d_fwd(P(xd), P(wd), P(wh), None, P(y), None, ctypes.byref(d), 0, 0.0, ops._variant(0, 0, 0, 4), s) == -1
+    d3 = _lib.HnConvDesc(n, h, w_, 3, cin, h, w_, cout, cout, k, k, 1, pad, 1)  # Cin = 3: not an f16x2 geometry
+    assert lib.hn_conv2d_fwd_scaled(P(xd), P(xs), P(wd), P(wh), None, P(y), None, ctypes.byref(d3), 0, 0.0, 0, s) == -4  # HN_ESHAPE
+    d13 = _lib.HnConvDesc(n, h, w_, cin, cin, h, w_, 13, cout, k, k, 1, pad, 1)  # Cout = 13: no f16x2 weight gradient
+    assert lib.hn_conv2d_wgrad_scaled(P(xd), P(xs), P(gyd), P(gs), P(dw), ctypes.byref(d13), 0, 0, 0, s) == -4
+
+
+def test_f16x2_all_zero_and_nonfinite_operands(dev):
+    """An all-zero tensor has scale 1 and an exactly zero result; an infinite element makes the outputs it reaches
+    non-finite, as under fp32 (the tensor's scale then falls back to 1: no statement about the other outputs)."""
+    ops = _ops()
+    prev = ops.set_conv_math("f16x2")
+    try:
+        w = rnd(64, 64, 3, 3, seed=81).to(dev).contiguous(memory_format=torch.channels_last)
+        x0 = torch.zeros(1, 64, 16, 24, device=dev).contiguous(memory_format=torch.channels_last)
+        assert float(ops.conv2d(x0, w, None, 1, 1, 1).abs().max()) == 0.0
+        x1 = rnd(1, 64, 16, 24, seed=82).to(dev).contiguous(memory_format=torch.channels_last)
+        x1[0, 3, 4, 5] = float("inf")
+        y = ops.conv2d(x1, w, None, 1, 1, 1)
+        assert not torch.isfinite(y[0, :, 4, 5]).all()
+    finally:
+        ops.set_conv_math(prev)

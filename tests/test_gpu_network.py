@@ -29,7 +29,7 @@ def _build(late, state_seed, dev):
     return net.to(dev)
 
 
-@pytest.mark.parametrize("conv_math", ["f32", "bf16x3"], indirect=True)
+@pytest.mark.parametrize("conv_math", ["f32", "bf16x3", "f16x2"], indirect=True)
 @pytest.mark.parametrize("tag,late", [("late", True), ("early", False)])
 def test_segnet_forward_matches_reference_fixture(dev, golden_dir, tag, late, conv_math):
     """Train-mode and eval-mode logits + the five feature maps vs. fixtures produced by the reference (tol 1e-3)."""
@@ -114,7 +114,7 @@ def test_segnet_backward_matches_oracle(dev):
     assert float(np.exp(np.mean(np.log(ratios)))) < 2.0, ratios
 
 
-@pytest.mark.parametrize("conv_math", ["f32", "bf16x3"], indirect=True)
+@pytest.mark.parametrize("conv_math", ["f32", "bf16x3", "f16x2"], indirect=True)
 def test_segnet_batch1_odd_geometry_with_ignored_labels(dev, conv_math):
     """Edge geometry: a single image (BatchNorm statistics over one sample) of 72x104 pixels (9x13 feature maps: bins of
     the 2/3/6 pyramid levels overlap, tiles are ragged everywhere) and labels containing the ignore index 13 of
@@ -142,7 +142,7 @@ def test_segnet_batch1_odd_geometry_with_ignored_labels(dev, conv_math):
         assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max())), k
 
 
-@pytest.mark.parametrize("conv_math", ["f32", "bf16x3"], indirect=True)
+@pytest.mark.parametrize("conv_math", ["f32", "bf16x3", "f16x2"], indirect=True)
 def test_fullres_minibatch_logits_and_miou(dev, golden_dir, conv_math):
     """BASELINE criterion: logits within 1e-3 and |d mIoU| < 1e-3 on the fixed 2x320x704 mini-batch."""
     from heatnet_amd import miou, train_step
@@ -185,7 +185,7 @@ def test_rgb18_config1(dev, golden_dir):
     np.testing.assert_allclose(net.final[0].weight.grad.cpu().numpy(), g["grad_final_w"], rtol=2e-3, atol=2e-5)
 
 
-@pytest.mark.parametrize("conv_math,optimizer", [("f32", "torch"), ("bf16x3", "torch"), ("bf16x3", "arena")],
+@pytest.mark.parametrize("conv_math,optimizer", [("f32", "torch"), ("bf16x3", "torch"), ("bf16x3", "arena"), ("f16x2", "arena")],
                          indirect=["conv_math"])
 @pytest.mark.parametrize("adv", ["MSE", "BCE"])
 def test_confusion_maximisation_steps(dev, golden_dir, adv, conv_math, optimizer):
@@ -384,7 +384,7 @@ def test_validation_convention_matches_oracle(dev):
     assert int(net.state_dict()["feats.bn1.num_batches_tracked"]) == 3
 
 
-@pytest.mark.parametrize("conv_math", ["f32", "bf16x3"], indirect=True)
+@pytest.mark.parametrize("conv_math", ["f32", "bf16x3", "f16x2"], indirect=True)
 @pytest.mark.parametrize("adv", ["MSE", "BCE"])
 @pytest.mark.parametrize("state_name", ["train_seg", "train_critic"])
 def test_gradient_tensors_match_reference_elementwise(dev, golden_dir, adv, state_name, conv_math):
@@ -530,7 +530,7 @@ def test_bf16_path_tolerance_on_the_fullres_minibatch(dev, golden_dir):
     assert abs(mine - ref) < BF16_MIOU_TOL, (mine, ref)
 
 
-@pytest.mark.parametrize("conv_math", ["bf16x3", "bf16"], indirect=True)
+@pytest.mark.parametrize("conv_math", ["bf16x3", "f16x2", "bf16"], indirect=True)
 def test_640x1408_forward_matches_oracle(dev, conv_math):
     """configs[4] geometry, bs 1: train-mode logits of the dual-stream PSPNet at 640x1408 against the CPU oracle run on
     this host -- 1e-3 for the fp32-equivalent arithmetic; CE / mIoU / rms-logit tolerance stated above for bf16."""
@@ -556,7 +556,7 @@ def test_640x1408_forward_matches_oracle(dev, conv_math):
     theirs = np.nanmean(R.calculate_ious(ref_logits.argmax(1).numpy(), lab.numpy()))
     print("640x1408 %s: logits max|err| %.3e rms %.3e, CE %.5f vs %.5f, mIoU %.5f vs %.5f" % (conv_math, err, rms, ce, ref_ce,
                                                                                             mine, theirs))
-    if conv_math == "bf16x3":
+    if conv_math in ("bf16x3", "f16x2"):
         assert err < 1e-3, err
         assert abs(ce - ref_ce) < 1e-4 and abs(mine - theirs) < 1e-3
     else:

@@ -68,6 +68,22 @@ def main():
         _lib.check(lib.hn_split_bf16x3(P(wt), P(wx3), nw, s), "split")
         flops = 2.0 * n * ho * wo * cout * k * k * cin
         res = {}
+        if os.environ.get("H2") == "1":  # f16x2 arithmetic: forward only (the data gradient is the same kernel)
+            xs = torch.zeros(ops.SCALE_SLOT_FLOATS, device=dev)
+            wh2 = torch.zeros(3 * ops.x3_plane(nw), device=dev, dtype=torch.int16)
+            _lib.check(lib.hn_split_f16x2(P(wt), P(wh2), nw, s), "split_f16x2")
+
+            def run_h2():
+                _lib.check(lib.hn_absmax_scale(P(x), cin, n * h * w, cin, P(xs), s), "absmax")
+                _lib.check(lib.hn_conv2d_fwd_scaled(P(x), P(xs), P(wt), P(wh2), None, P(y), None, ctypes.byref(d), 0, 0.0, VAR, s), "fwd_scaled")
+            t_all = timeit(run_h2)
+            t_conv = timeit(lambda: _lib.check(lib.hn_conv2d_fwd_scaled(P(x), P(xs), P(wt), P(wh2), None, P(y), None, ctypes.byref(d), 0, 0.0, VAR, s), "fwd_scaled"))
+            y2 = y.clone()
+            _lib.check(lib.hn_conv2d_fwd(P(x), P(wt), P(wx3), None, P(y), None, ctypes.byref(d), 0, 0.0, 129, s), "fwd")
+            err = float((y2 - y).abs().max()) / max(float(y.abs().max()), 1e-30)
+            print("%-34s %8.1f  f16x2 conv %7.1f TF/s   with absmax %7.1f TF/s   max|diff to bf16x3|/max %.2e  scale %s" % (
+                sh, flops / 1e9, flops / t_conv / 1e9, flops / t_all / 1e9, err, int(xs.view(torch.int32).max())))
+            continue
         if "fwd" in kinds:
             res["fwd"] = timeit(lambda: _lib.check(lib.hn_conv2d_fwd(P(x), P(wt), P(wx3), None, P(y), None, ctypes.byref(d), 0, 0.0, VAR, s), "fwd"))
         if "dgrad" in kinds:
