@@ -18,12 +18,12 @@ algorithmic conv FLOPs (2*M*N*K of every conv forward / data-gradient / weight-g
 of exactly those launches, measured in an instrumented pass after the timed region.
 `cpu_baseline` times the CPU oracle (oracle/heatnet_ref.py, a port) on this host, on a bounded sample.
 
-Conv arithmetic (HEATNET_CONV_MATH): the default "bf16x3" computes the fp32 convolution on the
-bf16 matrix cores -- every fp32 operand split EXACTLY into three bf16 terms inside the kernel, the six products of weight
->= 2^-24 accumulated in fp32 -- with the accuracy of the fp32 MFMA (tests/test_gpu_kernels.py::
-test_conv2d_bf16x3_is_fp32_accurate, profiles/r01_bf16x3_probe.txt); its roofline peak is the dense bf16 MFMA peak / 6.
-"f32" runs the same step on v_mfma_f32_32x32x2_f32.  At N=1 the other arithmetic is timed too, in the same process, and
-reported as `alt_conv_math` (same workload, same step, K steps), so both numbers come from one run.
+Conv arithmetic (HEATNET_CONV_MATH): the default "f16x2" computes the fp32 convolution on the
+fp16 matrix cores -- every operand tensor scaled by a power of two and split into two fp16 terms inside the kernel, three
+products accumulated in fp32 -- with an error against fp64 at or below the fp32 MFMA's (tests/test_gpu_kernels.py::
+test_conv2d_bf16x3_is_fp32_accurate, profiles/r02_f16x2_accuracy.txt); its roofline peak is the dense fp16 MFMA peak / 3.
+"bf16x3" (three bf16 terms, six products, peak / 6) and "f32" (v_mfma_f32_32x32x2_f32) run the same step; at N=1 both are
+timed too, in the same process (`alt_conv_math` = the fp32 MFMA, `alt_conv_maths` = both), so all numbers come from one run.
 """
 import argparse
 import json
@@ -380,30 +380,34 @@ def main():
     if distributed:
         dist.barrier()
     alt = None
+    alts = {}
     if world == 1 and not args.no_alt and args.workload != "seg_bf16":
-        # the same step under the other conv arithmetic, timed the same way (N=1 only: like cpu_baseline, it is a
-        # reference figure printed beside the headline, not part of it)
+        # the same step under the other fp32-result conv arithmetics, timed the same way (N=1 only: like cpu_baseline,
+        # reference figures printed beside the headline, not part of it): the fp32 MFMA first (`alt_conv_math`), then
+        # whichever of bf16x3 / f16x2 is not the headline's
         main_math = ops.CONV_MATH
-        other = "f32" if main_math in ("bf16x3", "f16x2") else "bf16x3"
-        ops.set_conv_math(other)
-        try:
-            for _ in range(max(2, args.warmup)):
-                step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            alt_elapsed = time.perf_counter() - t1
-            alt_roof = None
-            if not args.no_roofline:
-                r = measure_conv_roofline(step, max(1, min(3, args.steps)), args.workload, scale=scale,
-                                          geom=(args.batch, args.height, args.width))
-                alt_roof = dict({k: r[k] for k in ("bound", "conv_ms_per_step", "kernel")}, **r["mfma_view"])
-            alt = {"conv_math": other, "value": round(args.batch * args.steps / alt_elapsed, 3), "unit": "images/s",
-                   "ms_per_step": round(1e3 * alt_elapsed / args.steps, 3), "steps": args.steps, "roofline": alt_roof}
-        finally:
-            ops.set_conv_math(main_math)
+        for other in [m for m in ("f32", "bf16x3", "f16x2") if m != main_math]:
+            ops.set_conv_math(other)
+            try:
+                for _ in range(max(2, args.warmup)):
+                    step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                alt_elapsed = time.perf_counter() - t1
+                alt_roof = None
+                if not args.no_roofline:
+                    r = measure_conv_roofline(step, max(1, min(3, args.steps)), args.workload, scale=scale,
+                                              geom=(args.batch, args.height, args.width))
+                    alt_roof = dict({k: r[k] for k in ("bound", "conv_ms_per_step", "kernel")}, **r["mfma_view"])
+                alts[other] = {"conv_math": other, "value": round(args.batch * args.steps / alt_elapsed, 3), "unit": "images/s",
+                               "ms_per_step": round(1e3 * alt_elapsed / args.steps, 3), "steps": args.steps,
+                               "roofline": alt_roof}
+            finally:
+                ops.set_conv_math(main_math)
+        alt = alts.pop("f32", None) or next(iter(alts.values()))
     others = None
     if world == 1 and args.workload == "seg" and not args.no_other_workloads:
         # the other BASELINE configurations, timed in the same process so that one default run records them all (N=1
@@ -462,7 +466,8 @@ def main():
                           "width": args.width,
                           "parallelism": "dp%d" % world, "optimizer": "RMSprop lr=1e-4 (fused, flat arena)", "weights": "random init",
                           "conv_math": CONV_MATH_NOTE[ops.CONV_MATH]},
-               "roofline": roof, "cpu_baseline": base, "alt_conv_math": alt, "other_workloads": others}
+               "roofline": roof, "cpu_baseline": base, "alt_conv_math": alt,
+               "alt_conv_maths": list(alts.values()) or None, "other_workloads": others}
         if force_dist:
             out["rehearsal"] = {"backend": backend, "world_size": 1, "collectives_issued": buckets.launched,
                                 "note": "HN_BENCH_FORCE_DIST=1: the N>1 path (process group, bucketed all-reduce on the "

@@ -174,7 +174,7 @@ if AUTOTUNE:
 _MATH_CODES = {"f32": 1, "bf16x3": 2, "bf16": 3, "f16x2": 4}
 _PLANE_MATHS = ("bf16x3", "bf16", "f16x2")  # arithmetics that take the weight operand as pre-made 16-bit planes
 H2_MIN_K = int(os.environ.get("HEATNET_F16X2_MIN_K", "0"))
-CONV_MATH = os.environ.get("HEATNET_CONV_MATH", "bf16x3")
+CONV_MATH = os.environ.get("HEATNET_CONV_MATH", "f16x2")
 if CONV_MATH not in _MATH_CODES:
     raise RuntimeError("HEATNET_CONV_MATH must be one of %s" % sorted(_MATH_CODES))
 # diagnostics only: comma-separated launch kinds (fwd, dgrad, wgrad) kept on the fp32 MFMA while CONV_MATH is bf16x3

@@ -45,16 +45,22 @@ def main():
     set_dropout(net, 0.0)
     net = net.to(dev).train()
     rnames = [x for x in names if x != "feats.maxpool"]
+    from heatnet_amd import ops
+    maths = os.environ.get("DIAG_MATHS", ops.CONV_MATH).split(",")
     with torch.no_grad():
         o64 = stages(ref64, rgb.double(), ir.double(), rnames)
         o32 = stages(ref32, rgb, ir, rnames)
-        ohip = stages(net, rgb.to(dev), ir.to(dev), rnames)
-    print("%-16s %10s %12s %12s %12s" % ("stage", "rms", "cpu32-f64", "hip-f64", "hip-cpu32"))
+        ohip = {}
+        for m in maths:
+            ops.set_conv_math(m)
+            ohip[m] = stages(net, rgb.to(dev), ir.to(dev), rnames)
+    print("max |error| per stage against the fp64 oracle (DIAG_MATHS=%s)" % ",".join(maths))
+    print("%-16s %10s %12s " % ("stage", "rms", "cpu32-f64") + " ".join("%12s" % ("hip " + m) for m in maths))
     for k in rnames + ["logits"]:
         t = o64[k]
-        a, b = o32[k].double(), ohip[k].cpu().double()
-        print("%-16s %10.3e %12.3e %12.3e %12.3e" % (k, float(t.pow(2).mean().sqrt()), float((a - t).abs().max()),
-                                                      float((b - t).abs().max()), float((b - a).abs().max())))
+        a = o32[k].double()
+        print("%-16s %10.3e %12.3e " % (k, float(t.pow(2).mean().sqrt()), float((a - t).abs().max())) +
+              " ".join("%12.3e" % float((ohip[m][k].cpu().double() - t).abs().max()) for m in maths))
 
 
 if __name__ == "__main__":

@@ -35,7 +35,7 @@ def main():
         loss.backward()
         opt.step()
         curves["cpu fp32 oracle"].append(float(loss.detach()))
-    for math in ("f32", "bf16x3", "bf16"):
+    for math in ("f32", "bf16x3", "f16x2", "bf16"):
         ops.set_conv_math(math)
         net = PSPNet(backend="resnet50", pretrained=False, late_fusion=True, in_channels=4)
         net.load_state_dict(state)
@@ -45,11 +45,10 @@ def main():
         d = [t.to(dev) for t in (rgb, ir, lab)]
         curves["hip " + math] = [float(train_step.segmentation_step(net, opt, d[0], d[1], d[2])) for _ in range(steps)]
     names = list(curves)
-    print("step  " + "  ".join("%-16s" % n for n in names) + "  |hip f32 - cpu|  |hip bf16x3 - cpu|  |hip bf16 - cpu|")
+    print("step  " + "  ".join("%-16s" % n for n in names) + "  |hip - cpu|: f32, bf16x3, f16x2, bf16")
     for i in range(steps):
         v = [curves[n][i] for n in names]
-        print("%4d  " % i + "  ".join("%-16.6f" % x for x in v) + "  %.2e        %.2e           %.2e"
-              % (abs(v[1] - v[0]), abs(v[2] - v[0]), abs(v[3] - v[0])))
+        print("%4d  " % i + "  ".join("%-16.6f" % x for x in v) + "  " + "  ".join("%.2e" % abs(x - v[0]) for x in v[1:]))
 
 
 if __name__ == "__main__":
