@@ -290,7 +290,7 @@ __device__ __forceinline__ void conv_fill_rowinfo(const ConvArgs& p, int* rowinf
 }
 
 // conv_igemm2.hip
-enum : int { MATH2_X3 = 3, MATH2_BF16 = 1 };  // = number of bf16 planes per operand
+enum : int { MATH2_X3 = 3, MATH2_BF16 = 1, MATH2_H2 = 2 };  // = number of 16-bit planes per operand (2: fp16, f16x2)
 // runs the v2 schedule if it covers (tall, wide, ns); returns HN_OK / error, or 1 when it does not cover the request
 int launch_conv2(const ConvArgs& a, bool tall, bool wide, int ns, hipStream_t stream);
 // conv_igemm3.hip: bf16x3, 128 x 256 tile, weight operand by LDS-DMA

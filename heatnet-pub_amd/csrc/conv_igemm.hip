@@ -550,6 +550,10 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
         // the caller chose the operand format (fp16 planes + scales): there is no other kernel to fall back to
         if (!planes_ok || a.a_scale == nullptr) return HN_ESHAPE;
         pl.family = FAM_V1; pl.math = MATH_H2; pl.mode = MODE_VEC_BUF;
+        if (bk_sel == 2) {  // the wave-specialised schedule (conv_igemm2.hip)
+            pl.family = FAM_V2; pl.math = MATH2_H2;
+            pl.bk = (a.C % 64 == 0 && a.cps == 0) ? 64 : 32;
+        }
     } else if (math == HN_MATH_BF16 && planes_ok) {
         pl.family = FAM_V2; pl.math = MATH2_BF16; pl.mode = MODE_VEC_BUF;
         pl.bk = a.C % 64 == 0 ? 64 : 32;

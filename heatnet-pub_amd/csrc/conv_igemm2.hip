@@ -20,7 +20,9 @@
 // check and come back as zeros, so neither loop contains conditional code.
 // Arithmetic: NS = 3 -> bf16x3 (six products per fp32 product, identical accumulation order to conv_igemm.hip: results
 // are bitwise identical to the first schedule); NS = 1 -> plain bf16 (operands rounded to nearest bf16, fp32 accumulate;
-// K step 64 when Cin allows).
+// K step 64 when Cin allows); NS = 2 -> f16x2 (two fp16 planes per operand, per-tensor power-of-two scales, three products:
+// the producers' share of a step shrinks from ~200 to ~40 vector instructions per lane and a third of the LDS bytes go, so
+// here -- unlike under bf16x3 -- the consumers' MFMA chain is the longest thing in a step).
 #include "conv_common.h"
 
 namespace hnconv {
@@ -55,6 +57,14 @@ __global__ __launch_bounds__(512, (conv2_waves<TM, TN, NS, BK>())) void conv_ige
     conv_fill_rowinfo<BM>(p, rowinfo, m0, tid + (producer ? 256 : 0));  // (rows beyond 256 do not exist: BM <= 128)
     __syncthreads();
 
+    constexpr bool H2 = NS == 2;
+    float a_s = 1.f, o_s = 1.f, i_s = 1.f;  // f16x2 operand scales (conv_igemm.hip)
+    if constexpr (H2) {
+        float a_inv;
+        hn_h2_scales_of_slot(p.a_scale, a_s, a_inv);
+        o_s = a_inv * p.w_scale[1];
+        i_s = a_s * p.w_scale[0];
+    }
     const int total_chunks = p.Kdim / BK;  // a step never straddles a tap: C % BK == 0
     const int kc_first = p.cps > 0 ? split * p.cps : 0;
     const int nchunks = p.cps > 0 ? min(p.cps, total_chunks - kc_first) : total_chunks;  // >= 1 by construction
@@ -167,6 +177,11 @@ __global__ __launch_bounds__(512, (conv2_waves<TM, TN, NS, BK>())) void conv_ige
                     *reinterpret_cast<bf16x4*>(dst) = h;
                     *reinterpret_cast<bf16x4*>(dst + A_PLANE) = m;
                     *reinterpret_cast<bf16x4*>(dst + 2 * A_PLANE) = l;
+                } else if constexpr (H2) {
+                    f16x4 h, l;
+                    split2h(v, a_s, h, l);
+                    *reinterpret_cast<f16x4*>(dst) = h;
+                    *reinterpret_cast<f16x4*>(dst + A_PLANE) = l;
                 } else {
                     *reinterpret_cast<bf16x4*>(dst) = round_bf16(v);
                 }
@@ -205,7 +220,7 @@ __global__ __launch_bounds__(512, (conv2_waves<TM, TN, NS, BK>())) void conv_ige
     // ---- consumers: LDS -> fragments -> MFMA -> epilogue --------------------------------------------------------
     const AccMap<TM, TN, true> am{wm, wn, lane, n0};
     f32x16 acc[TM][TN];
-    conv_init_acc<TM, TN, true>(p, acc, am, rowinfo, m0);
+    conv_init_acc<TM, TN, true>(p, acc, am, rowinfo, m0, i_s);
 
     // lane -> (row lane & 15, k group lane >> 4) of a 16-row block; every block starts at a multiple of 16 rows
     const int frag_off = (lane & 15) * ROW + (((lane >> 4) ^ x3_kflip(lane & 15)) * 16);
@@ -238,7 +253,13 @@ __global__ __launch_bounds__(512, (conv2_waves<TM, TN, NS, BK>())) void conv_ige
             f32x4 c = {blk[sb], blk[sb + 1], blk[sb + 2], blk[sb + 3]};
 #pragma unroll
             for (int h = 0; h < KH; ++h) {
-                if constexpr (NS == 3) {  // smallest terms first (same order as conv_igemm.hip)
+                if constexpr (H2) {
+                    const f16x8 ah = __builtin_bit_cast(f16x8, fa.v[0][h]), al = __builtin_bit_cast(f16x8, fa.v[1][h]);
+                    const f16x8 bh = __builtin_bit_cast(f16x8, fb.v[bj][0][h]), bl = __builtin_bit_cast(f16x8, fb.v[bj][1][h]);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);  // lo*hi
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);  // hi*lo
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);  // hi*hi
+                } else if constexpr (NS == 3) {  // smallest terms first (same order as conv_igemm.hip)
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v[1][h], fb.v[bj][1][h], c, 0, 0, 0);  // mid*mid
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v[0][h], fb.v[bj][2][h], c, 0, 0, 0);  // hi*lo
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v[2][h], fb.v[bj][0][h], c, 0, 0, 0);  // lo*hi
@@ -277,7 +298,7 @@ __global__ __launch_bounds__(512, (conv2_waves<TM, TN, NS, BK>())) void conv_ige
         }
         if (kc < nchunks) step(stage0);
     }
-    conv_epilogue<TM, TN, true>(p, acc, am, rowinfo, m0, tile_m, split);
+    conv_epilogue<TM, TN, true, 64 * TM, 64 * TN, H2>(p, acc, am, rowinfo, m0, tile_m, split, o_s);
 }
 
 template <int TM, int TN, int NS, int BK>
@@ -318,6 +339,12 @@ int launch_conv2(const ConvArgs& a, bool tall, bool wide, int ns, hipStream_t st
     if (ns == MATH2_X3) {
         if (a.C % 32 != 0) return 1;
         return launch2_tile<3, 32>(a, tall, wide, stream);
+    }
+    if (ns == MATH2_H2) {
+        if (a.a_scale == nullptr || a.w_scale == nullptr || a.in_scale != nullptr) return 1;
+        if (a.C % 64 == 0 && a.cps == 0) return launch2_tile<2, 64>(a, tall, wide, stream);
+        if (a.C % 32 == 0) return launch2_tile<2, 32>(a, tall, wide, stream);
+        return 1;
     }
     if (ns == MATH2_BF16) {
         // (K step 128 -- half the barriers -- measured 15-30 % slower: 192 staging registers per producer thread)

@@ -86,14 +86,16 @@ int hn_conv2d_fwd(const float* x, const float* w, const void* w_x3, const float*
  * v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation; tensors in memory, BatchNorm statistics, master weights and the
  * optimizer stay fp32 (BASELINE configs[4], "mixed-precision bf16 conv MFMA path").  Never the default.
  * Geometries the bf16 kernels do not cover (Cin % 32 != 0, unaligned tensors, zero-dilated gathers) run on the fp32
- * kernels under either setting.  Process-wide; not synchronised with in-flight launches. */
+ * kernels under either setting.  Process-wide; not synchronised with in-flight launches.
+ * HN_MATH_F16X2 (3): fp32 results from two fp16 terms per operand and per-tensor power-of-two scales -- selected per call
+ * through the *_scaled entry points (section "f16x2" below), never a process-wide default: it needs the scales. */
 #define HN_MATH_F32 0
 #define HN_MATH_BF16X3 1
 #define HN_MATH_BF16 2
+#define HN_MATH_F16X2 3
 #define HN_SCALE_WORDS 64
-#define HN_SCALE_STRIDE 32 /* 32-bit words between the words of a slot: a slot is 64 x 128 B = 8 KB */
+#define HN_SCALE_STRIDE 32 /* 32-bit words between the words of a scale slot: a slot is 64 x 128 B = 8 KB */
 #define HN_SCALE_SLOT_FLOATS (HN_SCALE_WORDS * HN_SCALE_STRIDE)
-#define HN_MATH_F16X2 3 /* per call only (the *_scaled entry points below); not a process-wide default */
 int hn_set_conv_math(int math);
 int hn_get_conv_math(void);
 

@@ -951,3 +951,40 @@ def test_f16x2_all_zero_and_nonfinite_operands(dev):
         assert not torch.isfinite(y[0, :, 4, 5]).all()
     finally:
         ops.set_conv_math(prev)
+
+
+@pytest.mark.parametrize("case", X3_SCHEDULE_CASES + [(2, 128, 40, 44, 256, 3, 1, 1, 1)], ids=str)
+def test_f16x2_schedules_agree_bitwise(dev, case):
+    """The wave-specialised schedule of the f16x2 arithmetic (variant bk = 2: producer / consumer waves, K step 64 where Cin
+    allows) against the two-phase one: bit-identical outputs through ops.conv2d, forward and data gradient (split-K cases
+    with a tolerance: float atomics)."""
+    ops = _ops()
+    n, cin, h, w, cout, k, stride, pad, dil = case
+    x = rnd(n, cin, h, w, seed=84)
+    wt = rnd(cout, cin, k, k, seed=85, scale=1.0 / np.sqrt(cin * k * k))
+    outs = []
+    prev_math = ops.set_conv_math("f16x2")
+    prev_tune = ops.AUTOTUNE
+    cands = ops._igemm_candidates
+    try:
+        ops.AUTOTUNE = False  # candidates[0] is used
+        for bk in (0, 2):
+            ops._igemm_candidates = lambda cout_, kind, cred=0, math_name=None, bk=bk: [ops._variant(bk, 0, 0, ops._MATH_CODES[math_name])]
+            xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+            wd = wt.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+            y = ops.conv2d(xd, wd, None, stride, pad, dil)
+            y.backward(rnd(*y.shape, seed=86).to(dev))
+            outs.append((y.detach().clone(), xd.grad.detach().clone()))
+    finally:
+        ops._igemm_candidates = cands
+        ops.AUTOTUNE = prev_tune
+        ops.set_conv_math(prev_math)
+    (y1, dx1), (y2, dx2) = outs
+    if y1.shape[0] * y1.shape[2] * y1.shape[3] > 2048:
+        assert torch.equal(y1, y2)
+    else:
+        close(y2, y1, atol=1e-5, what="y (split-K)")
+    if n * h * w > 2048 * (4 if stride == 2 else 1):
+        assert torch.equal(dx1, dx2)
+    else:
+        close(dx2, dx1, atol=1e-5, what="dx (split-K)")
