@@ -407,7 +407,7 @@ def main():
                                "roofline": alt_roof}
             finally:
                 ops.set_conv_math(main_math)
-        alt = alts.pop("f32", None) or next(iter(alts.values()))
+        alt = alts.get("f32") or next(iter(alts.values()))
     others = None
     if world == 1 and args.workload == "seg" and not args.no_other_workloads:
         # the other BASELINE configurations, timed in the same process so that one default run records them all (N=1
