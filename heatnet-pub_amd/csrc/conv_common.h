@@ -294,8 +294,8 @@ enum : int { MATH2_X3 = 3, MATH2_BF16 = 1, MATH2_H2 = 2 };  // = number of 16-bi
 // runs the v2 schedule if it covers (tall, wide, ns); returns HN_OK / error, or 1 when it does not cover the request
 int launch_conv2(const ConvArgs& a, bool tall, bool wide, int ns, hipStream_t stream);
 // conv_igemm3.hip: bf16x3, 128 x 256 tile, weight operand by LDS-DMA
-bool conv3_covers(const ConvArgs& a);
-int launch_conv3(const ConvArgs& a, hipStream_t stream);
+bool conv3_covers(const ConvArgs& a, int planes, bool wide);
+int launch_conv3(const ConvArgs& a, int planes, bool wide, hipStream_t stream);
 const char* conv2_kernel_name(bool tall, bool wide, int ns);
 
 }  // namespace hnconv

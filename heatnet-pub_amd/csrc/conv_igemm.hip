@@ -539,7 +539,7 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
                         (long long)a.H * a.W >= 128;
     // the bf16 kernels need the pre-split weight planes and the buffer loaders; anything else runs on the fp32 MFMA
     const int math = math_sel ? math_sel - 1 : g_conv_math;  // HN_MATH_*
-    if (bk_sel == 3 && math != HN_MATH_BF16X3) return HN_EINVAL;  // the third schedule exists for bf16x3 only
+    if (bk_sel == 3 && math != HN_MATH_BF16X3 && math != HN_MATH_F16X2) return HN_EINVAL;  // (the LDS-DMA schedule)
     const bool planes_ok = a.wx3 != nullptr && vec && !strided && buf_ok && hn_aligned16(a.wx3) &&
                            a.wx3_plane % 8 == 0 && 6 * a.wx3_plane < (1ll << 32);
     pl.tall = tall;
@@ -553,6 +553,8 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
         if (bk_sel == 2) {  // the wave-specialised schedule (conv_igemm2.hip)
             pl.family = FAM_V2; pl.math = MATH2_H2;
             pl.bk = (a.C % 64 == 0 && a.cps == 0) ? 64 : 32;
+        } else if (bk_sel == 3 && conv3_covers(a, 2, tn_sel == 3)) {  // weights by LDS-DMA (conv_igemm3.hip)
+            pl.family = FAM_V3; pl.math = MATH_H2; pl.tall = true; pl.wide = true; pl.wn = tn_sel == 3 ? 4 : 2;
         }
     } else if (math == HN_MATH_BF16 && planes_ok) {
         pl.family = FAM_V2; pl.math = MATH2_BF16; pl.mode = MODE_VEC_BUF;
@@ -562,7 +564,7 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
         // default: the first schedule -- measured 2-10 % faster than the wave-specialised one on every layer shape of the
         // network (profiles/r02_conv_schedules.txt)
         if (bk_sel == 2) { pl.family = FAM_V2; pl.math = MATH2_X3; }
-        else if (bk_sel == 3 && conv3_covers(a)) { pl.family = FAM_V3; pl.math = MATH_X3; pl.tall = pl.wide = true; }
+        else if (bk_sel == 3 && conv3_covers(a, 3, true)) { pl.family = FAM_V3; pl.math = MATH_X3; pl.tall = pl.wide = true; }
         else {
             pl.family = FAM_V1; pl.math = MATH_X3;
             if (tn_sel == 3 && a.cps == 0) { pl.wn = 4; pl.tall = pl.wide = true; }  // 128 x 256 tile, eight waves
@@ -578,7 +580,7 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
 }
 
 int run_conv(const ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
-    if (pl.family == FAM_V3) return launch_conv3(a, stream);
+    if (pl.family == FAM_V3) return launch_conv3(a, pl.math == MATH_H2 ? 2 : 3, pl.wn == 4 || pl.math != MATH_H2, stream);
     if (pl.family == FAM_V2) {
         const int rc = launch_conv2(a, pl.tall, pl.wide, pl.math, stream);
         return rc == 1 ? HN_ESHAPE : rc;
@@ -606,7 +608,8 @@ int dispatch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
 // the kernel's name as rocprofv3 prints it (tools/pmc_aggregate.py keys), for per-instantiation accounting
 void plan_name(const ConvPlan& pl, char* buf, int n) {
     const int tm = pl.tall ? 2 : 1, tn = pl.wide ? 2 : 1;
-    if (pl.family == FAM_V3) snprintf(buf, n, "conv_igemm3_kernel");
+    if (pl.family == FAM_V3) snprintf(buf, n, "conv_igemm3_kernel<%d, %d, %d>", pl.math == MATH_H2 ? 2 : 3,
+                                      (pl.math == MATH_H2 && pl.wn != 4) ? 2 : 4, (pl.math == MATH_H2 && pl.wn != 4) ? 2 : 1);
     else if (pl.family == FAM_V2) snprintf(buf, n, "conv_igemm2_kernel<%d, %d, %d, %d, false>", tm, tn, pl.math, pl.bk);
     else if (pl.math == MATH_X3) snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 1, %d>", tm, tn, pl.mode, pl.bk, pl.wn);
     else if (pl.math == MATH_H2) snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 2, 2>", tm, tn, pl.mode, pl.bk);

@@ -6,7 +6,7 @@
 // (profiles/r02_conv_schedules.txt).  Half of those bytes are the weight planes, which are already
 // in their final form in memory.  Here they never touch a VGPR:
 //
-//   workgroup = 8 waves (2 x 4), block tile 128 pixels x 256 channels, ONE workgroup per CU (155 KB of LDS):
+//   bf16x3: workgroup = 8 waves (2 x 4), block tile 128 pixels x 256 channels, ONE workgroup per CU (155 KB of LDS):
 //     A stage   [3][128][80 B]        30 KB   activations: buffer loads -> registers -> exact 3-way split -> ds_write
 //     B stage 0 [3][256][80 B]        61 KB   weights: 60 x 1-KiB LDS-DMA pieces per K step (lane-linear: the 80-byte rows
 //     B stage 1                        61 KB   are 5 slots of 16 B, the 5th -- the bank padding -- fetched out of range)
@@ -18,6 +18,10 @@
 // Raw s_barrier with explicit waits: a __syncthreads() would drain the LDS-DMA just issued (cdna_hip_programming.md,
 // "Pipelining across barriers").  Same LDS images, fragment reads, MFMA order and epilogue as conv_igemm.hip: results are
 // bitwise identical to the other schedules.
+// f16x2 (two fp16 planes): the same kernel with 2 planes -- either the eight-wave 128 x 256 tile (104 KB), or FOUR waves on
+// 128 x 128 with 62 KB of LDS, i.e. TWO workgroups per CU as in the first schedule, and two A staging sets (fetch distance
+// two steps: the waits count "all but the newest RA loads").  What it removes from the first schedule: the weight planes'
+// trip through VGPRs and ds_write_b128 (13 of the ~25 VGPR->LDS transfer cycles a wave spends per K step).
 #include "conv_common.h"
 
 namespace hnconv {
@@ -30,32 +34,49 @@ __device__ __forceinline__ void dma16_lds(__amdgpu_buffer_rsrc_t rsrc, char* lds
 #endif
 }
 
-constexpr int T3_BM = 128, T3_BN = 256, T3_NT = 512, T3_BK = 32;
-constexpr int T3_A_PLANE = T3_BM * X3_ROW, T3_B_PLANE = T3_BN * X3_ROW;
-constexpr int T3_A_BYTES = 3 * T3_A_PLANE, T3_B_BYTES = 3 * T3_B_PLANE;  // 30 720 and 61 440
-constexpr int T3_B_CHUNKS = T3_B_BYTES / 1024;                           // 60 LDS-DMA pieces per K step
-constexpr int T3_LDS = T3_A_BYTES + 2 * T3_B_BYTES + T3_BM * 16;
+// NS planes per operand (3: bf16x3, 2: f16x2), WN waves along the channel axis (4: eight waves, 128 x 256 tile, one workgroup
+// per CU; 2: four waves, 128 x 128 tile, two workgroups per CU), SETS staging register sets of the A operand (fetch distance
+// in K steps).
+template <int NS, int WN>
+struct T3 {
+    static constexpr int BM = 128, BN = 64 * WN, NT = 128 * WN, BK = 32;
+    static constexpr int A_PLANE = BM * X3_ROW, B_PLANE = BN * X3_ROW;
+    static constexpr int A_BYTES = NS * A_PLANE, B_BYTES = NS * B_PLANE;
+    static constexpr int B_CHUNKS = B_BYTES / 1024;  // 1-KiB LDS-DMA pieces per K step
+    static constexpr int LDS = A_BYTES + 2 * B_BYTES + BM * 16;
+};
 
-__global__ __launch_bounds__(T3_NT, 2) void conv_igemm3_kernel(const ConvArgs p) {
-    constexpr int BM = T3_BM, BN = T3_BN, TM = 2, TN = 2, BK = T3_BK;
+template <int NS, int WN, int SETS>
+__global__ __launch_bounds__(128 * WN, 2) void conv_igemm3_kernel(const ConvArgs p) {
+    using T = T3<NS, WN>;
+    constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = 2, TN = 2, BK = T::BK;
+    constexpr int NW = 2 * WN;  // waves
+    constexpr bool H2 = NS == 2;
     extern __shared__ __attribute__((aligned(16))) char smem3[];
     char* As = smem3;
-    char* Bs0 = smem3 + T3_A_BYTES;
-    int* rowinfo = reinterpret_cast<int*>(smem3 + T3_A_BYTES + 2 * T3_B_BYTES);
+    char* Bs0 = smem3 + T::A_BYTES;
+    int* rowinfo = reinterpret_cast<int*>(smem3 + T::A_BYTES + 2 * T::B_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int logical = hn_xcd_remap(blockIdx.x, gridDim.x);
     int tile_m, tile_n;
     conv_tile_of(p, logical, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     conv_fill_rowinfo<BM>(p, rowinfo, m0, tid);
     __syncthreads();
+    float a_s = 1.f, o_s = 1.f, i_s = 1.f;  // f16x2 operand scales (conv_igemm.hip)
+    if constexpr (H2) {
+        float a_inv;
+        hn_h2_scales_of_slot(p.a_scale, a_s, a_inv);
+        o_s = a_inv * p.w_scale[1];
+        i_s = a_s * p.w_scale[0];
+    }
 
-    // ---- A operand: 128 rows x 8 pieces of 16 B per K step = 2 pieces per thread --------------------------------
-    constexpr int RA = BM * 8 / T3_NT;  // 2
-    constexpr int AROWS = T3_NT / 8;    // 64 rows per pass
+    // ---- A operand: 128 rows x 8 pieces of 16 B per K step ------------------------------------------------------
+    constexpr int RA = BM * 8 / NT;   // pieces per thread: 2 (eight waves) or 4
+    constexpr int AROWS = NT / 8;     // rows per pass
     const int a_c = tid & 7, a_r = tid >> 3;
     int ahb[RA], awb[RA], aoff32[RA];
     const int nb0 = __builtin_amdgcn_readfirstlane(rowinfo[2]);
@@ -70,97 +91,115 @@ __global__ __launch_bounds__(T3_NT, 2) void conv_igemm3_kernel(const ConvArgs p)
         awb[q] = rowinfo[r * 4 + 1];
         aoff32[q] = (((rowinfo[r * 4 + 2] - nb0) + ahb[q] * p.W + awb[q]) * p.ldx + a_c * 4) * 4;
     }
-    // ---- B operand: per wave, the source offsets of its LDS-DMA pieces (chunk c = wave + 8 j, slot = 64 c + lane) ---
-    constexpr int NBC = (T3_B_CHUNKS + 7) / 8;  // 8 pieces for waves 0-3, 7 for waves 4-7
-    const unsigned b_records = (unsigned)(3 * p.wx3_plane * 2);
+    // ---- B operand: per wave, the source offsets of its LDS-DMA pieces (chunk c = wave + NW j, slot = 64 c + lane) ---
+    constexpr int NBC = (T::B_CHUNKS + NW - 1) / NW;
+    const unsigned b_records = (unsigned)(NS * p.wx3_plane * 2);
     const __amdgpu_buffer_rsrc_t rsrc_b =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.wx3), 0, b_records, 0x00020000);
     unsigned bvoff[NBC];
 #pragma unroll
     for (int j = 0; j < NBC; ++j) {
-        const int slot = 64 * (wave + 8 * j) + lane;
+        const int slot = 64 * (wave + NW * j) + lane;
         const int plane = slot / (BN * 5), rem = slot % (BN * 5);
         const int row = rem / 5, piece = rem % 5;
         const int co = n0 + row;
-        const bool ok = piece < 4 && co < p.K && wave + 8 * j < T3_B_CHUNKS;
+        const bool ok = piece < 4 && co < p.K && wave + NW * j < T::B_CHUNKS;
         bvoff[j] = ok ? (unsigned)((plane * p.wx3_plane + (long long)co * p.Kdim + ((piece ^ x3_kflip(row)) * 8)) * 2) : b_records;
     }
 
     const int nchunks = p.Kdim / BK;  // (no split-K on this tile; C % 32 == 0)
-    int st_kh = 0, st_kw = 0, st_c0 = 0, st_k0 = 0, st_chunk = 0;
-    f32x4 va[RA];
-    auto fetch_a = [&]() {  // chunk st_chunk -> va (zeros past the end); advances the position
-        const bool live = st_chunk < nchunks;
-        const int dh = st_kh * p.dil, dw = st_kw * p.dil;
-        const int doff = ((dh * p.W + dw) * p.ldx + st_c0) * 4;
+    // A and B are fetched at different distances (A: SETS steps ahead, B: one), so each has its own position
+    struct Pos { int kh, kw, c0, k0, chunk; };
+    Pos pa{0, 0, 0, 0, 0}, pb{0, 0, 0, 0, 0};
+    auto advance = [&](Pos& s) {
+        s.c0 += BK;
+        const int wrap_c = s.c0 >= p.C ? 1 : 0;
+        s.c0 = wrap_c ? 0 : s.c0;
+        s.kw += wrap_c;
+        const int wrap_w = s.kw == p.KW ? 1 : 0;
+        s.kw = wrap_w ? 0 : s.kw;
+        s.kh += wrap_w;
+        s.k0 += BK;
+        ++s.chunk;
+    };
+    f32x4 va[SETS][RA];
+    auto fetch_a = [&](f32x4 (&dst)[RA]) {  // chunk pa.chunk -> dst (zeros past the end); advances
+        const bool live = pa.chunk < nchunks;
+        const int dh = pa.kh * p.dil, dw = pa.kw * p.dil;
+        const int doff = ((dh * p.W + dw) * p.ldx + pa.c0) * 4;
 #pragma unroll
         for (int q = 0; q < RA; ++q) {
             const bool ok = live & ((unsigned)(ahb[q] + dh) < (unsigned)p.H) & ((unsigned)(awb[q] + dw) < (unsigned)p.W);
-            va[q] = buffer_load16(rsrc_a, ok ? (unsigned)(aoff32[q] + doff) : a_records, 0);
+            dst[q] = buffer_load16(rsrc_a, ok ? (unsigned)(aoff32[q] + doff) : a_records, 0);
         }
+        advance(pa);
     };
-    auto dma_b = [&](char* bs) {  // chunk st_chunk -> bs (out of range past the end: zero fill)
-        const bool live = st_chunk < nchunks;
+    auto dma_b = [&](char* bs) {  // chunk pb.chunk -> bs (out of range past the end: zero fill); advances
+        const bool live = pb.chunk < nchunks;
 #pragma unroll
         for (int j = 0; j < NBC; ++j) {
-            if (j < NBC - 1 || wave < T3_B_CHUNKS - 8 * (NBC - 1))  // wave-uniform: the last round has 4 pieces
-                dma16_lds(rsrc_b, bs + 1024 * (wave + 8 * j), live ? bvoff[j] : b_records, (unsigned)(st_k0 * 2));
+            if (j < NBC - 1 || wave < T::B_CHUNKS - NW * (NBC - 1))  // wave-uniform: a ragged last round
+                dma16_lds(rsrc_b, bs + 1024 * (wave + NW * j), live ? bvoff[j] : b_records, (unsigned)(pb.k0 * 2));
         }
+        advance(pb);
     };
-    auto advance = [&]() {
-        st_c0 += BK;
-        const int wrap_c = st_c0 >= p.C ? 1 : 0;
-        st_c0 = wrap_c ? 0 : st_c0;
-        st_kw += wrap_c;
-        const int wrap_w = st_kw == p.KW ? 1 : 0;
-        st_kw = wrap_w ? 0 : st_kw;
-        st_kh += wrap_w;
-        st_k0 += BK;
-        ++st_chunk;
-    };
-    auto store_a = [&]() {
+    auto store_a = [&](const f32x4 (&src)[RA]) {
 #pragma unroll
         for (int q = 0; q < RA; ++q) {
-            bf16x4 h, m, l;
-            split3(va[q], h, m, l);
             const int row = a_r + AROWS * q;
             char* dst = As + row * X3_ROW + (((a_c >> 1) ^ x3_kflip(row)) * 16) + (a_c & 1) * 8;
-            *reinterpret_cast<bf16x4*>(dst) = h;
-            *reinterpret_cast<bf16x4*>(dst + T3_A_PLANE) = m;
-            *reinterpret_cast<bf16x4*>(dst + 2 * T3_A_PLANE) = l;
+            if constexpr (H2) {
+                f16x4 h, l;
+                split2h(src[q], a_s, h, l);
+                *reinterpret_cast<f16x4*>(dst) = h;
+                *reinterpret_cast<f16x4*>(dst + T::A_PLANE) = l;
+            } else {
+                bf16x4 h, m, l;
+                split3(src[q], h, m, l);
+                *reinterpret_cast<bf16x4*>(dst) = h;
+                *reinterpret_cast<bf16x4*>(dst + T::A_PLANE) = m;
+                *reinterpret_cast<bf16x4*>(dst + 2 * T::A_PLANE) = l;
+            }
         }
     };
 
     const AccMap<TM, TN, true> am{wm, wn, lane, n0};
     f32x16 acc[TM][TN];
-    conv_init_acc<TM, TN, true>(p, acc, am, rowinfo, m0);
+    conv_init_acc<TM, TN, true>(p, acc, am, rowinfo, m0, i_s);
 
     const int frag = (lane & 15) * X3_ROW + (((lane >> 4) ^ x3_kflip(lane & 15)) * 16);
     const char* a_frag = As + wm * TM * 32 * X3_ROW + frag;
     const int b_frag = wn * TN * 32 * X3_ROW + frag;
     auto mfma_phase = [&](const char* bs) {
-        bf16x8 fb[2 * TN][3];
+        using frag_t = std::conditional_t<H2, f16x8, bf16x8>;
+        frag_t fb[2 * TN][NS];
 #pragma unroll
         for (int bj = 0; bj < 2 * TN; ++bj)
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3)
-                fb[bj][s3] = *reinterpret_cast<const bf16x8*>(bs + b_frag + (s3 * BN + bj * 16) * X3_ROW);
+            for (int s3 = 0; s3 < NS; ++s3)
+                fb[bj][s3] = *reinterpret_cast<const frag_t*>(bs + b_frag + (s3 * BN + bj * 16) * X3_ROW);
 #pragma unroll
         for (int bi = 0; bi < 2 * TM; ++bi) {
-            bf16x8 fa[3];
+            frag_t fa[NS];
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) fa[s3] = *reinterpret_cast<const bf16x8*>(a_frag + (s3 * BM + bi * 16) * X3_ROW);
+            for (int s3 = 0; s3 < NS; ++s3) fa[s3] = *reinterpret_cast<const frag_t*>(a_frag + (s3 * BM + bi * 16) * X3_ROW);
 #pragma unroll
             for (int bj = 0; bj < 2 * TN; ++bj) {
                 const int sb = 4 * (2 * (bi & 1) + (bj & 1));
                 f32x16& blk = acc[bi >> 1][bj >> 1];
                 f32x4 c = {blk[sb], blk[sb + 1], blk[sb + 2], blk[sb + 3]};
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][1], c, 0, 0, 0);  // mid*mid
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][2], c, 0, 0, 0);  // hi*lo
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[bj][0], c, 0, 0, 0);  // lo*hi
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][1], c, 0, 0, 0);  // hi*mid
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][0], c, 0, 0, 0);  // mid*hi
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][0], c, 0, 0, 0);  // hi*hi
+                if constexpr (H2) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[bj][0], c, 0, 0, 0);  // lo*hi
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][1], c, 0, 0, 0);  // hi*lo
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][0], c, 0, 0, 0);  // hi*hi
+                } else {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][1], c, 0, 0, 0);  // mid*mid
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][2], c, 0, 0, 0);  // hi*lo
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[bj][0], c, 0, 0, 0);  // lo*hi
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][1], c, 0, 0, 0);  // hi*mid
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][0], c, 0, 0, 0);  // mid*hi
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][0], c, 0, 0, 0);  // hi*hi
+                }
                 blk[sb] = c[0];
                 blk[sb + 1] = c[1];
                 blk[sb + 2] = c[2];
@@ -168,52 +207,79 @@ __global__ __launch_bounds__(T3_NT, 2) void conv_igemm3_kernel(const ConvArgs p)
             }
         }
     };
-    // explicit waits + raw barrier (see header); the asm statements also keep hipcc from moving memory operations across
-    auto wait_vm = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    // explicit waits + raw barrier (see header); the asm statements also keep hipcc from moving memory operations across.
+    // Issue order inside a step is B DMA first, A loads second, so "all but the newest RA" = the B stage of this step and
+    // the A set of this step have landed while the A loads issued one step ago (SETS == 2) stay in flight.
+    auto wait_step = [] {
+        if constexpr (SETS == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     auto barrier = [] {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-
-    // prologue: chunk 0 in flight (A registers, B stage 0)
-    fetch_a();
-    dma_b(Bs0);
-    advance();
-    for (int kc = 0; kc < nchunks; ++kc) {
-        char* bs_cur = Bs0 + (kc & 1) * T3_B_BYTES;
-        char* bs_nxt = Bs0 + ((kc + 1) & 1) * T3_B_BYTES;
-        wait_vm();          // chunk kc: A in registers, B in its stage (this wave's pieces; the barrier covers the others')
-        store_a();
+    auto step = [&](int kc, f32x4 (&set)[RA]) {
+        char* bs_cur = Bs0 + (kc & 1) * T::B_BYTES;
+        char* bs_nxt = Bs0 + ((kc + 1) & 1) * T::B_BYTES;
+        wait_step();        // chunk kc: A in registers, B in its stage (this wave's pieces; the barrier covers the others')
+        store_a(set);
         barrier();          // #1: A stage and B stage kc & 1 complete for every wave
-        fetch_a();          // chunk kc + 1 (zeros past the end)
-        dma_b(bs_nxt);
-        advance();
+        dma_b(bs_nxt);      // chunk kc + 1
+        fetch_a(set);       // chunk kc + SETS (zeros past the end)
         mfma_phase(bs_cur);
         barrier();          // #2: every wave has read the A stage and B stage kc & 1
-    }
-    wait_vm();  // (the last, out-of-range fetches)
+    };
 
-    conv_epilogue<TM, TN, true, BM, BN>(p, acc, am, rowinfo, m0, tile_m, 0);
+    // prologue: B chunk 0, A chunks 0 .. SETS-1 in flight (the first wait_step() must see them in the steady-state order)
+    if constexpr (SETS == 2) {
+        fetch_a(va[0]);
+        dma_b(Bs0);
+        fetch_a(va[1]);
+        int kc = 0;
+        for (; kc + 1 < nchunks; kc += 2) {
+            step(kc, va[0]);
+            step(kc + 1, va[1]);
+        }
+        if (kc < nchunks) step(kc, va[0]);
+    } else {
+        dma_b(Bs0);
+        fetch_a(va[0]);
+        for (int kc = 0; kc < nchunks; ++kc) step(kc, va[0]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last, out-of-range fetches)
+
+    conv_epilogue<TM, TN, true, BM, BN, H2>(p, acc, am, rowinfo, m0, tile_m, 0, o_s);
+}
+
+template <int NS, int WN, int SETS>
+int launch3(const ConvArgs& a, hipStream_t stream) {
+    using T = T3<NS, WN>;
+    static std::atomic<unsigned long long> configured{0};
+    if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm3_kernel<NS, WN, SETS>), T::LDS, configured) != HN_OK)
+        return HN_ELAUNCH;
+    ConvArgs p = a;
+    p.ntm = (a.M + T::BM - 1) / T::BM;
+    p.ntn = (a.K + T::BN - 1) / T::BN;
+    p.gm = p.ntn >= (WN == 4 ? 4 : 8) ? 8 : 1;
+    if (p.gm > p.ntm) p.gm = p.ntm;
+    HN_LAUNCH((conv_igemm3_kernel<NS, WN, SETS>), dim3(p.ntm * p.ntn), dim3(T::NT), T::LDS, stream, p);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
 }
 
 }  // namespace
 
-bool conv3_covers(const ConvArgs& a) {
-    return a.C % 32 == 0 && a.cps == 0 && a.in_scale == nullptr && a.K >= 192 && a.wx3 != nullptr;
+// planes: 3 = bf16x3 (the 128 x 256 tile), 2 = f16x2 (wide: 128 x 256, eight waves; else 128 x 128, four waves, two per CU)
+bool conv3_covers(const ConvArgs& a, int planes, bool wide) {
+    if (!(a.C % 32 == 0 && a.cps == 0 && a.in_scale == nullptr && a.wx3 != nullptr)) return false;
+    if (planes == 2 && (a.a_scale == nullptr || a.w_scale == nullptr)) return false;
+    return a.K >= (planes == 3 || wide ? 192 : 96);
 }
 
-int launch_conv3(const ConvArgs& a, hipStream_t stream) {
-    static std::atomic<unsigned long long> configured{0};
-    if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm3_kernel), T3_LDS, configured) != HN_OK) return HN_ELAUNCH;
-    ConvArgs p = a;
-    p.ntm = (a.M + T3_BM - 1) / T3_BM;
-    p.ntn = (a.K + T3_BN - 1) / T3_BN;
-    p.gm = p.ntn >= 4 ? 8 : 1;
-    if (p.gm > p.ntm) p.gm = p.ntm;
-    HN_LAUNCH(conv_igemm3_kernel, dim3(p.ntm * p.ntn), dim3(T3_NT), T3_LDS, stream, p);
-    HN_CHECK_LAUNCH();
-    return HN_OK;
+int launch_conv3(const ConvArgs& a, int planes, bool wide, hipStream_t stream) {
+    if (planes == 3) return launch3<3, 4, 1>(a, stream);
+    return wide ? launch3<2, 4, 1>(a, stream) : launch3<2, 2, 2>(a, stream);
 }
 
 }  // namespace hnconv

@@ -453,9 +453,11 @@ def _tune_scratch(like):
 _X3_SCHEDULES = tuple(int(v) for v in os.environ.get("HEATNET_X3_SCHEDULES", "1").split(","))
 
 
-# f16x2 schedules offered to the tuner: 0 = two-phase (conv_igemm.hip); 2 = wave-specialised (conv_igemm2.hip: bitwise
-# identical, 0-30 % slower on every shape, profiles/r02_conv_schedules.txt run I -- reachable with HEATNET_H2_SCHEDULES=0,2)
-_H2_SCHEDULES = tuple(int(v) for v in os.environ.get("HEATNET_H2_SCHEDULES", "0").split(","))
+# f16x2 schedules offered to the tuner: 0 = two-phase (conv_igemm.hip); 3 = weights by LDS-DMA (conv_igemm3.hip: the 128 x 128
+# tile with two workgroups per CU and the eight-wave 128 x 256 tile; +4-16 % on the large shapes, run K of
+# profiles/r02_conv_schedules.txt); 2 = wave-specialised (conv_igemm2.hip: 0-30 % slower on every shape, run I -- only with
+# HEATNET_H2_SCHEDULES=0,2,3).  All bitwise identical.
+_H2_SCHEDULES = tuple(int(v) for v in os.environ.get("HEATNET_H2_SCHEDULES", "0,3").split(","))
 
 
 def _igemm_candidates(cout, kind, cred=0, math_name=None):
@@ -467,8 +469,13 @@ def _igemm_candidates(cout, kind, cred=0, math_name=None):
     # conv_igemm.hip; 2 = wave-specialised, conv_igemm2.hip -- slower on every shape of this network, so it is not a
     # tuning candidate; 3 = 128 x 256 tile with the weight planes by LDS-DMA, conv_igemm3.hip -- a few per cent faster on
     # some of the 3x3 and wide 1x1 layers in isolation, slower on others, no gain over a step); the bf16 kernels have one
-    bks = {"f32": (1, 2), "bf16x3": (1,), "bf16": (0,), "f16x2": _H2_SCHEDULES}[math_name]
+    bks = {"f32": (1, 2), "bf16x3": (1,), "bf16": (0,), "f16x2": tuple(b for b in _H2_SCHEDULES if b != 3)}[math_name]
     cands = [_variant(bk, tm, tn, math) for tm, tn in tiles for bk in bks]
+    if math_name == "f16x2" and 3 in _H2_SCHEDULES and cred % 32 == 0 and cred > 0:
+        if cout >= 96:
+            cands.append(_variant(3, 0, 0, math))   # 128 x 128, two workgroups per CU
+        if cout >= 192:
+            cands.append(_variant(3, 0, 3, math))   # 128 x 256, eight waves
     if math_name == "bf16x3" and 3 in _X3_SCHEDULES and cout >= 192 and cred % 32 == 0 and cred > 0:
         cands.append(_variant(3, 0, 0, math))  # (conv3_covers; a launch it does not cover runs the first schedule)
     return cands

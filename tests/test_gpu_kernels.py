@@ -955,9 +955,10 @@ def test_f16x2_all_zero_and_nonfinite_operands(dev):
 
 @pytest.mark.parametrize("case", X3_SCHEDULE_CASES + [(2, 128, 40, 44, 256, 3, 1, 1, 1)], ids=str)
 def test_f16x2_schedules_agree_bitwise(dev, case):
-    """The wave-specialised schedule of the f16x2 arithmetic (variant bk = 2: producer / consumer waves, K step 64 where Cin
-    allows) against the two-phase one: bit-identical outputs through ops.conv2d, forward and data gradient (split-K cases
-    with a tolerance: float atomics)."""
+    """The other schedules of the f16x2 arithmetic -- wave-specialised (variant bk = 2: producer / consumer waves, K step 64
+    where Cin allows) and weights-by-LDS-DMA (bk = 3: 128 x 128 with two workgroups per CU, or tn = 3: 128 x 256) -- against
+    the two-phase one: bit-identical outputs through ops.conv2d, forward and data gradient (split-K cases with a tolerance:
+    float atomics; geometries a schedule does not cover run the two-phase kernel)."""
     ops = _ops()
     n, cin, h, w, cout, k, stride, pad, dil = case
     x = rnd(n, cin, h, w, seed=84)
@@ -968,8 +969,8 @@ def test_f16x2_schedules_agree_bitwise(dev, case):
     cands = ops._igemm_candidates
     try:
         ops.AUTOTUNE = False  # candidates[0] is used
-        for bk in (0, 2):
-            ops._igemm_candidates = lambda cout_, kind, cred=0, math_name=None, bk=bk: [ops._variant(bk, 0, 0, ops._MATH_CODES[math_name])]
+        for bk, tn in ((0, 0), (2, 0), (3, 0), (3, 3)):  # two-phase | wave-specialised | LDS-DMA 128x128 | LDS-DMA 128x256
+            ops._igemm_candidates = lambda cout_, kind, cred=0, math_name=None, bk=bk, tn=tn: [ops._variant(bk, 0, tn, ops._MATH_CODES[math_name])]
             xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
             wd = wt.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
             y = ops.conv2d(xd, wd, None, stride, pad, dil)
@@ -979,12 +980,13 @@ def test_f16x2_schedules_agree_bitwise(dev, case):
         ops._igemm_candidates = cands
         ops.AUTOTUNE = prev_tune
         ops.set_conv_math(prev_math)
-    (y1, dx1), (y2, dx2) = outs
-    if y1.shape[0] * y1.shape[2] * y1.shape[3] > 2048:
-        assert torch.equal(y1, y2)
-    else:
-        close(y2, y1, atol=1e-5, what="y (split-K)")
-    if n * h * w > 2048 * (4 if stride == 2 else 1):
-        assert torch.equal(dx1, dx2)
-    else:
-        close(dx2, dx1, atol=1e-5, what="dx (split-K)")
+    y1, dx1 = outs[0]
+    for y2, dx2 in outs[1:]:
+        if y1.shape[0] * y1.shape[2] * y1.shape[3] > 2048:
+            assert torch.equal(y1, y2)
+        else:
+            close(y2, y1, atol=1e-5, what="y (split-K)")
+        if n * h * w > 2048 * (4 if stride == 2 else 1):
+            assert torch.equal(dx1, dx2)
+        else:
+            close(dx2, dx1, atol=1e-5, what="dx (split-K)")
