@@ -53,7 +53,7 @@ using namespace hnconv;
 // Loader variants.  BUF fetches through buffer descriptors: one SGPR resource per tile, 32-bit byte offsets, and
 // out-of-range taps / rows are zero-filled by the hardware range check instead of by selects.
 enum : int { MODE_SCALAR = 0, MODE_SCALAR_STRIDED = 1, MODE_VEC = 2, MODE_VEC_STRIDED = 3, MODE_VEC_BUF = 4 };
-enum : int { MATH_F32 = 0, MATH_X3 = 1, MATH_H2 = 2 };
+enum : int { MATH_F32 = 0, MATH_X3 = 1, MATH_H2 = 2, MATH3_BF16 = 3 };  // (MATH3_BF16: plan code of FAM_V3 only)
 
 // STRIDED = the gathered tensor is "dilated" by in_dil > 1 (data gradient of a strided convolution): taps must
 // land on multiples of in_dil.  Kept out of the common instantiation because it costs integer divisions per tap.
@@ -539,7 +539,7 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
                         (long long)a.H * a.W >= 128;
     // the bf16 kernels need the pre-split weight planes and the buffer loaders; anything else runs on the fp32 MFMA
     const int math = math_sel ? math_sel - 1 : g_conv_math;  // HN_MATH_*
-    if (bk_sel == 3 && math != HN_MATH_BF16X3 && math != HN_MATH_F16X2) return HN_EINVAL;  // (the LDS-DMA schedule)
+    if (bk_sel == 3 && math == HN_MATH_F32) return HN_EINVAL;  // (the LDS-DMA schedule needs weight planes)
     const bool planes_ok = a.wx3 != nullptr && vec && !strided && buf_ok && hn_aligned16(a.wx3) &&
                            a.wx3_plane % 8 == 0 && 6 * a.wx3_plane < (1ll << 32);
     pl.tall = tall;
@@ -559,6 +559,9 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
     } else if (math == HN_MATH_BF16 && planes_ok) {
         pl.family = FAM_V2; pl.math = MATH2_BF16; pl.mode = MODE_VEC_BUF;
         pl.bk = a.C % 64 == 0 ? 64 : 32;
+        if (bk_sel == 3 && conv3_covers(a, 1, tn_sel == 3)) {  // weights by LDS-DMA (conv_igemm3.hip)
+            pl.family = FAM_V3; pl.math = MATH3_BF16; pl.tall = pl.wide = true; pl.wn = tn_sel == 3 ? 4 : 2; pl.bk = 32;
+        }
     } else if (math == HN_MATH_BF16X3 && planes_ok) {
         pl.mode = MODE_VEC_BUF;
         // default: the first schedule -- measured 2-10 % faster than the wave-specialised one on every layer shape of the
@@ -580,7 +583,10 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
 }
 
 int run_conv(const ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
-    if (pl.family == FAM_V3) return launch_conv3(a, pl.math == MATH_H2 ? 2 : 3, pl.wn == 4 || pl.math != MATH_H2, stream);
+    if (pl.family == FAM_V3) {
+        const int planes = pl.math == MATH_H2 ? 2 : (pl.math == MATH3_BF16 ? 1 : 3);
+        return launch_conv3(a, planes, pl.wn == 4 || planes == 3, stream);
+    }
     if (pl.family == FAM_V2) {
         const int rc = launch_conv2(a, pl.tall, pl.wide, pl.math, stream);
         return rc == 1 ? HN_ESHAPE : rc;
@@ -608,8 +614,11 @@ int dispatch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
 // the kernel's name as rocprofv3 prints it (tools/pmc_aggregate.py keys), for per-instantiation accounting
 void plan_name(const ConvPlan& pl, char* buf, int n) {
     const int tm = pl.tall ? 2 : 1, tn = pl.wide ? 2 : 1;
-    if (pl.family == FAM_V3) snprintf(buf, n, "conv_igemm3_kernel<%d, %d, %d>", pl.math == MATH_H2 ? 2 : 3,
-                                      (pl.math == MATH_H2 && pl.wn != 4) ? 2 : 4, (pl.math == MATH_H2 && pl.wn != 4) ? 2 : 1);
+    if (pl.family == FAM_V3) {
+        const int planes = pl.math == MATH_H2 ? 2 : (pl.math == MATH3_BF16 ? 1 : 3);
+        const bool small = planes != 3 && pl.wn != 4;  // the 128 x 128 four-wave tile with two A staging sets
+        snprintf(buf, n, "conv_igemm3_kernel<%d, %d, %d>", planes, small ? 2 : 4, small ? 2 : 1);
+    }
     else if (pl.family == FAM_V2) snprintf(buf, n, "conv_igemm2_kernel<%d, %d, %d, %d, false>", tm, tn, pl.math, pl.bk);
     else if (pl.math == MATH_X3) snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 1, %d>", tm, tn, pl.mode, pl.bk, pl.wn);
     else if (pl.math == MATH_H2) snprintf(buf, n, "conv_igemm_kernel<%d, %d, %d, %d, 2, 2>", tm, tn, pl.mode, pl.bk);

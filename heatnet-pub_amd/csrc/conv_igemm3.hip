@@ -153,6 +153,8 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm3_kernel(const ConvArgs
                 split2h(src[q], a_s, h, l);
                 *reinterpret_cast<f16x4*>(dst) = h;
                 *reinterpret_cast<f16x4*>(dst + T::A_PLANE) = l;
+            } else if constexpr (NS == 1) {
+                *reinterpret_cast<bf16x4*>(dst) = round_bf16(src[q]);
             } else {
                 bf16x4 h, m, l;
                 split3(src[q], h, m, l);
@@ -192,6 +194,8 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm3_kernel(const ConvArgs
                     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[bj][0], c, 0, 0, 0);  // lo*hi
                     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][1], c, 0, 0, 0);  // hi*lo
                     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][0], c, 0, 0, 0);  // hi*hi
+                } else if constexpr (NS == 1) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][0], c, 0, 0, 0);
                 } else {
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[bj][1], c, 0, 0, 0);  // mid*mid
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][2], c, 0, 0, 0);  // hi*lo
@@ -270,7 +274,8 @@ int launch3(const ConvArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-// planes: 3 = bf16x3 (the 128 x 256 tile), 2 = f16x2 (wide: 128 x 256, eight waves; else 128 x 128, four waves, two per CU)
+// planes: 3 = bf16x3 (the 128 x 256 tile), 2 = f16x2, 1 = bf16 (wide: 128 x 256, eight waves; else 128 x 128, four waves, two
+// workgroups per CU)
 bool conv3_covers(const ConvArgs& a, int planes, bool wide) {
     if (!(a.C % 32 == 0 && a.cps == 0 && a.in_scale == nullptr && a.wx3 != nullptr)) return false;
     if (planes == 2 && (a.a_scale == nullptr || a.w_scale == nullptr)) return false;
@@ -279,6 +284,7 @@ bool conv3_covers(const ConvArgs& a, int planes, bool wide) {
 
 int launch_conv3(const ConvArgs& a, int planes, bool wide, hipStream_t stream) {
     if (planes == 3) return launch3<3, 4, 1>(a, stream);
+    if (planes == 1) return wide ? launch3<1, 4, 1>(a, stream) : launch3<1, 2, 2>(a, stream);
     return wide ? launch3<2, 4, 1>(a, stream) : launch3<2, 2, 2>(a, stream);
 }
 

@@ -471,7 +471,7 @@ def _igemm_candidates(cout, kind, cred=0, math_name=None):
     # some of the 3x3 and wide 1x1 layers in isolation, slower on others, no gain over a step); the bf16 kernels have one
     bks = {"f32": (1, 2), "bf16x3": (1,), "bf16": (0,), "f16x2": tuple(b for b in _H2_SCHEDULES if b != 3)}[math_name]
     cands = [_variant(bk, tm, tn, math) for tm, tn in tiles for bk in bks]
-    if math_name == "f16x2" and 3 in _H2_SCHEDULES and cred % 32 == 0 and cred > 0:
+    if math_name in ("f16x2", "bf16") and 3 in _H2_SCHEDULES and cred % 32 == 0 and cred > 0:
         if cout >= 96:
             cands.append(_variant(3, 0, 0, math))   # 128 x 128, two workgroups per CU
         if cout >= 192:

@@ -990,3 +990,17 @@ def test_f16x2_schedules_agree_bitwise(dev, case):
             assert torch.equal(dx1, dx2)
         else:
             close(dx2, dx1, atol=1e-5, what="dx (split-K)")
+
+
+@pytest.mark.parametrize("case", [(2, 256, 32, 40, 256, 3, 1, 2, 2), (2, 64, 40, 44, 256, 1, 1, 0, 1), (2, 128, 40, 44, 128, 3, 1, 1, 1)], ids=str)  # > 2048 pixels: no split-K
+def test_bf16_schedules_agree_bitwise(dev, case):
+    """The reduced-precision bf16 arithmetic on the LDS-DMA schedule (variant bk = 3, both tiles) against the wave-specialised
+    kernel it normally runs on: bit-identical outputs (same rounding of the operands, same accumulation order)."""
+    ops = _ops()
+    n, cin, h, w, cout, k, stride, pad, dil = case
+    x = rnd(n, cin, h, w, seed=87)
+    wt = rnd(cout, cin, k, k, seed=88, scale=1.0 / np.sqrt(cin * k * k))
+    y0, _ = _abi_conv(dev, x, wt, stride, pad, dil, ops._variant(0, 0, 0, 3))
+    for tn in (0, 3):
+        y3, _ = _abi_conv(dev, x, wt, stride, pad, dil, ops._variant(3, 0, tn, 3))
+        assert torch.equal(y0, y3)
