@@ -64,11 +64,14 @@ int hn_version(void);
  *      cm/discriminator_model.py:40-44.  Implicit GEMM on v_mfma_f32_32x32x2_f32. ------------------------- */
 
 /* `variant` selects the kernel: 0 = built-in heuristics, else bk + 4*tm + 16*tn + 64*math with tm/tn 1/2 = 64/128-row/
- * -column block tile, math 1/2/3 = fp32 MFMA / bf16x3 / bf16 (see hn_set_conv_math) and bk = the schedule: fp32 MFMA
- * 1/2 = K step 32/16 (2 or 3 resident workgroups per CU); bf16x3 1 = two workgroups per CU with barrier-separated
- * staging and MFMA phases, 2 = one wave per SIMD, software-pipelined (csrc/conv_igemm2.hip; the bf16 arithmetic always
- * runs on this one).  0 = heuristic / library default for that field.  Within one math mode results are bitwise
- * identical across variants; callers may time them per shape (heatnet-pub_amd/ops.py does).
+ * -column block tile, math 1/2/3 = fp32 MFMA / bf16x3 / bf16 (see hn_set_conv_math; 4 = f16x2 is set by the *_scaled
+ * entry points) and bk = the schedule: fp32 MFMA 1/2 = K step 32/16 (2 or 3 resident workgroups per CU); the plane
+ * arithmetics: 0/1 = two workgroups per CU with barrier-separated staging and MFMA phases (csrc/conv_igemm.hip; bf16: as 2),
+ * 2 = producer / consumer waves (csrc/conv_igemm2.hip; the home of the bf16 arithmetic), 3 = weight planes by LDS-DMA
+ * (csrc/conv_igemm3.hip: a 128 x 128 tile with two workgroups per CU, or with tn = 3 the eight-wave 128 x 256 tile;
+ * bf16x3: the latter only); a schedule that does not cover a launch runs the default one.  0 = heuristic / library default
+ * for that field.  Within one math mode results are bitwise identical across variants; callers may time them per shape
+ * (heatnet-pub_amd/ops.py does).
  *
  * y = act(conv(x, w) + bias).  `bias` may be NULL.  If `stats` is non-NULL it must hold
  * HN_STAT_REPLICAS*2*Cout DOUBLES, zero on entry; the kernel adds per-channel sum and sum of squares of the PRE-activation output
@@ -159,11 +162,11 @@ int hn_weight_prepare_batch(const void* table_dev, int n, int total_blocks, int 
  * lands in [2^14, 2^15), below fp16's range limit); t * s_t is split into hi = fp16(t * s_t) and lo = fp16(t * s_t - hi) --
  * 22 significant bits for every element within 2^-18 of the tensor's maximum, fewer (gracefully) below that -- and the
  * three products lo*hi, hi*lo, hi*hi are accumulated in fp32 on v_mfma_f32_16x16x32_f16; the result is multiplied by
- * 1 / (s_a * s_b) on the way out (all scalings are exact).  Error against fp64: within 1.0-1.2x of the fp32 MFMA's for
- * reductions of >= 512 terms (the products' 2^-23 representation error is below the fp32 accumulation error there) at
- * half the matrix-core work of bf16x3; short reductions are better served by bf16x3 (tests/test_gpu_kernels.py,
+ * 1 / (s_a * s_b) on the way out (all scalings are exact).  Error against fp64: 0.6-1.05x the fp32 MFMA's for reductions
+ * of 64 ... 2304 terms (the products' 2^-23 representation error is below the fp32 accumulation error, and three
+ * accumulation steps per 32 k round less than sixteen) at half the matrix-core work of bf16x3 (tests/test_gpu_kernels.py,
  * profiles/r02_f16x2_accuracy.txt).  Heavy-tailed tensors (max / typical magnitude > 2^18) lose bits on their small
- * elements: the caller chooses per layer.
+ * elements -- bf16x3 has no such range: the caller chooses per layer.
  *
  * Scale slots: HN_SCALE_SLOT_FLOATS floats (8 KB) per tensor, of which every HN_SCALE_STRIDE-th word is used: 64 words on 64
  * different 128-B lines, each the bit pattern of the largest |t| seen by some of the producing blocks (as an unsigned
