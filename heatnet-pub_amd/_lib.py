@@ -39,11 +39,11 @@ SIGNATURES = {
     "hn_channel_stats": [P, c_int, c_i64, c_int, P, P],
     "hn_bn_finalize": [P, c_i64, P, P, P, P, c_float, c_float, P, P, P, P, c_int, P],
     "hn_bn_eval_params": [P, P, P, P, c_float, P, P, P, P, c_int, P],
-    "hn_bn_act_fwd": [P, c_int, P, P, P, c_int, P, c_int, c_i64, c_int, c_int, P, c_float, P, c_i64, P, P],
+    "hn_bn_act_fwd": [P, c_int, P, P, P, c_int, P, c_int, c_i64, c_int, c_int, P, c_float, P, c_i64, P, P, P],
     "hn_bn_act_bwd_reduce": [P, c_int, P, c_int, P, c_int, P, P, P, P, c_i64, c_int, c_int, P, c_float, P, P, P, P, P,
-                             c_int, P, c_i64, P],
+                             c_int, P, c_i64, P, P],
     "hn_bn_act_bwd_apply": [P, c_int, P, c_int, P, c_int, P, P, P, P, P, P, c_i64, c_int, P, c_int, P, c_int,
-                            c_i64, c_int, c_int, P, c_float, P, c_i64, P, P],
+                            c_i64, c_int, c_int, P, c_float, P, c_i64, P, P, P],
     "hn_act_bwd": [P, c_int, P, c_int, P, c_int, c_i64, c_int, c_int, c_float, P],
     "hn_scale_nc": [P, c_int, P, P, c_int, c_int, c_i64, c_int, P],
     "hn_add": [P, c_int, P, c_int, P, c_int, c_i64, c_int, P],

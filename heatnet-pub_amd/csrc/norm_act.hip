@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                         const float* __restrict__ res, int ldr, float* __restrict__ z,
                                                         int ldz, int64_t npix, int C, int act, const float* slope_p,
                                                         float leaky, const float* __restrict__ mask, int64_t hw,
-                                                        float* __restrict__ z_scale) {
+                                                        float* __restrict__ z_scale, unsigned char* __restrict__ rbits) {
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     unsigned amax = 0u;  // largest |z| written by this thread (f16x2 scale of the output, optional)
     if (c < C) {
@@ -106,6 +106,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                 amax = max(amax, __float_as_uint(o[i]) & 0x7fffffffu);
             }
             stv<V>(z + pix * ldz + c, o);
+            if constexpr (V == 4) {
+                // one byte per 16-B piece: bit i = (z[c + i] > 0), what the backward passes need of z (a 16th of its bytes)
+                if (rbits != nullptr)
+                    rbits[pix * (C / 4) + c / 4] = (unsigned char)((o[0] > 0.f) | ((o[1] > 0.f) << 1) | ((o[2] > 0.f) << 2) | ((o[3] > 0.f) << 3));
+            }
         }
     }
     if (z_scale != nullptr) hn_absmax_publish(amax, z_scale);
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                int64_t npix, int C, int act, const float* slope_p, float leaky,
                                                                double* __restrict__ sums, const float* __restrict__ mask,
-                                                               int64_t hw) {
+                                                               int64_t hw, const unsigned char* __restrict__ rbits) {
     __shared__ double red[2 * 256 * 4 + 256];
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     const bool live = c < C;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
         const int64_t first = (int64_t)blockIdx.y * blockDim.y + threadIdx.y, step = (int64_t)gridDim.y * blockDim.y;
         const float* pg = dz + first * lddz + c;
         const float* py = y + first * ldy + c;
-        const float* pz = ZMASK ? z + first * ldz + c : nullptr;
+        const float* pz = (ZMASK && z != nullptr) ? z + first * ldz + c : nullptr;
         const int64_t sg = step * lddz, sy = step * ldy, sz = step * ldz;
 #pragma unroll 4
         for (int64_t pix = first; pix < npix; pix += step) {
@@ -151,8 +156,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
             ldv<V>(pg, g);
             ldv<V>(py, yy);
             if constexpr (ZMASK) {
-                ldv<V>(pz, zz);
-                pz += sz;
+                if (V == 4 && rbits != nullptr) {  // the ReLU mask as one byte per 16-B piece instead of z itself
+                    const unsigned b = rbits[pix * (C / 4) + c / 4];
+#pragma unroll
+                    for (int i = 0; i < V; ++i) zz[i] = (b >> i) & 1u ? 1.f : 0.f;
+                } else {
+                    ldv<V>(pz, zz);
+                    pz += sz;
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < V; ++i) zz[i] = 0.f;
@@ -241,7 +252,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
                                                               float inv_count, int training, float* __restrict__ dy, int lddy,
                                                               float* __restrict__ dres, int lddr, int64_t npix, int C, int act,
                                                               const float* slope_p, float leaky, const float* __restrict__ mask,
-                                                              int64_t hw, float* __restrict__ dy_scale) {
+                                                              int64_t hw, float* __restrict__ dy_scale,
+                                                              const unsigned char* __restrict__ rbits) {
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     unsigned amax = 0u;  // largest |dy| written by this thread (f16x2 scale of the output, optional)
     if (c < C) {
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
         ga[i] *= is[i];
     }
     const float slope = act == HN_ACT_PRELU ? *slope_p : leaky;
-    const bool zmask = act == HN_ACT_RELU && z != nullptr;
+    const bool zmask = act == HN_ACT_RELU && (z != nullptr || (V == 4 && rbits != nullptr));
     float unused = 0.f;
 #pragma unroll 2
     for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
@@ -271,8 +283,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
 #pragma unroll
             for (int i = 0; i < V; ++i) g[i] *= m[i];
         }
-        if (zmask) ldv<V>(z + pix * ldz + c, zz);
-        else {
+        if (zmask) {
+            if (V == 4 && rbits != nullptr) {
+                const unsigned b = rbits[pix * (C / 4) + c / 4];
+#pragma unroll
+                for (int i = 0; i < V; ++i) zz[i] = (b >> i) & 1u ? 1.f : 0.f;
+            } else {
+                ldv<V>(z + pix * ldz + c, zz);
+            }
+        } else {
 #pragma unroll
             for (int i = 0; i < V; ++i) zz[i] = 0.f;
         }
@@ -489,14 +508,16 @@ extern "C" int hn_bn_eval_params(const float* gamma, const float* beta, const fl
 
 extern "C" int hn_bn_act_fwd(const float* y, int ldy, const float* scale, const float* shift, const float* residual,
                              int ldr, float* z, int ldz, int64_t npix, int C, int act, const float* slope,
-                             float leaky_slope, const float* mask, int64_t hw, float* z_scale, void* stream) {
+                             float leaky_slope, const float* mask, int64_t hw, float* z_scale, unsigned char* relu_bits,
+                             void* stream) {
     if (!y || !scale || !shift || !z || act < 0 || act > 3 || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
     if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
     if (bad_rows(npix, C, {ldy, ldz}) || (residual && ldr < C)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const RowLaunch pl = plan_rows(npix, C, {y, z, residual, scale, shift, mask}, {ldy, ldz, residual ? ldr : 4});
+    if (relu_bits != nullptr && pl.V != 4) return HN_EALIGN;  // the byte mask exists for whole 16-B pieces only
     HN_LAUNCH_V(pl, bn_act_fwd_kernel, y, ldy, scale, shift, residual, ldr, z, ldz, npix, C, act, slope, leaky_slope, mask,
-                hw, z_scale);
+                hw, z_scale, relu_bits);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -505,15 +526,18 @@ extern "C" int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, i
                                     const float* mean, const float* invstd, const float* scale, const float* shift,
                                     int64_t npix, int C, int act, const float* slope, float leaky_slope, double* sums,
                                     float* dparams, float* dgamma_out, float* dbeta_out, float* dslope_out,
-                                    int out_accumulate, const float* mask, int64_t hw, void* stream) {
+                                    int out_accumulate, const float* mask, int64_t hw, const unsigned char* relu_bits,
+                                    void* stream) {
     if (!dz || !y || !mean || !invstd || !scale || !shift || !sums || !dparams || act < 0 || act > 3) return HN_EINVAL;
     if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
     if (act == HN_ACT_PRELU && !slope) return HN_EINVAL;
     if (bad_rows(npix, C, {lddz, ldy}) || (z && ldz < C)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool zmask = act == HN_ACT_RELU && z != nullptr;
-    RowLaunch pl = plan_rows(npix, C, {dz, y, zmask ? z : nullptr, mean, invstd, scale, shift},
-                             {lddz, ldy, zmask ? ldz : 4}, 2048);
+    const bool zmask = act == HN_ACT_RELU && (z != nullptr || relu_bits != nullptr);
+    const bool zread = zmask && relu_bits == nullptr;  // z itself is read only when there is no byte mask
+    RowLaunch pl = plan_rows(npix, C, {dz, y, zread ? z : nullptr, mean, invstd, scale, shift},
+                             {lddz, ldy, zread ? ldz : 4}, 2048);
+    if (relu_bits != nullptr && pl.V != 4) return HN_EALIGN;
     {
         // every block ends with 2C double atomics: give each thread at least MINPIX pixels so that small tensors are not
         // dominated by them (a [8x40x88, 256] tensor went from 2048 blocks / 1 M atomics to 440 / 225 k)
@@ -528,10 +552,10 @@ extern "C" int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, i
     do {                                                                                                                \
         if (pl.V == 4)                                                                                                  \
             HN_LAUNCH((bn_act_bwd_reduce_kernel<4, ZM, MK>), pl.grid, pl.block, 0, s, dz, lddz, z, ldz, y, ldy, mean, invstd, \
-                      scale, shift, npix, C, act, slope, leaky_slope, sums, mask, hw);                                  \
+                      scale, shift, npix, C, act, slope, leaky_slope, sums, mask, hw, relu_bits);                       \
         else                                                                                                            \
             HN_LAUNCH((bn_act_bwd_reduce_kernel<1, ZM, MK>), pl.grid, pl.block, 0, s, dz, lddz, z, ldz, y, ldy, mean, invstd, \
-                      scale, shift, npix, C, act, slope, leaky_slope, sums, mask, hw);                                  \
+                      scale, shift, npix, C, act, slope, leaky_slope, sums, mask, hw, relu_bits);                       \
     } while (0)
     if (zmask) {
         if (mask != nullptr) HN_LAUNCH_REDUCE(true, true);
@@ -552,19 +576,21 @@ extern "C" int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, in
                                    const float* mean, const float* invstd, const float* gamma, const float* scale,
                                    const float* shift, const float* dparams, int64_t count, int training, float* dy,
                                    int lddy, float* dres, int lddr, int64_t npix, int C, int act, const float* slope,
-                                   float leaky_slope, const float* mask, int64_t hw, float* dy_scale, void* stream) {
+                                   float leaky_slope, const float* mask, int64_t hw, float* dy_scale,
+                                   const unsigned char* relu_bits, void* stream) {
     if (!dz || !y || !mean || !invstd || !gamma || !scale || !shift || !dy || act < 0 || act > 3) return HN_EINVAL;
     if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
     if ((training && (!dparams || count <= 0)) || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
     if (bad_rows(npix, C, {lddz, ldy, lddy}) || (dres && lddr < C) || (z && ldz < C)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool zmask = act == HN_ACT_RELU && z != nullptr;
+    const bool zmask = act == HN_ACT_RELU && z != nullptr && relu_bits == nullptr;  // (z itself is read)
     const RowLaunch pl =
         plan_rows(npix, C, {dz, y, dy, dres, zmask ? z : nullptr, mean, invstd, gamma, scale, shift},
                   {lddz, ldy, lddy, dres ? lddr : 4, zmask ? ldz : 4});
+    if (relu_bits != nullptr && pl.V != 4) return HN_EALIGN;
     const float inv_count = training ? (float)(1.0 / (double)count) : 0.f;
     HN_LAUNCH_V(pl, bn_act_bwd_apply_kernel, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, dparams, inv_count,
-                training, dy, lddy, dres, lddr, npix, C, act, slope, leaky_slope, mask, hw, dy_scale);
+                training, dy, lddy, dres, lddr, npix, C, act, slope, leaky_slope, mask, hw, dy_scale, relu_bits);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

@@ -831,6 +831,9 @@ def conv2d(x, w, b=None, stride=1, pad=0, dil=1, act=ACT_NONE, slope=0.0, want_s
 # batch norm (+ residual) (+ activation)
 # ------------------------------------------------------------------------------------------------------
 
+RELU_BITS = os.environ.get("HEATNET_RELU_BITS", "1") != "0"  # A/B knob: byte ReLU masks for the residual BatchNorm layers
+
+
 class _BnAct(torch.autograd.Function):
     """z = act(bn(y) + residual).  Training mode takes the batch statistics produced by the conv epilogue
     (or computes them when `stats` is None) and updates the running buffers in place, as nn.BatchNorm2d does."""
@@ -869,20 +872,26 @@ class _BnAct(torch.autograd.Function):
         z = new_nhwc(n, c, h, w, dev)
         if drop_mask is not None:
             drop_mask = drop_mask.contiguous()
+        # ReLU behind a residual add: the backward passes need the sign of z only -- one byte per four channels instead of z
+        rbits = None
+        if (act == ACT_RELU and residual is not None and c % 4 == 0 and ldy % 4 == 0 and ldr % 4 == 0 and RELU_BITS and
+                any(ctx.needs_input_grad) and y.data_ptr() % 16 == 0 and residual.data_ptr() % 16 == 0):
+            rbits = torch.empty(npix * (c // 4), device=dev, dtype=torch.uint8)
         check(lib.hn_bn_act_fwd(_ptr(y), ldy, _ptr(scale), _ptr(shift), _ptr(residual), ldr, _ptr(z), c, npix, c, act,
-                                _ptr(prelu_w), leaky, _ptr(drop_mask), h * w, _ptr(z_scale), s), "hn_bn_act_fwd")
+                                _ptr(prelu_w), leaky, _ptr(drop_mask), h * w, _ptr(z_scale), _ptr(rbits), s), "hn_bn_act_fwd")
         ctx.drop_mask = drop_mask
         ctx.leaves = (_leaf(gamma), _leaf(beta), _leaf(prelu_w))
         ctx.cfg = (training, act, leaky, residual is not None)
         ctx.ws = ws
         # the ReLU mask is recomputed from y in backward unless a residual entered u (then z is kept)
-        ctx.save_for_backward(y, z if (act == ACT_RELU and residual is not None) else None, par, gamma, prelu_w)
+        ctx.save_for_backward(y, z if (act == ACT_RELU and residual is not None and rbits is None) else None, par, gamma,
+                              prelu_w, rbits)
         return z
 
     @staticmethod
     def backward(ctx, dz):
         lib = _lib.load()
-        y, z, par, gamma, prelu_w = ctx.saved_tensors
+        y, z, par, gamma, prelu_w, rbits = ctx.saved_tensors
         training, act, leaky, has_res = ctx.cfg
         y, ldy = as_nhwc(y)
         dz, lddz = as_nhwc(dz)
@@ -910,7 +919,7 @@ class _BnAct(torch.autograd.Function):
         check(lib.hn_bn_act_bwd_reduce(_ptr(dz), lddz, _ptr(z), ldz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(scale),
                                        _ptr(shift), npix, c, act, _ptr(prelu_w), leaky, _ptr(sums), _ptr(dpar),
                                        _ptr(sg[0]) if sg else None, _ptr(sb[0]) if sb else None,
-                                       _ptr(sp[0]) if sp else None, int(accumulate), _ptr(ctx.drop_mask), h * w, s),
+                                       _ptr(sp[0]) if sp else None, int(accumulate), _ptr(ctx.drop_mask), h * w, _ptr(rbits), s),
               "hn_bn_act_bwd_reduce")
         if ws is not None:
             ws.bwd_open = False  # hn_bn_act_bwd_reduce consumed and re-zeroed its accumulator
@@ -924,7 +933,7 @@ class _BnAct(torch.autograd.Function):
             check(lib.hn_bn_act_bwd_apply(_ptr(dz), lddz, _ptr(z), ldz, _ptr(y), ldy, _ptr(mean), _ptr(invstd),
                                           _ptr(gamma), _ptr(scale), _ptr(shift), _ptr(dpar), npix, int(training),
                                           _ptr(dy), c, _ptr(dres), c, npix, c, act, _ptr(prelu_w), leaky,
-                                          _ptr(ctx.drop_mask), h * w, _ptr(dy_scale), s), "hn_bn_act_bwd_apply")
+                                          _ptr(ctx.drop_mask), h * w, _ptr(dy_scale), _ptr(rbits), s), "hn_bn_act_bwd_apply")
             if dy_scale is not None:
                 dy._hn_scale = (dy._version, dy_scale)  # rides with the tensor to the producing convolution's backward
         def out(slot, fallback, needed):  # first use: the slot view; later use: nothing (added in place); no slot: dpar

@@ -246,24 +246,28 @@ int hn_bn_eval_params(const float* gamma, const float* beta, const float* runnin
  * HN_ACT_PRELU, ignored otherwise (HN_ACT_LEAKY uses leaky_slope).  `mask` (optional, with hw = pixels per image) is a
  * Dropout2d keep/(1-p) factor per (image, channel), cm/models/pspnet.py:55,66-72, applied in the same pass; the two
  * backward entry points take the same mask and fold it into dz.  `z_scale` (optional): a scale slot as hn_absmax_scale
- * takes; the pass then also publishes the f16x2 scale of z, so the convolution that consumes z needs no pass of its own. */
+ * takes; the pass then also publishes the f16x2 scale of z, so the convolution that consumes z needs no pass of its own.
+ * `relu_bits` (optional; C % 4 == 0 and 16-B aligned rows, else HN_EALIGN): npix * C/4 bytes, one per 16-B piece of z, bit i =
+ * (z[c + i] > 0) -- all the two backward passes need of z when the ReLU followed a residual add: they then read 1/16 of
+ * the bytes. */
 int hn_bn_act_fwd(const float* y, int ldy, const float* scale, const float* shift,
                   const float* residual, int ldr, float* z, int ldz, int64_t npix, int C,
                   int act, const float* slope, float leaky_slope, const float* mask, int64_t hw, float* z_scale,
-                  void* stream);
+                  unsigned char* relu_bits, void* stream);
 
 /* First backward pass.  du = dz * act'(u), u = y*scale+shift(+residual).  Accumulates into the double workspace
  * sums[HN_STAT_REPLICAS][2C+1] (must be all zero on entry; it is zero again on return) and writes
  * dparams = {dbeta [C], dgamma [C], dslope [1]} = {sum du, sum du*xhat, ...} in fp32 (xhat = (y-mean)*invstd).
- * HN_ACT_RELU takes its mask from z > 0, or -- when z is NULL (allowed only if the forward had no residual) -- from
- * u recomputed from y; PRELU/LEAKY always recompute u from y (residual must have been NULL).
+ * HN_ACT_RELU takes its mask from `relu_bits` (the forward's byte mask, see hn_bn_act_fwd) if given, else from z > 0, or
+ * -- when both are NULL (allowed only if the forward had no residual) -- from u recomputed from y; PRELU/LEAKY always
+ * recompute u from y (residual must have been NULL).
  * dgamma_out / dbeta_out / dslope_out (each optional): the same three results written where the caller keeps the
  * parameters' gradients (added to what is there when out_accumulate != 0), so that no copy or accumulation pass follows. */
 int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                          const float* mean, const float* invstd, const float* scale, const float* shift,
                          int64_t npix, int C, int act, const float* slope, float leaky_slope,
                          double* sums, float* dparams, float* dgamma_out, float* dbeta_out, float* dslope_out,
-                         int out_accumulate, const float* mask, int64_t hw, void* stream);
+                         int out_accumulate, const float* mask, int64_t hw, const unsigned char* relu_bits, void* stream);
 
 /* Second backward pass: dy = gamma*invstd*(du - dbeta/count - xhat*dgamma/count) when `training`,
  * dy = gamma*invstd*du otherwise; dres = du when dres != NULL (gradient of the residual input).
@@ -274,7 +278,7 @@ int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, cons
                         const float* shift, const float* dparams, int64_t count, int training,
                         float* dy, int lddy, float* dres, int lddr, int64_t npix, int C,
                         int act, const float* slope, float leaky_slope, const float* mask, int64_t hw, float* dy_scale,
-                        void* stream);
+                        const unsigned char* relu_bits, void* stream);
 
 /* dx = dy * act'(y_out) for an activation applied in a conv epilogue (LeakyReLU / ReLU: the sign of the
  * output equals the sign of the pre-activation).  In place allowed (dx == dy). */

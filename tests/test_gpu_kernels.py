@@ -469,8 +469,8 @@ def test_c_abi_rejects_bad_arguments(dev):
     assert lib.hn_conv2d_fwd(P(x), P(w), None, None, P(y), None, ctypes.byref(bad_shape), 0, 0.0, 0, s) == -4  # HN_ESHAPE
     bad_ld = _lib.HnConvDesc(1, 8, 8, 64, 32, 8, 8, 64, 64, 1, 1, 1, 0, 1)                              # ldx < Cin
     assert lib.hn_conv2d_fwd(P(x), P(w), None, None, P(y), None, ctypes.byref(bad_ld), 0, 0.0, 0, s) == -1
-    assert lib.hn_bn_act_fwd(P(x), 64, None, None, None, 0, P(y), 64, 64, 64, 1, None, 0.0, None, 0, None, s) == -1
-    assert lib.hn_bn_act_fwd(P(x), 64, P(w), P(w), None, 0, P(y), 64, 64, 64, 1, None, 0.0, P(w), 48, None, s) == -1  # hw !| npix
+    assert lib.hn_bn_act_fwd(P(x), 64, None, None, None, 0, P(y), 64, 64, 64, 1, None, 0.0, None, 0, None, None, s) == -1
+    assert lib.hn_bn_act_fwd(P(x), 64, P(w), P(w), None, 0, P(y), 64, 64, 64, 1, None, 0.0, P(w), 48, None, None, s) == -1  # hw !| npix
     assert lib.hn_pyramid_pool_bwd(9, None, None, None, None, P(y), 64, 1, 8, 8, 64, s) == -1            # > 8 levels
     assert lib.hn_ce_fwd(P(x), 64, P(y), 64, 64, -100, P(y), s) == -1                                   # C > 32 classes
     with pytest.raises(RuntimeError, match="invalid argument"):
@@ -1004,3 +1004,33 @@ def test_bf16_schedules_agree_bitwise(dev, case):
     for tn in (0, 3):
         y3, _ = _abi_conv(dev, x, wt, stride, pad, dil, ops._variant(3, 0, tn, 3))
         assert torch.equal(y0, y3)
+
+
+@pytest.mark.parametrize("c", [64, 6])
+def test_bn_relu_byte_mask_equals_reading_z(dev, c):
+    """Residual + ReLU layers: the backward passes take the ReLU mask from one byte per four channels written by the forward
+    pass (a 16th of z's bytes); gradients must be bitwise those of the path that reads z (C % 4 != 0 always reads z)."""
+    ops = _ops()
+    n, h, w = 2, 12, 16
+    y, res = rnd(n, c, h, w, seed=95, scale=2.0), rnd(n, c, h, w, seed=96)
+    gamma, beta = rnd(c, seed=97).abs() + 0.5, rnd(c, seed=98) * 0.1
+    gz = rnd(n, c, h, w, seed=99)
+    outs = []
+    prev = ops.RELU_BITS
+    try:
+        for bits in (True, False):
+            ops.RELU_BITS = bits
+            cl = torch.channels_last
+            yd = y.to(dev).contiguous(memory_format=cl).requires_grad_()
+            rd = res.to(dev).contiguous(memory_format=cl).requires_grad_()
+            gd, bd = gamma.to(dev).requires_grad_(), beta.to(dev).requires_grad_()
+            z = ops.bn_act(yd, None, gd, bd, torch.zeros(c, device=dev), torch.ones(c, device=dev), residual=rd, training=True,
+                           act=ops.ACT_RELU)
+            saved = [t for t in z.grad_fn.saved_tensors if t is not None and t.dtype == torch.uint8]
+            assert bool(saved) == (bits and c % 4 == 0)
+            z.backward(gz.to(dev))
+            outs.append((z.detach().clone(), yd.grad.clone(), rd.grad.clone(), gd.grad.clone(), bd.grad.clone()))
+    finally:
+        ops.RELU_BITS = prev
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
