@@ -22,6 +22,8 @@
 // 128 x 128 with 62 KB of LDS, i.e. TWO workgroups per CU as in the first schedule, and two A staging sets (fetch distance
 // two steps: the waits count "all but the newest RA loads").  What it removes from the first schedule: the weight planes'
 // trip through VGPRs and ds_write_b128 (13 of the ~25 VGPR->LDS transfer cycles a wave spends per K step).
+#include <cstdlib>
+
 #include "conv_common.h"
 
 namespace hnconv {
@@ -265,7 +267,8 @@ int launch3(const ConvArgs& a, hipStream_t stream) {
     ConvArgs p = a;
     p.ntm = (a.M + T::BM - 1) / T::BM;
     p.ntn = (a.K + T::BN - 1) / T::BN;
-    p.gm = p.ntn >= (WN == 4 ? 4 : 8) ? 8 : 1;
+    static const int gm_env = getenv("HN_GROUP_M") ? atoi(getenv("HN_GROUP_M")) : 0;  // experiment knob
+    p.gm = gm_env > 0 ? gm_env : (p.ntn >= (WN == 4 ? 4 : 8) ? 8 : 1);
     if (p.gm > p.ntm) p.gm = p.ntm;
     HN_LAUNCH((conv_igemm3_kernel<NS, WN, SETS>), dim3(p.ntm * p.ntn), dim3(T::NT), T::LDS, stream, p);
     HN_CHECK_LAUNCH();
