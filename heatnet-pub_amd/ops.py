@@ -1144,6 +1144,9 @@ class _Bilinear(torch.autograd.Function):
 
 
 def bilinear(x, size):
+    if (CONV_MATH == "f16x2" and x.is_cuda and x.dim() == 4 and getattr(x, "_hn_scale", None) is None and
+            int(size[0]) * int(size[1]) > x.shape[2] * x.shape[3] and x.shape[1] % 32 == 0):
+        tensor_scale(*as_nhwc(x), owner=x)  # an upsampling: find the scale on the small tensor, the large one inherits it
     return _inherit_scale(_Bilinear.apply(x, int(size[0]), int(size[1])), x)
 
 
