@@ -67,6 +67,13 @@ SIGNATURES = {
     "hn_weight_flip_transpose_h2": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_conv2d_wgrad_scaled": [P, P, P, P, P, DP, c_int, c_int, c_int, P],
     "hn_conv2d_wgrad_det_scaled": [P, P, P, P, P, DP, c_int, c_int, c_int, P, P],
+    "hn_tensor_to_planes": [P, c_int, c_i64, c_int, P, P, c_i64, c_int, P],
+    "hn_planes_to_tensor": [P, c_i64, c_int, P, P, c_int, c_i64, c_int, P],
+    "hn_conv2d_fwd_planes": [P, c_i64, P, P, P, P, P, P, DP, c_int, c_float, c_int, P],
+    "hn_conv2d_fwd_scaled_range": [P, P, P, P, P, P, P, P, DP, c_int, P],
+    "hn_conv2d_dgrad_planes": [P, c_i64, P, P, P, P, c_int, DP, c_int, P],
+    "hn_conv2d_wgrad_planes": [P, c_i64, P, P, c_i64, P, P, DP, c_int, c_int, c_int, P],
+    "hn_conv2d_wgrad_det_planes": [P, c_i64, P, P, c_i64, P, P, DP, c_int, c_int, c_int, P, P],
     "hn_thermal_augment": [P, P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P, P],
     "hn_thermal_resize": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "hn_set_conv_math": [c_int],

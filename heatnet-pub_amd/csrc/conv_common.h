@@ -48,6 +48,14 @@ struct ConvArgs {
     // (stored behind the two f16 planes, hn_split_f16x2); NULL for the other arithmetics
     const float* a_scale;
     const float* w_scale;
+    // f16x2, fourth schedule (conv_igemm4.hip): the gathered tensor as two fp16 planes (hi, lo) of xh_plane elements each,
+    // pixel stride ldx fp16 elements, made with the scale of a_scale by the pass that produced the tensor; x_bytes is then
+    // the extent of ONE plane.  NULL: the fp32 tensor `x` is split inside the kernel.
+    const unsigned short* xh = nullptr;
+    long long xh_plane = 0;
+    // optional [HN_STAT_REPLICAS][2][K] words next to `stats`: order-preserving keys of the per-channel maximum of y and of
+    // -y over the launch (zero = nothing seen), from which hn_bn_finalize bounds the normalised tensor's magnitude
+    unsigned* minmax = nullptr;
 };
 
 // bf16x3 LDS image: [split][row][32 k] bf16 with 80-byte rows (64 B of data + 16 B pad: 16 consecutive rows start in
@@ -209,6 +217,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                 const int col = am.col(j, c2);
                 const bool cok = FULL || col < p.K;
                 float s1 = 0.f, s2 = 0.f;
+                float vmax = -__builtin_inff(), vmin = __builtin_inff();
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -223,6 +232,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                             } else {
                                 s1 += v;
                                 s2 += v * v;
+                                vmax = fmaxf(vmax, v);
+                                vmin = fminf(vmin, v);
                                 p.y[(size_t)row * p.ldy + col] = v > 0.f ? v : v * neg_slope;
                             }
                         }
@@ -242,6 +253,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                         double* rep = p.stats + (size_t)(tile_m % HN_STAT_REPLICAS) * 2 * p.K;  // spread same-address atomics
                         unsafeAtomicAdd(rep + col, d1);
                         unsafeAtomicAdd(rep + p.K + col, d2);
+                    }
+                    if (p.minmax != nullptr) {  // range of the channel: keys of max(y) and max(-y), see hn_range_key
+                        vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
+                        vmin = fminf(vmin, __shfl_xor(vmin, 32));
+                        if constexpr (S16) {
+                            vmax = fmaxf(vmax, __shfl_xor(vmax, 16));
+                            vmin = fminf(vmin, __shfl_xor(vmin, 16));
+                        }
+                        if ((S16 ? (lane >> 4) : (lane >> 5)) == 0 && cok) {
+                            unsigned* rk = p.minmax + (size_t)(tile_m % HN_STAT_REPLICAS) * 2 * p.K;
+                            atomicMax(rk + col, hn_range_key(vmax));
+                            atomicMax(rk + p.K + col, hn_range_key(-vmin));
+                        }
                     }
                 }
             }
@@ -293,6 +317,10 @@ __device__ __forceinline__ void conv_fill_rowinfo(const ConvArgs& p, int* rowinf
 enum : int { MATH2_X3 = 3, MATH2_BF16 = 1, MATH2_H2 = 2 };  // = number of 16-bit planes per operand (2: fp16, f16x2)
 // runs the v2 schedule if it covers (tall, wide, ns); returns HN_OK / error, or 1 when it does not cover the request
 int launch_conv2(const ConvArgs& a, bool tall, bool wide, int ns, hipStream_t stream);
+// conv_igemm4.hip: f16x2 with both operands as fp16 planes, everything by LDS-DMA
+bool conv4_covers(const ConvArgs& a);
+int launch_conv4(const ConvArgs& a, int tile, hipStream_t stream);
+const char* conv4_kernel_name(int tile);
 // conv_igemm3.hip: bf16x3, 128 x 256 tile, weight operand by LDS-DMA
 bool conv3_covers(const ConvArgs& a, int planes, bool wide);
 int launch_conv3(const ConvArgs& a, int planes, bool wide, hipStream_t stream);

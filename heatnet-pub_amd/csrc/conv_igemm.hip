@@ -503,7 +503,7 @@ bool g_deterministic = false;  // hn_set_deterministic: no split-K float atomics
 int g_conv_math = 0;  // HN_MATH_* default for variant codes that leave the math field 0 (hn_set_conv_math)
 
 // What a launch will run: the kernel family, its tile and arithmetic.
-enum : int { FAM_V1 = 0, FAM_V2 = 1, FAM_V3 = 2 };
+enum : int { FAM_V1 = 0, FAM_V2 = 1, FAM_V3 = 2, FAM_V4 = 3 };
 struct ConvPlan {
     int family;      // FAM_V1: conv_igemm_kernel (this file); FAM_V2: conv_igemm2_kernel (conv_igemm2.hip); FAM_V3: conv_igemm3_kernel
     bool tall, wide;
@@ -546,6 +546,15 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
     pl.wide = wide;
     pl.wn = 2;
     pl.bk = 32;
+    if (a.xh != nullptr) {
+        // the gathered operand arrives as fp16 planes: only the all-DMA schedule (conv_igemm4.hip) reads that format.
+        // bk_sel = its tile (0: 128 x 128, or 128 x 64 when there are at most 64 output channels; 1: 128 x 64; 2: 128 x 256;
+        // 3: 256 x 128)
+        if (math != HN_MATH_F16X2 || !conv4_covers(a)) return HN_ESHAPE;
+        pl.family = FAM_V4; pl.math = MATH_H2; pl.mode = MODE_VEC_BUF;
+        pl.wn = bk_sel == 0 ? (a.K <= 64 ? 1 : 0) : bk_sel;
+        return HN_OK;
+    }
     if (math == HN_MATH_F16X2) {
         // the caller chose the operand format (fp16 planes + scales): there is no other kernel to fall back to
         if (!planes_ok || a.a_scale == nullptr) return HN_ESHAPE;
@@ -583,6 +592,7 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
 }
 
 int run_conv(const ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
+    if (pl.family == FAM_V4) return launch_conv4(a, pl.wn, stream);
     if (pl.family == FAM_V3) {
         const int planes = pl.math == MATH_H2 ? 2 : (pl.math == MATH3_BF16 ? 1 : 3);
         return launch_conv3(a, planes, pl.wn == 4 || planes == 3, stream);
@@ -614,7 +624,8 @@ int dispatch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
 // the kernel's name as rocprofv3 prints it (tools/pmc_aggregate.py keys), for per-instantiation accounting
 void plan_name(const ConvPlan& pl, char* buf, int n) {
     const int tm = pl.tall ? 2 : 1, tn = pl.wide ? 2 : 1;
-    if (pl.family == FAM_V3) {
+    if (pl.family == FAM_V4) snprintf(buf, n, "%s", conv4_kernel_name(pl.wn));
+    else if (pl.family == FAM_V3) {
         const int planes = pl.math == MATH_H2 ? 2 : (pl.math == MATH3_BF16 ? 1 : 3);
         const bool small = planes != 3 && pl.wn != 4;  // the 128 x 128 four-wave tile with two A staging sets
         snprintf(buf, n, "conv_igemm3_kernel<%d, %d, %d>", planes, small ? 2 : 4, small ? 2 : 1);
@@ -981,6 +992,10 @@ extern "C" int hn_conv2d_plan(int kind, const HnConvDesc* d, int has_planes, int
     const float* al = reinterpret_cast<const float*>(uintptr_t(256));
     ConvArgs a = fwd_args(al, al, has_planes ? al : nullptr, nullptr, const_cast<float*>(al), nullptr, d, HN_ACT_NONE, 0.f);
     if (variant >= VARIANT_F16X2) a.a_scale = a.w_scale = al;
+    if (has_planes & 2) {  // the gathered operand as fp16 planes too (hn_conv2d_fwd_planes / hn_conv2d_dgrad_planes)
+        a.xh = reinterpret_cast<const unsigned short*>(al);
+        a.xh_plane = 1ll << 20;
+    }
     bool can_split = d->ldy == d->Cout;
     if (kind == 1) {  // data gradient: the gathered tensor is dY, the produced one dX (first parity class when strided)
         const bool classes = parity_decomposable(d->KH, d->KW, d->stride, d->dil);
@@ -992,7 +1007,7 @@ extern "C" int hn_conv2d_plan(int kind, const HnConvDesc* d, int has_planes, int
         a.x_bytes = (((long long)d->N * d->Hout * d->Wout - 1) * d->ldy + d->Cout) * 4;
         can_split = d->ldx == d->Cin && (d->stride == 1 || classes);
     }
-    a.cps = (can_split && !g_deterministic) ? plan_split_k(a.M, a.K, a.Kdim) : 0;
+    a.cps = (can_split && !g_deterministic && !(has_planes & 2)) ? plan_split_k(a.M, a.K, a.Kdim) : 0;
     ConvPlan pl;
     const int rp = plan_conv(a, a.cps > 0 ? (variant & ~3) : variant, pl);
     if (rp != HN_OK) return rp;
@@ -1002,8 +1017,9 @@ extern "C" int hn_conv2d_plan(int kind, const HnConvDesc* d, int has_planes, int
 
 namespace {
 int conv2d_fwd_impl(const float* x, const float* x_scale, const float* w, const void* w_x3, const float* bias, float* y,
-                    double* stats, const HnConvDesc* d, int act, float slope, int variant, void* stream) {
-    if (x == nullptr || w == nullptr || y == nullptr) return HN_EINVAL;
+                    double* stats, const HnConvDesc* d, int act, float slope, int variant, void* stream,
+                    const void* xh = nullptr, long long xh_plane = 0, unsigned* minmax = nullptr) {
+    if ((x == nullptr && xh == nullptr) || (w == nullptr && xh == nullptr) || y == nullptr) return HN_EINVAL;
     if (act < HN_ACT_NONE || act > HN_ACT_LEAKY) return HN_EINVAL;
     const int rc = check_desc(d);
     if (rc != HN_OK) return rc;
@@ -1017,7 +1033,17 @@ int conv2d_fwd_impl(const float* x, const float* x_scale, const float* w, const 
         return HN_EINVAL;  // f16x2 needs the operand scales: hn_conv2d_fwd_scaled
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    a.minmax = minmax;
+    if (minmax != nullptr && (stats == nullptr || act != HN_ACT_NONE)) return HN_EINVAL;
+    if (xh != nullptr) {  // plane tensor: the all-DMA kernels only (no split-K on that path)
+        if (x_scale == nullptr || xh_plane <= 0) return HN_EINVAL;
+        a.xh = static_cast<const unsigned short*>(xh);
+        a.xh_plane = xh_plane;
+        a.x_bytes = (((long long)d->N * d->Hin * d->Win - 1) * d->ldx + d->Cin) * 2;
+        return dispatch_conv(a, variant, s);
+    }
     a.cps = (d->ldy == d->Cout && !g_deterministic) ? plan_split_k(a.M, a.K, a.Kdim) : 0;
+    if (a.cps > 0 && minmax != nullptr) a.cps = 0;  // (the range keys come from the kernel epilogue)
     if (a.cps == 0) return dispatch_conv(a, variant, s);
     // split-K: zero y, accumulate partial products, then bias / activation and (for BatchNorm) the statistics
     if (hipMemsetAsync(y, 0, (size_t)a.M * a.K * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
@@ -1049,6 +1075,21 @@ extern "C" int hn_conv2d_fwd_scaled(const float* x, const float* x_scale, const 
     return conv2d_fwd_impl(x, x_scale, w, w_h2, bias, y, stats, d, act, slope, variant, stream);
 }
 
+extern "C" int hn_conv2d_fwd_planes(const void* x_planes, int64_t plane_elems, const float* x_scale, const void* w_h2,
+                                    const float* bias, float* y, double* stats, uint32_t* range_keys, const HnConvDesc* d,
+                                    int act, float slope, int variant, void* stream) {
+    if (x_planes == nullptr || x_scale == nullptr || w_h2 == nullptr) return HN_EINVAL;
+    return conv2d_fwd_impl(nullptr, x_scale, nullptr, w_h2, bias, y, stats, d, act, slope, variant, stream, x_planes, plane_elems,
+                           range_keys);
+}
+
+extern "C" int hn_conv2d_fwd_scaled_range(const float* x, const float* x_scale, const float* w, const void* w_h2,
+                                          const float* bias, float* y, double* stats, uint32_t* range_keys, const HnConvDesc* d,
+                                          int variant, void* stream) {
+    if (x_scale == nullptr || w_h2 == nullptr || range_keys == nullptr) return HN_EINVAL;
+    return conv2d_fwd_impl(x, x_scale, w, w_h2, bias, y, stats, d, HN_ACT_NONE, 0.f, variant, stream, nullptr, 0, range_keys);
+}
+
 namespace {
 // dX = addend, or zero: what the accumulating (split-K / partially covered) data-gradient paths start from
 int init_output(float* dx, int ldx, const float* addend, int ldadd, int64_t npix, int C, void* stream) {
@@ -1062,8 +1103,10 @@ int init_output(float* dx, int ldx, const float* addend, int ldadd, int64_t npix
 
 namespace {
 int conv2d_dgrad_impl(const float* dy, const float* dy_scale, const float* wt, const void* wt_x3, float* dx, const float* addend,
-                      int ldadd, const HnConvDesc* d, int variant, void* stream) {
-    if (dy == nullptr || wt == nullptr || dx == nullptr) return HN_EINVAL;
+                      int ldadd, const HnConvDesc* d, int variant, void* stream, const void* dyh = nullptr,
+                      long long dyh_plane = 0) {
+    if ((dy == nullptr && dyh == nullptr) || (wt == nullptr && dyh == nullptr) || dx == nullptr) return HN_EINVAL;
+    if (dyh != nullptr && (dy_scale == nullptr || dyh_plane <= 0)) return HN_EINVAL;
     if (dy_scale != nullptr) {
         if (wt_x3 == nullptr || variant < 0) return HN_EINVAL;
         variant = (variant & 63) | VARIANT_F16X2;
@@ -1089,6 +1132,12 @@ int conv2d_dgrad_impl(const float* dy, const float* dy_scale, const float* wt, c
     a.a_scale = dy_scale;
     a.w_scale = dy_scale != nullptr && wt_x3 != nullptr ? h2_scale_of(wt_x3, a.wx3_plane) : nullptr;
     a.gm = 1;
+    const bool planes_in = dyh != nullptr;
+    if (planes_in) {
+        a.xh = static_cast<const unsigned short*>(dyh);
+        a.xh_plane = dyh_plane;
+        a.x_bytes = (((long long)d->N * d->Hout * d->Wout - 1) * d->ldy + d->Cout) * 2;
+    }
 
     if (!parity_decomposable(d->KH, d->KW, d->stride, d->dil)) {
         // stride 1: a plain convolution of dY with the flipped taps; other strides: the same kernel gathering from the
@@ -1100,7 +1149,7 @@ int conv2d_dgrad_impl(const float* dy, const float* dy_scale, const float* wt, c
         a.M = d->N * d->Hin * d->Win;
         a.Kdim = d->KH * d->KW * d->Cout;
         a.omap = 0; a.oH = a.oW = a.oph = a.opw = 0; a.ostep = 1;
-        a.cps = (d->ldx == d->Cin && d->stride == 1 && !g_deterministic) ? plan_split_k(a.M, a.K, a.Kdim) : 0;
+        a.cps = (d->ldx == d->Cin && d->stride == 1 && !g_deterministic && !planes_in) ? plan_split_k(a.M, a.K, a.Kdim) : 0;
         if (a.cps > 0) {  // split-K partials add into dX, which therefore starts as the addend (or zero)
             const int rci = init_output(dx, d->ldx, addend, ldadd, (int64_t)a.M, d->Cin, stream);
             if (rci != HN_OK) return rci;
@@ -1118,7 +1167,8 @@ int conv2d_dgrad_impl(const float* dy, const float* dy_scale, const float* wt, c
     const bool some_empty = gh[0].T == 0 || gh[1].T == 0 || gw[0].T == 0 || gw[1].T == 0;
     // split-K when the classes are tiny (critic tails): every class then ADDS into a pre-initialised dX
     const int Mc = d->N * ((d->Hin + 1) / 2) * ((d->Win + 1) / 2);
-    const bool split = d->ldx == d->Cin && !g_deterministic && plan_split_k(Mc, d->Cin, gh[1].T * gw[1].T * d->Cout) > 0;
+    const bool split = d->ldx == d->Cin && !g_deterministic && !planes_in &&
+                       plan_split_k(Mc, d->Cin, gh[1].T * gw[1].T * d->Cout) > 0;
     if (some_empty || split) {  // pixels no tap reaches, or accumulation target: dX = addend or 0
         const int rci = init_output(dx, d->ldx, addend, ldadd, (int64_t)d->N * d->Hin * d->Win, d->Cin, stream);
         if (rci != HN_OK) return rci;
@@ -1167,6 +1217,13 @@ extern "C" int hn_conv2d_dgrad_scaled(const float* dy, const float* dy_scale, co
                                       const float* addend, int ldadd, const HnConvDesc* d, int variant, void* stream) {
     if (dy_scale == nullptr || wt_h2 == nullptr) return HN_EINVAL;
     return conv2d_dgrad_impl(dy, dy_scale, wt, wt_h2, dx, addend, ldadd, d, variant, stream);
+}
+
+extern "C" int hn_conv2d_dgrad_planes(const void* dy_planes, int64_t plane_elems, const float* dy_scale, const void* wt_h2,
+                                      float* dx, const float* addend, int ldadd, const HnConvDesc* d, int variant,
+                                      void* stream) {
+    if (dy_planes == nullptr || dy_scale == nullptr || wt_h2 == nullptr) return HN_EINVAL;
+    return conv2d_dgrad_impl(nullptr, dy_scale, nullptr, wt_h2, dx, addend, ldadd, d, variant, stream, dy_planes, plane_elems);
 }
 
 extern "C" int hn_absmax_scale(const float* x, int ld, int64_t npix, int C, float* scale, void* stream) {

@@ -47,6 +47,11 @@ struct WgradArgs {
     long long x_bytes, dy_bytes;
     const float* x_scale;   // f16x2: scale slots of x and of dy (hn_absmax_scale); NULL otherwise
     const float* dy_scale;
+    // plane tensors (conv_wgrad4_kernel): hi / lo fp16 images of x and dy, plane strides in elements, pixel strides ldx / ldy
+    // in fp16 elements; x_bytes / dy_bytes are then the extent of ONE plane
+    const unsigned short* xh = nullptr;
+    const unsigned short* dyh = nullptr;
+    long long xh_plane = 0, dyh_plane = 0;
 };
 
 __device__ __forceinline__ f32x4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
@@ -744,13 +749,257 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs p
     }
 }
 
+// ---- f16x2 weight gradient on plane tensors: everything by LDS-DMA ---------------------------------------------------------
+// Same GEMM, LDS images ([32 pixels][channels] fp16 per plane, x3_off swizzle), transposed fragment reads, MFMA order and
+// epilogue as conv_wgrad_x3_kernel<TM, TN, 2>, but both operands arrive as plane tensors (hi / lo fp16 images written by the
+// pass that produced them, include/heatnet_hip.h) and go global -> LDS with buffer_load_dwordx4 ... lds: no staging registers, no
+// split arithmetic, no ds_write.  The swizzle is applied on the source side: the lane that fills 16-byte position q of pixel
+// row k fetches the channel piece x3_off maps there.  Two LDS stages, one barrier per 32-pixel reduction step.  Given planes
+// made with the same scale the result of a launch with the same reduction split is bitwise that of the register kernel.
+__device__ __forceinline__ void wg_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, 0, 0, 0);
+#endif
+}
+
+// channel piece (8 channels = 16 B) stored at 16-byte position pp of pixel row k of a [32][B] image (inverse of x3_off)
+template <int B>
+__device__ __forceinline__ int x3_piece_at(int k, int pp) {
+    const int swz = B >= 128 ? (k & 3) : ((k >> 1) & 1);
+    return (((pp >> 2) ^ swz) << 2) | ((pp & 3) ^ (((k >> 3) & 1) << 1));
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) {
+    constexpr int BKP = 32;
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int PLANE_A = BKP * BM * 2, PLANE_B = BKP * BN * 2;  // bytes per fp16 plane
+    constexpr int STAGE = 2 * (PLANE_A + PLANE_B);
+    constexpr int ROWS_A = 1024 / (2 * BM), ROWS_B = 1024 / (2 * BN);  // pixel rows one 1-KiB DMA covers
+    constexpr int PPR_A = BM / 8, PPR_B = BN / 8;                       // 16-byte pieces per pixel row
+    constexpr int QA = BKP / ROWS_A / 4, QB = BKP / ROWS_B / 4;         // DMA row groups per wave, plane and stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles = p.ntm * p.ntn;
+    const int logical = hn_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / tiles, tile = logical - split * tiles;
+    const int tile_m = tile % p.ntm, tile_n = tile / p.ntm;
+    const int co0 = tile_m * BM, n0 = tile_n * BN;
+    const int total_chunks = (p.M + BKP - 1) / BKP;
+    const int c_begin = split * p.chunks_per_split;
+    const int c_end = min(total_chunks, c_begin + p.chunks_per_split);
+    const int hw = p.Ho * p.Wo;
+    float s_dy, s_x, i_dy, i_x;
+    hn_h2_scales_of_slot(p.dy_scale, s_dy, i_dy);
+    hn_h2_scales_of_slot(p.x_scale, s_x, i_x);
+    const float o_s = i_dy * i_x;
+
+    const int tap = n0 / p.C, ci0 = n0 - tap * p.C;  // a tile's column range lies inside one tap (C % BN == 0)
+    const int vkh = tap / p.KW, vkw = tap - vkh * p.KW;
+
+    const unsigned x_records = (unsigned)p.x_bytes, dy_records = (unsigned)p.dy_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc_x0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.xh), 0, x_records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.xh + p.xh_plane), 0, x_records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_d0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.dyh), 0, dy_records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_d1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.dyh + p.dyh_plane), 0, dy_records, 0x00020000);
+
+    // ---- A (dY): this lane's pixel rows and channel pieces --------------------------------------------------------
+    unsigned a_voff[QA];
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+        const int k = (wave + 4 * q) * ROWS_A + lane / PPR_A;
+        const int cp = x3_piece_at<BM>(k, lane % PPR_A);
+        const bool ok = co0 + cp * 8 < p.K;
+        a_voff[q] = ok ? (unsigned)((k * p.ldy + co0 + cp * 8) * 2) : dy_records;
+    }
+    // ---- B (X at this tile's tap): pixel coordinates tracked incrementally (no division in the loop) -----------------
+    int hq[QB], wq[QB], wo_[QB], ho_[QB];
+    long long xoff[QB];  // fp16-element offset of (pixel, channel piece)
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        const int k = (wave + 4 * q) * ROWS_B + lane / PPR_B;
+        const int cp = x3_piece_at<BN>(k, lane % PPR_B);
+        const int pix = c_begin * BKP + k;
+        const int n = pix / hw, rem = pix - n * hw;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        ho_[q] = ho;
+        wo_[q] = wo;
+        hq[q] = ho * p.stride - p.pad + vkh * p.dil;
+        wq[q] = wo * p.stride - p.pad + vkw * p.dil;
+        xoff[q] = ((long long)(n * p.H + hq[q]) * p.W + wq[q]) * p.ldx + ci0 + cp * 8;
+    }
+    const long long step_w = (long long)p.stride * p.ldx;
+    const long long step_h = (long long)p.stride * p.W * p.ldx;
+    const long long wrap_w = step_h - (long long)p.Wo * step_w;
+    const long long wrap_h = (long long)p.H * p.W * p.ldx - (long long)p.Ho * step_h;
+
+    int fetch_chunk = c_begin;
+    auto dma_chunk = [&](char* st) {  // chunk fetch_chunk -> stage st (zeros past M / outside the image); advances
+        const int p0 = fetch_chunk * BKP;
+        const unsigned adv = (unsigned)((long long)p0 * p.ldy * 2);
+#pragma unroll
+        for (int q = 0; q < QA; ++q) {
+            const unsigned off = a_voff[q] + adv;
+            const unsigned vo = off < a_voff[q] ? 0xFFFFFFFFu : off;
+            char* dst = st + (wave + 4 * q) * 1024;
+            wg_dma16(rsrc_d0, dst, vo);
+            wg_dma16(rsrc_d1, dst + PLANE_A, vo);
+        }
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            const int k = (wave + 4 * q) * ROWS_B + lane / PPR_B;
+            const bool ok = (p0 + k < p.M) & ((unsigned)hq[q] < (unsigned)p.H) & ((unsigned)wq[q] < (unsigned)p.W);
+            const unsigned vo = ok ? (unsigned)(xoff[q] * 2) : x_records;
+            char* dst = st + 2 * PLANE_A + (wave + 4 * q) * 1024;
+            wg_dma16(rsrc_x0, dst, vo);
+            wg_dma16(rsrc_x1, dst + PLANE_B, vo);
+            wo_[q] += BKP;
+            wq[q] += BKP * p.stride;
+            xoff[q] += BKP * step_w;
+            while (wo_[q] >= p.Wo) {
+                wo_[q] -= p.Wo;
+                wq[q] -= p.Wo * p.stride;
+                ho_[q] += 1;
+                hq[q] += p.stride;
+                xoff[q] += wrap_w;
+                if (ho_[q] >= p.Ho) {
+                    ho_[q] -= p.Ho;
+                    hq[q] -= p.Ho * p.stride;
+                    xoff[q] += wrap_h;
+                }
+            }
+        }
+        ++fetch_chunk;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed-read duty of this lane: see conv_wgrad_x3_kernel
+    const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int krow = 8 * tg + tq;
+    int offA[2 * TM], offB[2 * TN];
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i) offA[i] = x3_off<BM>(krow, (wm * TM * 2 + i) * 16 + 4 * tp);
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) offB[j] = 2 * PLANE_A + x3_off<BN>(krow, (wn * TN * 2 + j) * 16 + 4 * tp);
+
+    auto k32 = [&](const char* st) {
+        f16x8 fb[2 * TN][2];
+#pragma unroll
+        for (int bj = 0; bj < 2 * TN; ++bj)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const char* b = st + s2 * PLANE_B + offB[bj];
+                const bf16x4 lo = lds_read_tr(b), hi = lds_read_tr(b + 4 * (2 * BN));
+                fb[bj][s2] = __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+        for (int bi = 0; bi < 2 * TM; ++bi) {
+            f16x8 fa[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const char* a = st + s2 * PLANE_A + offA[bi];
+                const bf16x4 lo = lds_read_tr(a), hi = lds_read_tr(a + 4 * (2 * BM));
+                fa[s2] = __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            f32x4 c[2 * TN];
+#pragma unroll
+            for (int bj = 0; bj < 2 * TN; ++bj) {
+                const int sb = 4 * (2 * (bi & 1) + (bj & 1));
+                const f32x16& blk = acc[bi >> 1][bj >> 1];
+                c[bj] = f32x4{blk[sb], blk[sb + 1], blk[sb + 2], blk[sb + 3]};
+            }
+            // per accumulator: lo*hi, hi*lo, hi*hi (the register kernel's order); consecutive MFMAs hit different accumulators
+#pragma unroll
+            for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[bj][0], c[bj], 0, 0, 0);
+#pragma unroll
+            for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][1], c[bj], 0, 0, 0);
+#pragma unroll
+            for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][0], c[bj], 0, 0, 0);
+#pragma unroll
+            for (int bj = 0; bj < 2 * TN; ++bj) {
+                const int sb = 4 * (2 * (bi & 1) + (bj & 1));
+                f32x16& blk = acc[bi >> 1][bj >> 1];
+                blk[sb] = c[bj][0];
+                blk[sb + 1] = c[bj][1];
+                blk[sb + 2] = c[bj][2];
+                blk[sb + 3] = c[bj][3];
+            }
+        }
+    };
+
+    auto barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    const int nch = c_end - c_begin;
+    if (nch > 0) {
+        dma_chunk(lds);
+        for (int kc = 0; kc < nch; ++kc) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk kc has landed (this wave's pieces)
+            barrier();                                         // ... everybody's; the other stage is free
+            if (kc + 1 < nch) dma_chunk(lds + ((kc + 1) & 1) * STAGE);
+            k32(lds + (kc & 1) * STAGE);
+        }
+    }
+
+    const bool full = (co0 + BM <= p.K) && (n0 + BN <= p.Kdim);
+    float* out = p.slab != nullptr ? p.slab + (size_t)split * p.K * p.Kdim : p.dw;
+    auto finish = [&](auto full_tag, auto atomic_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        constexpr bool ATOMIC = decltype(atomic_tag)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = co0 + (wm * TM + i) * 32 + 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3);
+                    const int n = n0 + (wn * TN + j) * 32 + 16 * ((r >> 2) & 1) + (lane & 15);
+                    if (FULL || (n < p.Kdim && row < p.K)) {
+                        float* dst = out + (size_t)row * p.Kdim + n;
+                        const float v = acc[i][j][r] * o_s;
+                        if constexpr (ATOMIC) atomicAdd(dst, v);
+                        else *dst = v;
+                    }
+                }
+            }
+        }
+    };
+    if (p.atomic) {
+        if (full) finish(std::true_type{}, std::true_type{});
+        else finish(std::false_type{}, std::true_type{});
+    } else {
+        if (full) finish(std::true_type{}, std::false_type{});
+        else finish(std::false_type{}, std::false_type{});
+    }
+}
+
 // X3: 0 = fp32 MFMA kernel, 3 = bf16x3, 1 = bf16, 2 = f16x2 (planes per operand of conv_wgrad_x3_kernel)
 template <int TM, int TN, int MODE, int BKP, int X3 = 0>
 int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int lds = X3 ? X3 * BKP * (BM + BN) * 2 : 2 * BKP * (BM + BN) * (int)sizeof(float);
-    const void* kern = X3 ? reinterpret_cast<const void*>(conv_wgrad_x3_kernel<TM, TN, X3 ? X3 : 3>)
-                          : reinterpret_cast<const void*>(conv_wgrad_kernel<TM, TN, MODE, BKP>);
+    // X3 == 4: plane tensors, two LDS stages of two fp16 planes per operand (conv_wgrad4_kernel)
+    constexpr int lds = X3 == 4 ? 2 * 2 * BKP * (BM + BN) * 2
+                                : (X3 ? X3 * BKP * (BM + BN) * 2 : 2 * BKP * (BM + BN) * (int)sizeof(float));
+    const void* kern = X3 == 4 ? reinterpret_cast<const void*>(conv_wgrad4_kernel<TM, TN>)
+                               : (X3 ? reinterpret_cast<const void*>(conv_wgrad_x3_kernel<TM, TN, (X3 && X3 != 4) ? X3 : 3>)
+                                     : reinterpret_cast<const void*>(conv_wgrad_kernel<TM, TN, MODE, BKP>));
     static std::atomic<unsigned long long> configured{0};
     if (hn_ensure_dynamic_lds(kern, lds, configured) != HN_OK) return HN_ELAUNCH;
     a.ntm = (a.K + BM - 1) / BM;
@@ -774,7 +1023,8 @@ int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     if (a.atomic && !a.dw_zeroed && !a.accumulate) {
         if (hipMemsetAsync(a.dw, 0, (size_t)a.K * a.Kdim * sizeof(float), stream) != hipSuccess) return HN_ELAUNCH;
     }
-    if constexpr (X3 != 0) HN_LAUNCH((conv_wgrad_x3_kernel<TM, TN, X3 ? X3 : 3>), dim3(tiles * split_k), dim3(256), lds, stream, a);
+    if constexpr (X3 == 4) HN_LAUNCH((conv_wgrad4_kernel<TM, TN>), dim3(tiles * split_k), dim3(256), lds, stream, a);
+    else if constexpr (X3 != 0) HN_LAUNCH((conv_wgrad_x3_kernel<TM, TN, (X3 && X3 != 4) ? X3 : 3>), dim3(tiles * split_k), dim3(256), lds, stream, a);
     else HN_LAUNCH((conv_wgrad_kernel<TM, TN, MODE, BKP>), dim3(tiles * split_k), dim3(256), lds, stream, a);
     HN_CHECK_LAUNCH();
     return HN_OK;
@@ -882,7 +1132,79 @@ int wgrad_impl(const float* x, const float* x_scale, const float* dy, const floa
     if (tn_sel) wide_n = tn_sel == 2;
     return dispatch_wgrad<WG_SCALAR, 32>(a, wide_m, wide_n, split_k, s);
 }
+
+// plane tensors: conv_wgrad4_kernel, or nothing (HN_ESHAPE)
+int wgrad_planes_impl(const void* xh, long long xh_plane, const float* x_scale, const void* dyh, long long dyh_plane,
+                      const float* dy_scale, float* dw, const HnConvDesc* d, int split_k, int variant, int flags, float* slab,
+                      void* stream) {
+    if (xh == nullptr || dyh == nullptr || x_scale == nullptr || dy_scale == nullptr || dw == nullptr || d == nullptr ||
+        xh_plane <= 0 || dyh_plane <= 0 || variant < 0)
+        return HN_EINVAL;
+    if (d->N <= 0 || d->Hin <= 0 || d->Win <= 0 || d->Cin <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0 ||
+        d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->dil <= 0 || d->pad < 0 || d->ldx < d->Cin || d->ldy < d->Cout)
+        return HN_EINVAL;
+    const int tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3;
+    if (tm_sel == 3 || tn_sel == 3) return HN_EINVAL;
+    WgradArgs a;
+    a.x = nullptr; a.dy = nullptr; a.dw = dw;
+    a.xh = static_cast<const unsigned short*>(xh); a.dyh = static_cast<const unsigned short*>(dyh);
+    a.xh_plane = xh_plane; a.dyh_plane = dyh_plane;
+    a.H = d->Hin; a.W = d->Win; a.C = d->Cin; a.ldx = d->ldx;
+    a.Ho = d->Hout; a.Wo = d->Wout; a.K = d->Cout; a.ldy = d->ldy;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+    a.M = d->N * d->Hout * d->Wout;
+    a.Kdim = d->KH * d->KW * d->Cin;
+    a.ntm = a.ntn = a.chunks_per_split = a.atomic = 0;
+    a.slab = slab;
+    a.x_scale = x_scale;
+    a.dy_scale = dy_scale;
+    a.dw_zeroed = (flags & HN_WGRAD_DW_ZEROED) != 0;
+    a.accumulate = (flags & HN_WGRAD_ACCUMULATE) != 0;
+    a.x_bytes = (((long long)d->N * d->Hin * d->Win - 1) * d->ldx + d->Cin) * 2;
+    a.dy_bytes = (((long long)a.M - 1) * d->ldy + d->Cout) * 2;
+    if (xh_plane < a.x_bytes / 2 || dyh_plane < a.dy_bytes / 2) return HN_EINVAL;
+    const bool ok = d->Cin % 64 == 0 && d->Cout % 64 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && hn_aligned16(xh) &&
+                    hn_aligned16(dyh) && xh_plane % 8 == 0 && dyh_plane % 8 == 0 && a.x_bytes < 0xFFFF0000ll &&
+                    a.dy_bytes + 64ll * d->ldy * 2 < 0xFFFF0000ll;
+    if (!ok) return HN_ESHAPE;
+    bool wide_m = d->Cout % 128 == 0, wide_n = d->Cin % 128 == 0;
+    if (tm_sel == 1) wide_m = false;
+    if (tn_sel == 1) wide_n = false;
+    return dispatch_wgrad<WG_VEC_BUF, 32, 4>(a, wide_m, wide_n, split_k, static_cast<hipStream_t>(stream));
+}
 }  // namespace
+
+extern "C" int hn_conv2d_wgrad_planes(const void* x_planes, int64_t x_plane_elems, const float* x_scale, const void* dy_planes,
+                                      int64_t dy_plane_elems, const float* dy_scale, float* dw, const HnConvDesc* d, int split_k,
+                                      int variant, int flags, void* stream) {
+    return wgrad_planes_impl(x_planes, x_plane_elems, x_scale, dy_planes, dy_plane_elems, dy_scale, dw, d, split_k, variant, flags,
+                             nullptr, stream);
+}
+
+extern "C" int hn_conv2d_wgrad_det_planes(const void* x_planes, int64_t x_plane_elems, const float* x_scale,
+                                          const void* dy_planes, int64_t dy_plane_elems, const float* dy_scale, float* dw,
+                                          const HnConvDesc* d, int split_k, int variant, int flags, float* workspace,
+                                          void* stream) {
+    if (d == nullptr || workspace == nullptr || split_k <= 0) return HN_EINVAL;
+    if (d->N <= 0 || d->Hout <= 0 || d->Wout <= 0) return HN_EINVAL;
+    const long long total_chunks = ((long long)d->N * d->Hout * d->Wout + 31) / 32;
+    long long s = split_k < total_chunks ? split_k : total_chunks;
+    const long long cps = (total_chunks + s - 1) / s;
+    s = (total_chunks + cps - 1) / cps;
+    const int accumulate = (flags & HN_WGRAD_ACCUMULATE) != 0;
+    if (s == 1 && !accumulate)
+        return wgrad_planes_impl(x_planes, x_plane_elems, x_scale, dy_planes, dy_plane_elems, dy_scale, dw, d, 1, variant, 0, nullptr,
+                                 stream);
+    const int rc = wgrad_planes_impl(x_planes, x_plane_elems, x_scale, dy_planes, dy_plane_elems, dy_scale, dw, d, (int)s, variant,
+                                     flags, workspace, stream);
+    if (rc != HN_OK) return rc;
+    const long long n = (long long)d->Cout * d->KH * d->KW * d->Cin;
+    const long long blocks = (n + 255) / 256;
+    HN_LAUNCH(wgrad_slab_reduce_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0,
+              static_cast<hipStream_t>(stream), workspace, dw, n, (int)s, accumulate);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
 
 extern "C" int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant,
                                int flags, void* stream) {

@@ -77,6 +77,16 @@ __device__ __forceinline__ void hn_h2_scales_of_slot(const float* slot, float& s
     hn_h2_scales((unsigned)__builtin_amdgcn_readfirstlane((int)m), s, inv);
 }
 
+// Order-preserving key of a float (key(a) < key(b) <=> a < b for non-NaN values); 0 is below every key a kernel produces
+// ("nothing seen"), so accumulators of atomicMax(key) start from zero-filled memory.
+__device__ __forceinline__ unsigned hn_range_key(float f) {
+    const unsigned b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float hn_range_unkey(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
 // Every thread of a 256-thread block (1-D or 2-D) calls this with the largest |value| bit pattern it produced (0 if none):
 // ONE no-return atomic max per block into word (block % HN_SCALE_WORDS).  Device-scope atomics on one word serialise at
 // ~11 ns each (MI355X_MICROARCH.md, fan-in): the words sit on 64 different 128-B lines.

@@ -30,6 +30,42 @@ __device__ __forceinline__ void stv(float* p, const float (&v)[V]) {
     }
 }
 
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+// Plane tensors (f16x2 operands made by the producing pass, conv_igemm4.hip): element (pix, c) of a tensor t lives as
+// hi = fp16(t * s) at planes[pix * ldp + c] and lo = fp16(t * s - hi) at planes[plane + pix * ldp + c], s = the power of two of
+// the tensor's scale slot.  t is recovered as (hi + lo) / s (exact sums in fp32).
+template <int V>
+__device__ __forceinline__ void st_planes(unsigned short* __restrict__ hi, long long plane, const float (&v)[V], float s) {
+    if constexpr (V == 4) {
+        h16x4 h, l;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xs = v[i] * s;
+            h[i] = (_Float16)xs;
+            l[i] = (_Float16)(xs - (float)h[i]);
+        }
+        *reinterpret_cast<h16x4*>(hi) = h;
+        *reinterpret_cast<h16x4*>(hi + plane) = l;
+    } else {
+        const float xs = v[0] * s;
+        const _Float16 h = (_Float16)xs;
+        const _Float16 l = (_Float16)(xs - (float)h);
+        hi[0] = __builtin_bit_cast(unsigned short, h);
+        hi[plane] = __builtin_bit_cast(unsigned short, l);
+    }
+}
+template <int V>
+__device__ __forceinline__ void ld_planes(const unsigned short* __restrict__ hi, long long plane, float (&v)[V], float inv) {
+    if constexpr (V == 4) {
+        const h16x4 h = *reinterpret_cast<const h16x4*>(hi), l = *reinterpret_cast<const h16x4*>(hi + plane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ((float)h[i] + (float)l[i]) * inv;
+    } else {
+        v[0] = ((float)__builtin_bit_cast(_Float16, hi[0]) + (float)__builtin_bit_cast(_Float16, hi[plane])) * inv;
+    }
+}
+
 struct RowLaunch {
     dim3 grid, block;
     int V;
@@ -467,6 +503,36 @@ __global__ __launch_bounds__(256) void scale_nc_kernel(const float* __restrict__
     }
 }
 
+// fp32 tensor -> plane tensor with the scale of `slot` (tests, and tensors whose producer cannot write planes itself)
+template <int V>
+__global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ slot,
+                                                       unsigned short* __restrict__ planes, long long plane, int ldp,
+                                                       int64_t npix, int C) {
+    float s, inv;
+    hn_h2_scales_of_slot(slot, s, inv);
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (c >= C) return;
+    for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
+        float v[V];
+        ldv<V>(x + pix * ldx + c, v);
+        st_planes<V>(planes + pix * ldp + c, plane, v, s);
+    }
+}
+template <int V>
+__global__ __launch_bounds__(256) void from_planes_kernel(const unsigned short* __restrict__ planes, long long plane, int ldp,
+                                                         const float* __restrict__ slot, float* __restrict__ x, int ldx,
+                                                         int64_t npix, int C) {
+    float s, inv;
+    hn_h2_scales_of_slot(slot, s, inv);
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (c >= C) return;
+    for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
+        float v[V];
+        ld_planes<V>(planes + pix * ldp + c, plane, v, inv);
+        stv<V>(x + pix * ldx + c, v);
+    }
+}
+
 bool bad_rows(int64_t npix, int C, std::initializer_list<int> lds) {
     if (npix <= 0 || C <= 0) return true;
     for (int ld : lds)
@@ -696,6 +762,33 @@ extern "C" int hn_copy(const float* x, int ldx, float* y, int ldy, int64_t npix,
     const RowLaunch pl = plan_rows(npix, C, {x, y}, {ldx, ldy});
     if (pl.V == 4) HN_LAUNCH((rowwise_kernel<4, 2>), pl.grid, pl.block, 0, s, x, ldx, nullptr, 0, y, ldy, npix, C, 0, 0.f);
     else HN_LAUNCH((rowwise_kernel<1, 2>), pl.grid, pl.block, 0, s, x, ldx, nullptr, 0, y, ldy, npix, C, 0, 0.f);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_tensor_to_planes(const float* x, int ldx, int64_t npix, int C, const float* scale, void* planes,
+                                   int64_t plane_elems, int ldp, void* stream) {
+    if (!x || !scale || !planes || bad_rows(npix, C, {ldx, ldp}) || plane_elems < (npix - 1) * ldp + C) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    RowLaunch pl = plan_rows(npix, C, {x}, {ldx});
+    if (pl.V == 4 && (ldp % 4 != 0 || plane_elems % 4 != 0 || (reinterpret_cast<uintptr_t>(planes) & 7u) != 0)) {
+        pl = plan_rows(npix, C, {reinterpret_cast<const void*>(uintptr_t(1))}, {ldx});
+    }
+    unsigned short* ph = static_cast<unsigned short*>(planes);
+    HN_LAUNCH_V(pl, to_planes_kernel, x, ldx, scale, ph, (long long)plane_elems, ldp, npix, C);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_planes_to_tensor(const void* planes, int64_t plane_elems, int ldp, const float* scale, float* x, int ldx,
+                                   int64_t npix, int C, void* stream) {
+    if (!x || !scale || !planes || bad_rows(npix, C, {ldx, ldp}) || plane_elems < (npix - 1) * ldp + C) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    RowLaunch pl = plan_rows(npix, C, {x}, {ldx});
+    if (pl.V == 4 && (ldp % 4 != 0 || plane_elems % 4 != 0 || (reinterpret_cast<uintptr_t>(planes) & 7u) != 0))
+        pl = plan_rows(npix, C, {reinterpret_cast<const void*>(uintptr_t(1))}, {ldx});
+    const unsigned short* ph = static_cast<const unsigned short*>(planes);
+    HN_LAUNCH_V(pl, from_planes_kernel, ph, (long long)plane_elems, ldp, scale, x, ldx, npix, C);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

@@ -193,6 +193,48 @@ int hn_conv2d_wgrad_scaled(const float* x, const float* x_scale, const float* dy
 int hn_conv2d_wgrad_det_scaled(const float* x, const float* x_scale, const float* dy, const float* dy_scale, float* dw,
                                const HnConvDesc* d, int split_k, int variant, int flags, float* workspace, void* stream);
 
+/* ---- f16x2 with PLANE TENSORS: the operand split is made once, by the pass that produces the tensor -------------------
+ * A plane tensor holds t as two dense fp16 images of `plane_elems` elements each, pixel stride ldp fp16 elements:
+ * hi = fp16(t * s) at planes[pix * ldp + c], lo = fp16(t * s - hi) at planes[plane_elems + pix * ldp + c], s the power of two
+ * derived from the tensor's scale slot (above) -- the 4 bytes per element of the fp32 tensor, in the form the f16x2
+ * kernels otherwise build in registers for every tile that touches the element (nine times per column tile of a 3x3
+ * convolution).  t = (hi + lo) / s; elements within 2^-18 of the slot's magnitude keep 22 significant bits.  The slot
+ * must be final BEFORE the producing pass runs, so it holds a BOUND of max|t| known beforehand: hn_bn_finalize_range derives
+ * one for a BatchNorm output from the per-channel range of the convolution output (the `range_keys` of hn_conv2d_fwd_planes /
+ * hn_conv2d_fwd_scaled_range), hn_bn_act_bwd_reduce_range one for the gradient hn_bn_act_bwd_apply_planes writes.
+ * The *_planes convolution entry points run csrc/conv_igemm4.hip / conv_wgrad4.hip: both operands global -> LDS by LDS-DMA,
+ * no staging registers, no split arithmetic, no ds_write in the K loop; with planes made with the same scale the results
+ * are bitwise those of the *_scaled entry points.  They cover Cin % 32 == 0 (weight gradient: Cin % 64 == 0 and
+ * Cout % 64 == 0), ldp % 8 == 0, 16-B aligned planes, no split-K; HN_ESHAPE otherwise.
+ * cm/models/extractors.py:84-102 (bottleneck: conv1 -> bn1 -> relu -> conv2 -> bn2 -> relu -> conv3 -> bn3 -> add -> relu). */
+int hn_tensor_to_planes(const float* x, int ldx, int64_t npix, int C, const float* scale, void* planes, int64_t plane_elems,
+                        int ldp, void* stream);
+int hn_planes_to_tensor(const void* planes, int64_t plane_elems, int ldp, const float* scale, float* x, int ldx, int64_t npix,
+                        int C, void* stream);
+/* d->ldx = pixel stride of the planes (fp16 elements).  `variant`: 0 = heuristic tile, 1 = 128 x 64, 2 = 128 x 256 (eight
+ * waves), 3 = 256 x 128 (eight waves); else 128 x 128 with two workgroups per CU.  `range_keys` (optional, needs `stats` and
+ * act = none): HN_STAT_REPLICAS * 2 * Cout words, zero on entry: order-preserving keys of the per-channel maximum of y and
+ * of -y (see hn_bn_finalize_range, which consumes and re-zeroes them). */
+int hn_conv2d_fwd_planes(const void* x_planes, int64_t plane_elems, const float* x_scale, const void* w_h2, const float* bias,
+                         float* y, double* stats, uint32_t* range_keys, const HnConvDesc* d, int act, float slope, int variant,
+                         void* stream);
+/* hn_conv2d_fwd_scaled (fp32 input tensor) that also accumulates the range keys of its output */
+int hn_conv2d_fwd_scaled_range(const float* x, const float* x_scale, const float* w, const void* w_h2, const float* bias,
+                               float* y, double* stats, uint32_t* range_keys, const HnConvDesc* d, int variant, void* stream);
+/* d->ldy = pixel stride of the dY planes */
+int hn_conv2d_dgrad_planes(const void* dy_planes, int64_t plane_elems, const float* dy_scale, const void* wt_h2, float* dx,
+                           const float* addend, int ldadd, const HnConvDesc* d, int variant, void* stream);
+
+/* Weight gradient with BOTH operands as plane tensors (d->ldx / d->ldy = their pixel strides in fp16 elements); split_k,
+ * flags and the deterministic form as for hn_conv2d_wgrad / hn_conv2d_wgrad_det; `variant`: only the tile fields
+ * (4 * tm + 16 * tn, 1 = 64-wide, 0 / 2 = 128-wide where the channel counts allow). */
+int hn_conv2d_wgrad_planes(const void* x_planes, int64_t x_plane_elems, const float* x_scale, const void* dy_planes,
+                           int64_t dy_plane_elems, const float* dy_scale, float* dw, const HnConvDesc* d, int split_k,
+                           int variant, int flags, void* stream);
+int hn_conv2d_wgrad_det_planes(const void* x_planes, int64_t x_plane_elems, const float* x_scale, const void* dy_planes,
+                               int64_t dy_plane_elems, const float* dy_scale, float* dw, const HnConvDesc* d, int split_k,
+                               int variant, int flags, float* workspace, void* stream);
+
 /* dx = conv_transpose(dy, w) [+ addend] for the forward geometry `d` (dy is N x Hout x Wout x Cout with pixel stride
  * d->ldy, dx is N x Hin x Win x Cin with pixel stride d->ldx); `wt` from hn_weight_flip_transpose.  `addend`
  * (optional, pixel stride ldadd, must not overlap dx) is a gradient that reached the same tensor through another branch --

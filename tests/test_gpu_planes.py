@@ -1,0 +1,227 @@
+"""Plane tensors (f16x2 operands made by the producing pass) and the all-LDS-DMA convolution kernels that read them
+(csrc/conv_igemm4.hip, csrc/conv_wgrad4.hip), through the C ABI.
+
+With planes made with the SAME scale slot the kernels must reproduce the *_scaled entry points (which split the fp32 tensor in
+registers) bit for bit: same LDS contents, same MFMA order.  The reference layers these kernels serve:
+cm/models/extractors.py:84-102 (bottleneck), cm/models/pspnet.py:37-40 (decoder convolutions)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_planes(lib, x_nhwc, slot, ldp=None):
+    """[N, H, W, C] fp32 -> int16 buffer of 2 planes with the scale of `slot`."""
+    from heatnet_amd import _lib
+    n, h, w, c = x_nhwc.shape
+    ldp = c if ldp is None else ldp
+    npix = n * h * w
+    plane = npix * ldp
+    buf = torch.zeros(2 * plane, device=x_nhwc.device, dtype=torch.int16)
+    _lib.check(lib.hn_tensor_to_planes(P(x_nhwc), c, npix, c, P(slot), P(buf), plane, ldp, _stream()), "to_planes")
+    return buf, plane
+
+
+def make_slot(lib, t_nhwc):
+    from heatnet_amd import _lib, ops
+    n, h, w, c = t_nhwc.shape
+    slot = torch.zeros(ops.SCALE_SLOT_FLOATS, device=t_nhwc.device)
+    _lib.check(lib.hn_absmax_scale(P(t_nhwc), c, n * h * w, c, P(slot), _stream()), "absmax")
+    return slot
+
+
+def test_plane_tensor_round_trip(dev):
+    """(hi + lo) / s recovers the tensor to 2^-22 of each element (elements within 2^-18 of the maximum), exactly for fp16-
+    representable values; scalar path (C % 4 != 0) agrees with the vector path."""
+    from heatnet_amd import _lib
+    lib = _lib.load()
+    for c in (64, 6):
+        x = (rnd(2, 9, 11, c, seed=1) * 3.0).to(dev)
+        slot = make_slot(lib, x)
+        buf, plane = to_planes(lib, x, slot)
+        back = torch.empty_like(x)
+        _lib.check(lib.hn_planes_to_tensor(P(buf), plane, c, P(slot), P(back), c, x.numel() // c, c, _stream()), "from_planes")
+        err = ((back - x).abs() / x.abs().clamp_min(1e-30)).max().item()
+        assert err <= 2.0 ** -21, err
+        xi = torch.randint(-2048, 2048, x.shape, device=dev).float()  # exactly representable after any power-of-two scale
+        slot = make_slot(lib, xi)
+        buf, plane = to_planes(lib, xi, slot)
+        _lib.check(lib.hn_planes_to_tensor(P(buf), plane, c, P(slot), P(back), c, x.numel() // c, c, _stream()), "from_planes")
+        assert torch.equal(back, xi)
+
+
+PLANE_CONV_CASES = [  # n, cin, h, w, cout, k, stride, pad, dil
+    (2, 64, 40, 44, 256, 1, 1, 0, 1),
+    (2, 256, 32, 40, 256, 3, 1, 2, 2),
+    (2, 128, 33, 47, 320, 3, 1, 1, 1),    # ragged rows and columns
+    (2, 128, 40, 44, 64, 3, 1, 1, 1),     # 64 output channels
+    (2, 128, 40, 44, 128, 3, 2, 1, 1),    # stride 2 (forward gather; data gradient by parity classes)
+    (2, 256, 40, 44, 512, 1, 2, 0, 1),    # strided 1x1 (downsample)
+    (1, 512, 24, 40, 512, 3, 1, 4, 4),    # dilation 4
+    (3, 96, 30, 30, 160, 1, 1, 0, 1),     # Cin % 64 != 0, Cout % 64 != 0
+]
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("case", PLANE_CONV_CASES, ids=str)
+def test_conv_planes_forward_dgrad_bitwise(dev, case, tile):
+    from heatnet_amd import _lib, ops
+    lib = _lib.load()
+    s = _stream()
+    n, cin, h, w_, cout, k, stride, pad, dil = case
+    ho, wo = ops.conv_out_size(h, k, stride, pad, dil), ops.conv_out_size(w_, k, stride, pad, dil)
+    x = F.relu(rnd(n, h, w_, cin, seed=11)).to(dev)
+    wt = rnd(cout, k, k, cin, seed=12, scale=1.0 / np.sqrt(cin * k * k)).to(dev)
+    b = rnd(cout, seed=13).to(dev)
+    gy = (rnd(n, ho, wo, cout, seed=14) * 1e-3).to(dev)
+    skip = (rnd(n, h, w_, cin, seed=15) * 1e-3).to(dev)
+    nw, plane_w = wt.numel(), ops.x3_plane(wt.numel())
+    wh, wth, wtf = (torch.empty(3 * plane_w, device=dev, dtype=torch.int16), torch.empty(3 * plane_w, device=dev, dtype=torch.int16),
+                    torch.empty(nw, device=dev))
+    _lib.check(lib.hn_weight_flip_transpose_h2(P(wt), P(wh), P(wtf), P(wth), cout, k, k, cin, stride, pad, dil, s), "flip")
+    xs, gs = make_slot(lib, x), make_slot(lib, gy)
+    d = _lib.HnConvDesc(n, h, w_, cin, cin, ho, wo, cout, cout, k, k, stride, pad, dil)
+    # reference: the fp32-input f16x2 kernels (deterministic: no split-K atomics)
+    lib.hn_set_deterministic(1)
+    try:
+        y0 = torch.empty(n, ho, wo, cout, device=dev)
+        st0 = torch.zeros(ops.STAT_REPLICAS * 2 * cout, device=dev, dtype=torch.float64)
+        _lib.check(lib.hn_conv2d_fwd_scaled(P(x), P(xs), P(wt), P(wh), P(b), P(y0), P(st0), ctypes.byref(d), 0, 0.0, 0, s), "fwd")
+        dx0 = torch.empty_like(x)
+        _lib.check(lib.hn_conv2d_dgrad_scaled(P(gy), P(gs), P(wtf), P(wth), P(dx0), P(skip), cin, ctypes.byref(d), 0, s), "dgrad")
+    finally:
+        lib.hn_set_deterministic(0)
+    xh, xplane = to_planes(lib, x, xs)
+    gh, gplane = to_planes(lib, gy, gs)
+    y1 = torch.full((n, ho, wo, cout), float("nan"), device=dev)
+    st1 = torch.zeros(ops.STAT_REPLICAS * 2 * cout, device=dev, dtype=torch.float64)
+    keys = torch.zeros(ops.STAT_REPLICAS * 2 * cout, device=dev, dtype=torch.int32)
+    _lib.check(lib.hn_conv2d_fwd_planes(P(xh), xplane, P(xs), P(wh), P(b), P(y1), P(st1), P(keys), ctypes.byref(d), 0, 0.0, tile, s),
+               "fwd_planes")
+    assert torch.equal(y0, y1)
+    # statistics: per-lane fp32 partial sums over a tile's rows, then double -- the grouping depends on the tile
+    a1 = st1.view(ops.STAT_REPLICAS, 2, cout).sum(0)
+    yd = y1.double().reshape(-1, cout)
+    assert float((a1[0] - yd.sum(0)).abs().max()) <= 1e-5 * float(yd.abs().sum(0).max())
+    assert float((a1[1] - (yd * yd).sum(0)).abs().max()) <= 1e-5 * float((yd * yd).sum(0).max())
+    # range keys: exact per-channel max / min of y
+    kk = keys.view(ops.STAT_REPLICAS, 2, cout).cpu().numpy().astype(np.uint32).max(0)
+
+    def unkey(u):
+        u = u.astype(np.uint32)
+        b_ = np.where(u & 0x80000000, u ^ np.uint32(0x80000000), ~u)
+        return b_.astype(np.uint32).view(np.float32)
+    ymax, ymin = unkey(kk[0]), -unkey(kk[1])
+    yc = y1.reshape(-1, cout).cpu().numpy()
+    assert np.array_equal(ymax, yc.max(0)) and np.array_equal(ymin, yc.min(0))
+    dx1 = torch.full_like(x, float("nan"))
+    _lib.check(lib.hn_conv2d_dgrad_planes(P(gh), gplane, P(gs), P(wth), P(dx1), P(skip), cin, ctypes.byref(d), tile, s), "dgrad_planes")
+    assert torch.equal(dx0, dx1)
+    # fused ReLU epilogue
+    y2 = torch.empty_like(y1)
+    _lib.check(lib.hn_conv2d_fwd_planes(P(xh), xplane, P(xs), P(wh), P(b), P(y2), None, None, ctypes.byref(d), 1, 0.0, tile, s), "relu")
+    assert torch.equal(y2, torch.relu(y1))
+
+
+def test_conv_planes_refusals(dev):
+    from heatnet_amd import _lib, ops
+    lib = _lib.load()
+    s = _stream()
+    n, cin, h, w_, cout, k = 2, 64, 16, 24, 64, 3
+    x = rnd(n, h, w_, cin, seed=21).to(dev)
+    wt = rnd(cout, k, k, cin, seed=22).to(dev)
+    plane_w = ops.x3_plane(wt.numel())
+    wh = torch.empty(3 * plane_w, device=dev, dtype=torch.int16)
+    _lib.check(lib.hn_split_f16x2(P(wt), P(wh), wt.numel(), s), "split")
+    xs = make_slot(lib, x)
+    xh, xplane = to_planes(lib, x, xs)
+    y = torch.empty(n, h, w_, cout, device=dev)
+    d = _lib.HnConvDesc(n, h, w_, cin, cin, h, w_, cout, cout, k, k, 1, 1, 1)
+    assert lib.hn_conv2d_fwd_planes(P(xh), xplane, None, P(wh), None, P(y), None, None, ctypes.byref(d), 0, 0.0, 0, s) == -1
+    assert lib.hn_conv2d_fwd_planes(None, xplane, P(xs), P(wh), None, P(y), None, None, ctypes.byref(d), 0, 0.0, 0, s) == -1
+    d48 = _lib.HnConvDesc(n, h, w_, 48, 48, h, w_, cout, cout, k, k, 1, 1, 1)  # Cin % 32 != 0
+    assert lib.hn_conv2d_fwd_planes(P(xh), xplane, P(xs), P(wh), None, P(y), None, None, ctypes.byref(d48), 0, 0.0, 0, s) == -4
+    keys = torch.zeros(ops.STAT_REPLICAS * 2 * cout, device=dev, dtype=torch.int32)  # range keys need the statistics
+    assert lib.hn_conv2d_fwd_planes(P(xh), xplane, P(xs), P(wh), None, P(y), None, P(keys), ctypes.byref(d), 0, 0.0, 0, s) == -1
+
+
+WGRAD_CASES = [  # n, cin, h, w, cout, k, stride, pad, dil
+    (2, 64, 40, 44, 256, 1, 1, 0, 1),
+    (2, 256, 32, 40, 256, 3, 1, 2, 2),
+    (2, 128, 33, 47, 320, 3, 1, 1, 1),    # ragged pixel count, Cout = 5 x 64
+    (2, 128, 40, 44, 64, 3, 1, 1, 1),
+    (2, 128, 40, 44, 128, 3, 2, 1, 1),    # stride 2
+    (2, 256, 40, 44, 512, 1, 2, 0, 1),
+    (1, 512, 24, 40, 512, 3, 1, 4, 4),
+    (3, 192, 30, 30, 192, 1, 1, 0, 1),    # 64-wide tiles both ways
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=str)
+def test_wgrad_planes_bitwise(dev, case):
+    """hn_conv2d_wgrad_planes against hn_conv2d_wgrad_scaled: bitwise with one reduction split and through the deterministic
+    (slab) form, to float-atomic noise with the default split; the accumulate flag; every tile choice."""
+    from heatnet_amd import _lib, ops
+    lib = _lib.load()
+    s = _stream()
+    n, cin, h, w_, cout, k, stride, pad, dil = case
+    ho, wo = ops.conv_out_size(h, k, stride, pad, dil), ops.conv_out_size(w_, k, stride, pad, dil)
+    x = F.relu(rnd(n, h, w_, cin, seed=31)).to(dev)
+    gy = (rnd(n, ho, wo, cout, seed=32) * 1e-3).to(dev)
+    xs, gs = make_slot(lib, x), make_slot(lib, gy)
+    xh, xplane = to_planes(lib, x, xs)
+    gh, gplane = to_planes(lib, gy, gs)
+    d = _lib.HnConvDesc(n, h, w_, cin, cin, ho, wo, cout, cout, k, k, stride, pad, dil)
+    dw0 = torch.empty(cout, k, k, cin, device=dev)
+    _lib.check(lib.hn_conv2d_wgrad_scaled(P(x), P(xs), P(gy), P(gs), P(dw0), ctypes.byref(d), 1, 0, 0, s), "wgrad")
+    for tm, tn in ((0, 0), (1, 1), (2, 1), (1, 2)):
+        var = 4 * tm + 16 * tn
+        dw0v = torch.empty_like(dw0)
+        _lib.check(lib.hn_conv2d_wgrad_scaled(P(x), P(xs), P(gy), P(gs), P(dw0v), ctypes.byref(d), 1, var, 0, s), "wgrad")
+        dw1 = torch.full_like(dw0, float("nan"))
+        _lib.check(lib.hn_conv2d_wgrad_planes(P(xh), xplane, P(xs), P(gh), gplane, P(gs), P(dw1), ctypes.byref(d), 1, var, 0, s),
+                   "wgrad_planes")
+        assert torch.equal(dw0v, dw1), (tm, tn)
+        assert torch.equal(dw0, dw1)  # (tilings agree bitwise as well)
+    # default split: float atomics
+    dw2 = torch.empty_like(dw0)
+    _lib.check(lib.hn_conv2d_wgrad_planes(P(xh), xplane, P(xs), P(gh), gplane, P(gs), P(dw2), ctypes.byref(d), 0, 0, 0, s), "split")
+    assert float((dw2 - dw0).abs().max()) <= 2e-5 * float(dw0.abs().max())
+    # accumulate into a zeroed / pre-filled dW
+    dw3 = dw0.clone()
+    _lib.check(lib.hn_conv2d_wgrad_planes(P(xh), xplane, P(xs), P(gh), gplane, P(gs), P(dw3), ctypes.byref(d), 0, 0, 2, s), "acc")
+    assert float((dw3 - 2 * dw0).abs().max()) <= 4e-5 * float(dw0.abs().max())
+    # deterministic form
+    wsp = torch.empty(4 * dw0.numel(), device=dev)
+    dw4, dw5 = torch.empty_like(dw0), torch.empty_like(dw0)
+    _lib.check(lib.hn_conv2d_wgrad_det_scaled(P(x), P(xs), P(gy), P(gs), P(dw4), ctypes.byref(d), 4, 0, 0, P(wsp), s), "det")
+    _lib.check(lib.hn_conv2d_wgrad_det_planes(P(xh), xplane, P(xs), P(gh), gplane, P(gs), P(dw5), ctypes.byref(d), 4, 0, 0, P(wsp), s),
+               "det_planes")
+    assert torch.equal(dw4, dw5)
+    # refusal: Cout % 64 != 0
+    d32 = _lib.HnConvDesc(n, h, w_, cin, cin, ho, wo, cout - 32, cout, k, k, stride, pad, dil)
+    assert lib.hn_conv2d_wgrad_planes(P(xh), xplane, P(xs), P(gh), gplane, P(gs), P(dw1), ctypes.byref(d32), 0, 0, 0, s) == -4
