@@ -74,6 +74,14 @@ SIGNATURES = {
     "hn_conv2d_dgrad_planes": [P, c_i64, P, P, P, P, c_int, DP, c_int, P],
     "hn_conv2d_wgrad_planes": [P, c_i64, P, P, c_i64, P, P, DP, c_int, c_int, c_int, P],
     "hn_conv2d_wgrad_det_planes": [P, c_i64, P, P, c_i64, P, P, DP, c_int, c_int, c_int, P, P],
+    "hn_bn_finalize_range": [P, P, c_i64, P, P, P, P, c_float, c_float, P, P, P, P, P, c_int, c_int, P, c_float, P, c_float, P, P],
+    "hn_bn_act_fwd_planes": [P, c_int, P, P, P, c_int, P, c_i64, c_int, P, P, c_int, P, c_i64, c_int, P, c_i64, c_int, c_int, P,
+                             c_float, P, c_i64, P, P],
+    "hn_bn_act_bwd_reduce_range": [P, c_int, P, c_int, P, c_int, P, P, P, P, c_i64, c_int, c_int, P, c_float, P, P, P, P, P,
+                                   c_int, P, c_i64, P, P, P, P, c_i64, c_int, P, P],
+    "hn_bn_act_bwd_apply_planes": [P, c_int, P, c_int, P, c_int, P, P, P, P, P, P, c_i64, c_int, P, c_i64, c_int, P, P, c_int,
+                                   c_i64, c_int, c_int, P, c_float, P, c_i64, P, P],
+    "hn_bilinear_up2_planes": [P, c_int, P, P, c_i64, c_int, c_int, c_int, c_int, c_int, P],
     "hn_thermal_augment": [P, P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P, P],
     "hn_thermal_resize": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "hn_set_conv_math": [c_int],

@@ -114,15 +114,36 @@ __device__ __forceinline__ void act_grad(const float (&dz)[V], const float (&z)[
     }
 }
 
-template <int V>
+// plane-tensor operands of the BatchNorm passes (see st_planes): `slot` is READ (the scale the planes are / were made with)
+struct PlaneOut {
+    unsigned short* hi;   // NULL: no plane output
+    long long plane;
+    int ld;
+    const float* slot;
+};
+struct PlaneIn {
+    const unsigned short* hi;  // NULL: the fp32 operand is used
+    long long plane;
+    int ld;
+    const float* slot;
+};
+
+// ZP: z is (also) written as a plane tensor with the scale of zp.slot (a bound known before the pass, hn_bn_finalize_range);
+// the fp32 z is then optional.  RP: the residual is a plane tensor.
+template <int V, bool ZP = false, bool RP = false>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, int ldy,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ res, int ldr, float* __restrict__ z,
                                                         int ldz, int64_t npix, int C, int act, const float* slope_p,
                                                         float leaky, const float* __restrict__ mask, int64_t hw,
-                                                        float* __restrict__ z_scale, unsigned char* __restrict__ rbits) {
+                                                        float* __restrict__ z_scale, unsigned char* __restrict__ rbits,
+                                                        PlaneOut zp = PlaneOut{nullptr, 0, 0, nullptr},
+                                                        PlaneIn rp = PlaneIn{nullptr, 0, 0, nullptr}) {
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     unsigned amax = 0u;  // largest |z| written by this thread (f16x2 scale of the output, optional)
+    float zs = 1.f, zi = 1.f, rs = 1.f, ri = 1.f;
+    if constexpr (ZP) hn_h2_scales_of_slot(zp.slot, zs, zi);
+    if constexpr (RP) hn_h2_scales_of_slot(rp.slot, rs, ri);
     if (c < C) {
         float sc[V], sh[V];
         ldv<V>(scale + c, sc);
@@ -131,17 +152,23 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
         for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
             float v[V], r[V], o[V], m[V];
             ldv<V>(y + pix * ldy + c, v);
-            if (res != nullptr) ldv<V>(res + pix * ldr + c, r);
+            if constexpr (RP) ld_planes<V>(rp.hi + pix * rp.ld + c, rp.plane, r, ri);
+            else if (res != nullptr) ldv<V>(res + pix * ldr + c, r);
             if (mask != nullptr) ldv<V>(mask + (pix / hw) * C + c, m);  // Dropout2d keep/(1-p) factor of (image, channel)
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 float u = v[i] * sc[i] + sh[i];
-                if (res != nullptr) u += r[i];
+                if (RP || res != nullptr) u += r[i];
                 o[i] = hn_apply_act(u, act, slope);
                 if (mask != nullptr) o[i] *= m[i];
                 amax = max(amax, __float_as_uint(o[i]) & 0x7fffffffu);
             }
-            stv<V>(z + pix * ldz + c, o);
+            if constexpr (ZP) {
+                st_planes<V>(zp.hi + pix * zp.ld + c, zp.plane, o, zs);
+                if (z != nullptr) stv<V>(z + pix * ldz + c, o);
+            } else {
+                stv<V>(z + pix * ldz + c, o);
+            }
             if constexpr (V == 4) {
                 // one byte per 16-B piece: bit i = (z[c + i] > 0), what the backward passes need of z (a 16th of its bytes)
                 if (rbits != nullptr)
@@ -150,6 +177,27 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
         }
     }
     if (z_scale != nullptr) hn_absmax_publish(amax, z_scale);
+}
+
+// Bound of |act(y * scale + shift [+ r]) * m| over a channel from the range [ymin, ymax] of y, max |r| and max m: the
+// affine map and the activations are monotone, so the extremes sit at the ends of the range (exact without a residual).
+__device__ __forceinline__ float bn_out_bound(float ymax, float ymin, float sc, float sh, int act, float slope, float rmax,
+                                              float mmax) {
+    const float a = ymax * sc + sh, b = ymin * sc + sh;
+    const float hi = fmaxf(a, b) + rmax, lo = fminf(a, b) - rmax;
+    float bound;
+    if (act == HN_ACT_RELU) bound = fmaxf(hi, 0.f);
+    else if (act == HN_ACT_PRELU || act == HN_ACT_LEAKY) bound = fmaxf(fabsf(hn_apply_act(hi, act, slope)), fabsf(hn_apply_act(lo, act, slope)));
+    else bound = fmaxf(fabsf(hi), fabsf(lo));
+    return bound * mmax;
+}
+
+// largest magnitude a scale slot holds
+__device__ __forceinline__ float slot_max(const float* slot) {
+    const int lane = (threadIdx.y * blockDim.x + threadIdx.x) & (HN_SCALE_WORDS - 1);
+    unsigned m = reinterpret_cast<const unsigned*>(slot)[lane * HN_SCALE_STRIDE];
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)m));
 }
 
 // sums[0:C] += sum du ; sums[C:2C] += sum du*xhat ; sums[2C] += dslope   (double accumulation throughout)
@@ -163,15 +211,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                int64_t npix, int C, int act, const float* slope_p, float leaky,
                                                                double* __restrict__ sums, const float* __restrict__ mask,
-                                                               int64_t hw, const unsigned char* __restrict__ rbits) {
+                                                               int64_t hw, const unsigned char* __restrict__ rbits,
+                                                               unsigned* __restrict__ gmax = nullptr) {
     __shared__ double red[2 * 256 * 4 + 256];
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     const bool live = c < C;
     float sc[V], sh[V], mu[V], is[V];
     double s1[V], s2[V];
     double dslope = 0.0;
+    unsigned gm[V];  // largest |du| of the channel seen by this thread (bound of dy, optional)
 #pragma unroll
-    for (int i = 0; i < V; ++i) { sc[i] = sh[i] = mu[i] = is[i] = 0.f; s1[i] = s2[i] = 0.0; }
+    for (int i = 0; i < V; ++i) { sc[i] = sh[i] = mu[i] = is[i] = 0.f; s1[i] = s2[i] = 0.0; gm[i] = 0u; }
     if (live) {
         ldv<V>(scale + c, sc);
         ldv<V>(shift + c, sh);
@@ -218,6 +268,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
             for (int i = 0; i < V; ++i) {
                 s1[i] += (double)du[i];
                 s2[i] += (double)(du[i] * ((yy[i] - mu[i]) * is[i]));
+                gm[i] = max(gm[i], __float_as_uint(du[i]) & 0x7fffffffu);
             }
         }
     }
@@ -246,6 +297,21 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
             unsafeAtomicAdd(rep + C + c + i, b);
         }
     }
+    if (gmax != nullptr) {  // block maximum per channel through LDS (re-using the reduction buffer), one atomic per channel
+        __syncthreads();
+        unsigned* rg = reinterpret_cast<unsigned*>(red);
+#pragma unroll
+        for (int i = 0; i < V; ++i) rg[(ty * bx + tx) * V + i] = gm[i];
+        __syncthreads();
+        if (ty == 0 && live) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                unsigned m = 0u;
+                for (int k = 0; k < by; ++k) m = max(m, rg[(k * bx + tx) * V + i]);
+                if (m != 0u) atomicMax(gmax + (size_t)(blockIdx.y % HN_STAT_REPLICAS) * C + c + i, m);
+            }
+        }
+    }
     if (act == HN_ACT_PRELU) {
         if (ty == 0 && tx == 0) {
             double a = 0.0;
@@ -259,10 +325,48 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
 // reduction can accumulate into it
 // (bn backward: n = 2C+1 = dbeta | dgamma | dslope; the three optional pointers receive the same values where the
 // caller wants them -- the parameters' gradient slots -- so that no copy / accumulation kernel follows)
+// `gmax` (optional, with dy_slot): per-channel max |du| replicas from the reduction kernel (consumed and re-zeroed here) ->
+// bound of |dy| = |gamma invstd| (max|du| + |dbeta| / count + max|xhat| |dgamma| / count) over the channels, published into
+// dy_slot BEFORE the apply pass writes dy as a plane tensor with that scale.
 __global__ void f64_to_f32_reset_kernel(double* __restrict__ in, float* __restrict__ out, int n, int C,
                                         float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dslope,
-                                        int accumulate) {
+                                        int accumulate, unsigned* __restrict__ gmax = nullptr,
+                                        const float* __restrict__ gamma = nullptr, const float* __restrict__ invstd = nullptr,
+                                        const float* __restrict__ xhat_max = nullptr, float inv_count = 0.f,
+                                        float* __restrict__ dy_slot = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gmax != nullptr) {  // (uniform) thread i < C finishes BOTH sums of channel i (no other thread touches them), 2C: dslope
+        unsigned bits = 0u;
+        if (i < C || i == 2 * C) {
+            const int e1 = i < C ? C + i : i;  // second entry of this thread (the channel's dgamma sum); dslope: itself
+            double a = 0.0, b = 0.0;
+            unsigned g = 0u;
+#pragma unroll
+            for (int r = 0; r < HN_STAT_REPLICAS; ++r) {
+                a += in[(size_t)r * n + i];
+                in[(size_t)r * n + i] = 0.0;
+                if (i < C) {
+                    b += in[(size_t)r * n + e1];
+                    in[(size_t)r * n + e1] = 0.0;
+                    g = max(g, gmax[(size_t)r * C + i]);
+                    gmax[(size_t)r * C + i] = 0u;
+                }
+            }
+            const float va = (float)a, vb = (float)b;
+            out[i] = va;
+            if (i < C) {
+                out[e1] = vb;
+                if (dbeta != nullptr) dbeta[i] = accumulate ? dbeta[i] + va : va;
+                if (dgamma != nullptr) dgamma[i] = accumulate ? dgamma[i] + vb : vb;
+                const float bound = fabsf(gamma[i] * invstd[i]) * (__uint_as_float(g) + fabsf(va) * inv_count + xhat_max[i] * fabsf(vb) * inv_count);
+                bits = __float_as_uint(bound) & 0x7fffffffu;
+            } else if (dslope != nullptr) {
+                *dslope = accumulate ? *dslope + va : va;
+            }
+        }
+        hn_absmax_publish(bits, dy_slot);
+        return;
+    }
     if (i < n) {
         double a = 0.0;
 #pragma unroll
@@ -278,7 +382,7 @@ __global__ void f64_to_f32_reset_kernel(double* __restrict__ in, float* __restri
     }
 }
 
-template <int V>
+template <int V, bool DP = false>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __restrict__ dz, int lddz,
                                                               const float* __restrict__ z, int ldz,
                                                               const float* __restrict__ y, int ldy,
@@ -289,9 +393,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
                                                               float* __restrict__ dres, int lddr, int64_t npix, int C, int act,
                                                               const float* slope_p, float leaky, const float* __restrict__ mask,
                                                               int64_t hw, float* __restrict__ dy_scale,
-                                                              const unsigned char* __restrict__ rbits) {
+                                                              const unsigned char* __restrict__ rbits,
+                                                              PlaneOut dp = PlaneOut{nullptr, 0, 0, nullptr}) {
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     unsigned amax = 0u;  // largest |dy| written by this thread (f16x2 scale of the output, optional)
+    float ds = 1.f, di = 1.f;
+    if constexpr (DP) hn_h2_scales_of_slot(dp.slot, ds, di);
     if (c < C) {
     float sc[V], sh[V], mu[V], is[V], ga[V], m1[V], m2[V];
     ldv<V>(scale + c, sc);
@@ -337,7 +444,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
             o[i] = ga[i] * (du[i] - m1[i] - (yy[i] - mu[i]) * is[i] * m2[i]);
             amax = max(amax, __float_as_uint(o[i]) & 0x7fffffffu);
         }
-        stv<V>(dy + pix * lddy + c, o);
+        if constexpr (DP) st_planes<V>(dp.hi + pix * dp.ld + c, dp.plane, o, ds);
+        else stv<V>(dy + pix * lddy + c, o);
         if (dres != nullptr) stv<V>(dres + pix * lddr + c, du);
     }
     }
@@ -371,6 +479,55 @@ __global__ void bn_finalize_kernel(double* __restrict__ stats, double inv_count,
     shift[c] = beta[c] - mf * sc;
     if (running_mean != nullptr) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
     if (running_var != nullptr) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+}
+
+// hn_bn_finalize + the bound of the normalised tensor: `keys` are the range keys the convolution epilogue accumulated next to
+// the statistics (per channel max y and max -y, replicated; consumed and re-zeroed here); the bound of
+// |act(bn(y) [+ residual]) * mask| over all channels is published into z_slot and max |xhat| per channel is kept for the
+// backward bound.
+__global__ void bn_finalize_range_kernel(double* __restrict__ stats, unsigned* __restrict__ keys, double inv_count, double unbias,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                         float* running_var, float momentum, float eps, float* __restrict__ mean,
+                                         float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
+                                         float* __restrict__ xhat_max, int C, int act, const float* slope_p, float leaky,
+                                         const float* __restrict__ res_slot, float mask_max, float* __restrict__ z_slot) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const float rmax = res_slot != nullptr ? slot_max(res_slot) : 0.f;
+    unsigned bits = 0u;
+    if (c < C) {
+        double s1 = 0.0, s2 = 0.0;
+        unsigned k0 = 0u, k1 = 0u;
+#pragma unroll
+        for (int r = 0; r < HN_STAT_REPLICAS; ++r) {
+            s1 += stats[(size_t)r * 2 * C + c];
+            s2 += stats[(size_t)r * 2 * C + C + c];
+            stats[(size_t)r * 2 * C + c] = 0.0;
+            stats[(size_t)r * 2 * C + C + c] = 0.0;
+            k0 = max(k0, keys[(size_t)r * 2 * C + c]);
+            k1 = max(k1, keys[(size_t)r * 2 * C + C + c]);
+            keys[(size_t)r * 2 * C + c] = 0u;
+            keys[(size_t)r * 2 * C + C + c] = 0u;
+        }
+        const double m = s1 * inv_count;
+        double var = s2 * inv_count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        const float mf = (float)m;
+        mean[c] = mf;
+        invstd[c] = is;
+        const float sc = gamma[c] * is;
+        const float sh = beta[c] - mf * sc;
+        scale[c] = sc;
+        shift[c] = sh;
+        if (running_mean != nullptr) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+        if (running_var != nullptr) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+        // (keys of zero: the channel saw no value -- an empty launch; treat as the single value 0)
+        const float ymax = k0 != 0u ? hn_range_unkey(k0) : 0.f, ymin = k1 != 0u ? -hn_range_unkey(k1) : 0.f;
+        xhat_max[c] = fmaxf(fabsf(ymax - mf), fabsf(ymin - mf)) * is;
+        const float slope = act == HN_ACT_PRELU ? *slope_p : leaky;
+        bits = __float_as_uint(bn_out_bound(ymax, ymin, sc, sh, act, slope, rmax, mask_max)) & 0x7fffffffu;
+    }
+    hn_absmax_publish(bits, z_slot);
 }
 
 __global__ void bn_eval_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -588,12 +745,74 @@ extern "C" int hn_bn_act_fwd(const float* y, int ldy, const float* scale, const 
     return HN_OK;
 }
 
-extern "C" int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+
+namespace {
+// vector width a plane operand allows (8-byte accesses of four fp16 values)
+bool planes_v4(const void* hi, long long plane, int ld) {
+    return hi == nullptr || ((reinterpret_cast<uintptr_t>(hi) & 7u) == 0 && plane % 4 == 0 && ld % 4 == 0);
+}
+const void* const kUnaligned = reinterpret_cast<const void*>(uintptr_t(1));  // forces plan_rows to the scalar plan
+}  // namespace
+
+extern "C" int hn_bn_finalize_range(double* stats, uint32_t* range_keys, int64_t count, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                                    float* invstd, float* scale, float* shift, float* xhat_max, int C, int act,
+                                    const float* slope, float leaky_slope, const float* res_slot, float mask_max, float* z_slot,
+                                    void* stream) {
+    if (!stats || !range_keys || !gamma || !beta || !mean || !invstd || !scale || !shift || !xhat_max || !z_slot || C <= 0 ||
+        count <= 0 || act < 0 || act > 3 || (act == HN_ACT_PRELU && !slope) || !(mask_max > 0.f))
+        return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+    HN_LAUNCH(bn_finalize_range_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, range_keys, 1.0 / (double)count, unbias, gamma,
+              beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, xhat_max, C, act, slope, leaky_slope,
+              res_slot, mask_max, z_slot);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_bn_act_fwd_planes(const float* y, int ldy, const float* scale, const float* shift, const float* residual, int ldr,
+                                    const void* res_planes, int64_t res_plane_elems, int ldrp, const float* res_slot, float* z,
+                                    int ldz, void* z_planes, int64_t z_plane_elems, int ldzp, const float* z_slot, int64_t npix,
+                                    int C, int act, const float* slope, float leaky_slope, const float* mask, int64_t hw,
+                                    unsigned char* relu_bits, void* stream) {
+    if (!y || !scale || !shift || !z_planes || !z_slot || act < 0 || act > 3 || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
+    if (residual && res_planes) return HN_EINVAL;
+    if (res_planes && (!res_slot || res_plane_elems < (npix - 1) * ldrp + C || ldrp < C)) return HN_EINVAL;
+    if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
+    if (bad_rows(npix, C, {ldy, ldzp}) || (z && ldz < C) || (residual && ldr < C) || z_plane_elems < (npix - 1) * ldzp + C)
+        return HN_EINVAL;
+    if ((residual || res_planes) && (act == HN_ACT_PRELU || act == HN_ACT_LEAKY)) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool v4 = planes_v4(z_planes, z_plane_elems, ldzp) && planes_v4(res_planes, res_plane_elems, ldrp);
+    const RowLaunch pl = plan_rows(npix, C, {y, z, residual, scale, shift, mask, v4 ? nullptr : kUnaligned}, {ldy, z ? ldz : 4, residual ? ldr : 4});
+    if (relu_bits != nullptr && pl.V != 4) return HN_EALIGN;
+    const PlaneOut zp{static_cast<unsigned short*>(z_planes), (long long)z_plane_elems, ldzp, z_slot};
+    const PlaneIn rp{static_cast<const unsigned short*>(res_planes), (long long)res_plane_elems, ldrp, res_slot};
+#define HN_LAUNCH_FWDP(RPF)                                                                                                    \
+    do {                                                                                                                        \
+        if (pl.V == 4)                                                                                                          \
+            HN_LAUNCH((bn_act_fwd_kernel<4, true, RPF>), pl.grid, pl.block, 0, s, y, ldy, scale, shift, residual, ldr, z, ldz, npix, \
+                      C, act, slope, leaky_slope, mask, hw, (float*)nullptr, relu_bits, zp, rp);                                \
+        else                                                                                                                    \
+            HN_LAUNCH((bn_act_fwd_kernel<1, true, RPF>), pl.grid, pl.block, 0, s, y, ldy, scale, shift, residual, ldr, z, ldz, npix, \
+                      C, act, slope, leaky_slope, mask, hw, (float*)nullptr, relu_bits, zp, rp);                                \
+    } while (0)
+    if (res_planes) HN_LAUNCH_FWDP(true);
+    else HN_LAUNCH_FWDP(false);
+#undef HN_LAUNCH_FWDP
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+namespace {
+int bn_bwd_reduce_impl(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                                     const float* mean, const float* invstd, const float* scale, const float* shift,
                                     int64_t npix, int C, int act, const float* slope, float leaky_slope, double* sums,
                                     float* dparams, float* dgamma_out, float* dbeta_out, float* dslope_out,
                                     int out_accumulate, const float* mask, int64_t hw, const unsigned char* relu_bits,
-                                    void* stream) {
+                                    void* stream, unsigned* gmax = nullptr, const float* gamma = nullptr,
+                                    const float* xhat_max = nullptr, float inv_count = 0.f, float* dy_slot = nullptr) {
     if (!dz || !y || !mean || !invstd || !scale || !shift || !sums || !dparams || act < 0 || act > 3) return HN_EINVAL;
     if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
     if (act == HN_ACT_PRELU && !slope) return HN_EINVAL;
@@ -618,10 +837,10 @@ extern "C" int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, i
     do {                                                                                                                \
         if (pl.V == 4)                                                                                                  \
             HN_LAUNCH((bn_act_bwd_reduce_kernel<4, ZM, MK>), pl.grid, pl.block, 0, s, dz, lddz, z, ldz, y, ldy, mean, invstd, \
-                      scale, shift, npix, C, act, slope, leaky_slope, sums, mask, hw, relu_bits);                       \
+                      scale, shift, npix, C, act, slope, leaky_slope, sums, mask, hw, relu_bits, gmax);                 \
         else                                                                                                            \
             HN_LAUNCH((bn_act_bwd_reduce_kernel<1, ZM, MK>), pl.grid, pl.block, 0, s, dz, lddz, z, ldz, y, ldy, mean, invstd, \
-                      scale, shift, npix, C, act, slope, leaky_slope, sums, mask, hw, relu_bits);                       \
+                      scale, shift, npix, C, act, slope, leaky_slope, sums, mask, hw, relu_bits, gmax);                 \
     } while (0)
     if (zmask) {
         if (mask != nullptr) HN_LAUNCH_REDUCE(true, true);
@@ -633,10 +852,72 @@ extern "C" int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, i
 #undef HN_LAUNCH_REDUCE
     HN_CHECK_LAUNCH();
     HN_LAUNCH(f64_to_f32_reset_kernel, dim3((2 * C + 1 + 255) / 256), dim3(256), 0, s, sums, dparams, 2 * C + 1, C, dgamma_out,
-              dbeta_out, dslope_out, out_accumulate);
+              dbeta_out, dslope_out, out_accumulate, gmax, gamma, invstd, xhat_max, inv_count, dy_slot);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
+}  // namespace
+
+extern "C" int hn_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                                    const float* mean, const float* invstd, const float* scale, const float* shift,
+                                    int64_t npix, int C, int act, const float* slope, float leaky_slope, double* sums,
+                                    float* dparams, float* dgamma_out, float* dbeta_out, float* dslope_out,
+                                    int out_accumulate, const float* mask, int64_t hw, const unsigned char* relu_bits,
+                                    void* stream) {
+    return bn_bwd_reduce_impl(dz, lddz, z, ldz, y, ldy, mean, invstd, scale, shift, npix, C, act, slope, leaky_slope, sums, dparams,
+                              dgamma_out, dbeta_out, dslope_out, out_accumulate, mask, hw, relu_bits, stream);
+}
+
+extern "C" int hn_bn_act_bwd_reduce_range(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                                          const float* mean, const float* invstd, const float* scale, const float* shift,
+                                          int64_t npix, int C, int act, const float* slope, float leaky_slope, double* sums,
+                                          float* dparams, float* dgamma_out, float* dbeta_out, float* dslope_out,
+                                          int out_accumulate, const float* mask, int64_t hw, const unsigned char* relu_bits,
+                                          uint32_t* du_max, const float* gamma, const float* xhat_max, int64_t count, int training,
+                                          float* dy_slot, void* stream) {
+    if (!du_max || !gamma || !xhat_max || !dy_slot || count <= 0) return HN_EINVAL;
+    return bn_bwd_reduce_impl(dz, lddz, z, ldz, y, ldy, mean, invstd, scale, shift, npix, C, act, slope, leaky_slope, sums, dparams,
+                              dgamma_out, dbeta_out, dslope_out, out_accumulate, mask, hw, relu_bits, stream, du_max, gamma, xhat_max,
+                              training ? (float)(1.0 / (double)count) : 0.f, dy_slot);
+}
+
+namespace {
+int bn_bwd_apply_impl(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                                   const float* mean, const float* invstd, const float* gamma, const float* scale,
+                                   const float* shift, const float* dparams, int64_t count, int training, float* dy,
+                                   int lddy, float* dres, int lddr, int64_t npix, int C, int act, const float* slope,
+                                   float leaky_slope, const float* mask, int64_t hw, float* dy_scale,
+                                   const unsigned char* relu_bits, void* stream, PlaneOut dp = PlaneOut{nullptr, 0, 0, nullptr}) {
+    if (!dz || !y || !mean || !invstd || !gamma || !scale || !shift || (!dy && !dp.hi) || act < 0 || act > 3) return HN_EINVAL;
+    if (dp.hi != nullptr) { dy = nullptr; lddy = C; }
+    if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
+    if ((training && (!dparams || count <= 0)) || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
+    if (bad_rows(npix, C, {lddz, ldy, lddy}) || (dres && lddr < C) || (z && ldz < C)) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool zmask = act == HN_ACT_RELU && z != nullptr && relu_bits == nullptr;  // (z itself is read)
+    const RowLaunch pl =
+        plan_rows(npix, C, {dz, y, dy, dres, zmask ? z : nullptr, mean, invstd, gamma, scale, shift,
+                            planes_v4(dp.hi, dp.plane, dp.ld) ? nullptr : kUnaligned},
+                  {lddz, ldy, lddy, dres ? lddr : 4, zmask ? ldz : 4});
+    if (relu_bits != nullptr && pl.V != 4) return HN_EALIGN;
+    const float inv_count = training ? (float)(1.0 / (double)count) : 0.f;
+    if (dp.hi != nullptr) {
+        if (pl.V == 4)
+            HN_LAUNCH((bn_act_bwd_apply_kernel<4, true>), pl.grid, pl.block, 0, s, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale,
+                      shift, dparams, inv_count, training, dy, lddy, dres, lddr, npix, C, act, slope, leaky_slope, mask, hw,
+                      (float*)nullptr, relu_bits, dp);
+        else
+            HN_LAUNCH((bn_act_bwd_apply_kernel<1, true>), pl.grid, pl.block, 0, s, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale,
+                      shift, dparams, inv_count, training, dy, lddy, dres, lddr, npix, C, act, slope, leaky_slope, mask, hw,
+                      (float*)nullptr, relu_bits, dp);
+    } else {
+        HN_LAUNCH_V(pl, bn_act_bwd_apply_kernel, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, dparams, inv_count,
+                    training, dy, lddy, dres, lddr, npix, C, act, slope, leaky_slope, mask, hw, dy_scale, relu_bits);
+    }
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+}  // namespace
 
 extern "C" int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                                    const float* mean, const float* invstd, const float* gamma, const float* scale,
@@ -644,21 +925,20 @@ extern "C" int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, in
                                    int lddy, float* dres, int lddr, int64_t npix, int C, int act, const float* slope,
                                    float leaky_slope, const float* mask, int64_t hw, float* dy_scale,
                                    const unsigned char* relu_bits, void* stream) {
-    if (!dz || !y || !mean || !invstd || !gamma || !scale || !shift || !dy || act < 0 || act > 3) return HN_EINVAL;
-    if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
-    if ((training && (!dparams || count <= 0)) || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
-    if (bad_rows(npix, C, {lddz, ldy, lddy}) || (dres && lddr < C) || (z && ldz < C)) return HN_EINVAL;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool zmask = act == HN_ACT_RELU && z != nullptr && relu_bits == nullptr;  // (z itself is read)
-    const RowLaunch pl =
-        plan_rows(npix, C, {dz, y, dy, dres, zmask ? z : nullptr, mean, invstd, gamma, scale, shift},
-                  {lddz, ldy, lddy, dres ? lddr : 4, zmask ? ldz : 4});
-    if (relu_bits != nullptr && pl.V != 4) return HN_EALIGN;
-    const float inv_count = training ? (float)(1.0 / (double)count) : 0.f;
-    HN_LAUNCH_V(pl, bn_act_bwd_apply_kernel, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, dparams, inv_count,
-                training, dy, lddy, dres, lddr, npix, C, act, slope, leaky_slope, mask, hw, dy_scale, relu_bits);
-    HN_CHECK_LAUNCH();
-    return HN_OK;
+    return bn_bwd_apply_impl(dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, dparams, count, training, dy, lddy, dres,
+                             lddr, npix, C, act, slope, leaky_slope, mask, hw, dy_scale, relu_bits, stream);
+}
+
+extern "C" int hn_bn_act_bwd_apply_planes(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                                          const float* mean, const float* invstd, const float* gamma, const float* scale,
+                                          const float* shift, const float* dparams, int64_t count, int training, void* dy_planes,
+                                          int64_t dy_plane_elems, int lddp, const float* dy_slot, float* dres, int lddr,
+                                          int64_t npix, int C, int act, const float* slope, float leaky_slope, const float* mask,
+                                          int64_t hw, const unsigned char* relu_bits, void* stream) {
+    if (!dy_planes || !dy_slot || lddp < C || dy_plane_elems < (npix - 1) * lddp + C) return HN_EINVAL;
+    return bn_bwd_apply_impl(dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, dparams, count, training, nullptr, C, dres,
+                             lddr, npix, C, act, slope, leaky_slope, mask, hw, nullptr, relu_bits, stream,
+                             PlaneOut{static_cast<unsigned short*>(dy_planes), (long long)dy_plane_elems, lddp, dy_slot});
 }
 
 extern "C" int hn_channel_sum(const float* x, int ld, int64_t npix, int C, float* out, void* stream) {

@@ -311,9 +311,16 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
 // One thread-iteration owns one INPUT pixel: it reads the 3x3 input neighbourhood once and produces the 2x2 output pixels
 // (2h..2h+1, 2w..2w+1) with the generic weights (bilinear_src: the border clamps come out identically) -- a quarter of
 // the index arithmetic and 9 instead of 16 loads per four outputs.
-template <int V>
+typedef _Float16 h16x4s __attribute__((ext_vector_type(4)));
+
+// PL: the output is written as a plane tensor (hi / lo fp16 images, include/heatnet_hip.h) with the scale of `slot` -- the
+// input's slot: bilinear weights are convex, so the input's magnitude bounds the output's.
+template <int V, bool PL = false>
 __global__ __launch_bounds__(256) void bilinear_up2_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
-                                                              int N, int H, int W, int C) {
+                                                              int N, int H, int W, int C, unsigned short* __restrict__ yh = nullptr,
+                                                              long long yplane = 0, const float* __restrict__ slot = nullptr) {
+    float ps = 1.f, pi = 1.f;
+    if constexpr (PL) hn_h2_scales_of_slot(slot, ps, pi);
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (c >= C) return;
     const int64_t npix = (int64_t)N * H * W;
@@ -345,7 +352,28 @@ __global__ __launch_bounds__(256) void bilinear_up2_fwd_kernel(const float* __re
                 for (int i = 0; i < V; ++i)
                     o[i] = lh0 * (lw0 * g[dh][dw][i] + lw1 * g[dh][dw + 1][i]) +
                            lh1 * (lw0 * g[dh + 1][dw][i] + lw1 * g[dh + 1][dw + 1][i]);
-                stv<V>(y + ((int64_t)(n * 2 * H + 2 * h + dh) * Wo + 2 * w + dw) * ldy + c, o);
+                const int64_t opix = ((int64_t)(n * 2 * H + 2 * h + dh) * Wo + 2 * w + dw);
+                if constexpr (PL) {
+                    unsigned short* dst = yh + opix * ldy + c;
+                    if constexpr (V == 4) {
+                        h16x4s hh, ll;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float xs = o[i] * ps;
+                            hh[i] = (_Float16)xs;
+                            ll[i] = (_Float16)(xs - (float)hh[i]);
+                        }
+                        *reinterpret_cast<h16x4s*>(dst) = hh;
+                        *reinterpret_cast<h16x4s*>(dst + yplane) = ll;
+                    } else {
+                        const float xs = o[0] * ps;
+                        const _Float16 hh = (_Float16)xs;
+                        dst[0] = __builtin_bit_cast(unsigned short, hh);
+                        dst[yplane] = __builtin_bit_cast(unsigned short, (_Float16)(xs - (float)hh));
+                    }
+                } else {
+                    stv<V>(y + opix * ldy + c, o);
+                }
             }
         }
     }
@@ -614,6 +642,24 @@ extern "C" int hn_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N
     const RowLaunch pl = plan_rows((int64_t)N * Hout * Wout, C, {x, y}, {ldx, ldy});
     const float sh = (float)Hin / (float)Hout, sw = (float)Win / (float)Wout;
     HN_LAUNCH_V(pl, bilinear_fwd_kernel, x, ldx, y, ldy, N, Hin, Win, C, Hout, Wout, sh, sw);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_bilinear_up2_planes(const float* x, int ldx, const float* slot, void* y_planes, int64_t plane_elems, int ldp,
+                                      int N, int Hin, int Win, int C, void* stream) {
+    if (!x || !slot || !y_planes || bad_geom(N, Hin, Win, C, 2 * Hin, 2 * Win, ldx, ldp)) return HN_EINVAL;
+    if (plane_elems < ((int64_t)N * 4 * Hin * Win - 1) * ldp + C) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool v4 = (reinterpret_cast<uintptr_t>(y_planes) & 7u) == 0 && plane_elems % 4 == 0 && ldp % 4 == 0;
+    const RowLaunch p2 = plan_rows((int64_t)N * Hin * Win, C, {x, v4 ? nullptr : reinterpret_cast<const void*>(uintptr_t(1))}, {ldx});
+    unsigned short* yh = static_cast<unsigned short*>(y_planes);
+    if (p2.V == 4)
+        HN_LAUNCH((bilinear_up2_fwd_kernel<4, true>), p2.grid, p2.block, 0, s, x, ldx, (float*)nullptr, ldp, N, Hin, Win, C, yh,
+                  (long long)plane_elems, slot);
+    else
+        HN_LAUNCH((bilinear_up2_fwd_kernel<1, true>), p2.grid, p2.block, 0, s, x, ldx, (float*)nullptr, ldp, N, Hin, Win, C, yh,
+                  (long long)plane_elems, slot);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

@@ -86,20 +86,33 @@ class HnBatchNorm2d(_NoDataParallel, nn.BatchNorm2d):
         return self._ws
 
 
-def conv_bn_act(x, conv, bn, act=ops.ACT_NONE, residual=None, prelu_weight=None, passthrough=False, drop_mask=None):
+def conv_bn_act(x, conv, bn, act=ops.ACT_NONE, residual=None, prelu_weight=None, passthrough=False, drop_mask=None,
+                out="f32", mask_max=1.0):
     """conv -> BatchNorm (batch statistics from the conv epilogue) -> (+residual) -> activation.
 
     `passthrough=True` additionally returns an alias of `x` to be used for the block's skip connection: its gradient
-    then joins this conv's data gradient inside the dgrad kernel instead of in a separate elementwise add."""
+    then joins this conv's data gradient inside the dgrad kernel instead of in a separate elementwise add.
+    `out`: "f32" (default), or -- a request the fused f16x2 node honours where it covers the layer, ignored elsewhere --
+    "planes" (the result as a plane tensor: ONLY for tensors whose every consumer is another conv_bn_act / its residual
+    input) or "dual" (fp32 carrying a plane twin).  `x` and `residual` may be plane tensors."""
     s, p, d = conv.geometry()
+    batch_stats = bn.training or bn.running_mean is None
+    if ops.fused_conv_bn_ok(x, conv.weight, s, p, d, batch_stats):
+        if bn.training and bn.num_batches_tracked is not None:
+            bn._pending_batches += 1
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        leaky = 0.0
+        return ops.conv_bn_act_fused(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual,
+                                     prelu_weight, s, p, d, act, leaky, momentum, bn.eps, bn.workspace(x.device), drop_mask,
+                                     passthrough, out, mask_max)
+    x, residual = ops.as_f32(x), ops.as_f32(residual)
     ws = bn.workspace(x.device)
     stats = ws.stats if bn.training else None  # conv epilogue adds into it, hn_bn_finalize re-zeroes
     if stats is not None:
         ws.open_stats()
-    batch_stats = bn.training or bn.running_mean is None
-    out = ops.conv2d(x, conv.weight, conv.bias, s, p, d, want_stats=stats if stats is not None else False,
-                     passthrough=passthrough, zero_bias_grad=batch_stats and conv.bias is not None)
-    y, skip = out if passthrough else (out, None)
+    out_ = ops.conv2d(x, conv.weight, conv.bias, s, p, d, want_stats=stats if stats is not None else False,
+                      passthrough=passthrough, zero_bias_grad=batch_stats and conv.bias is not None)
+    y, skip = out_ if passthrough else (out_, None)
     z = bn(y, residual=residual, act=act, stats=stats, prelu_weight=prelu_weight, drop_mask=drop_mask)
     return (z, skip) if passthrough else z
 

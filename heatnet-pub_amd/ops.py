@@ -34,6 +34,9 @@ def _ptr(t):
 
 
 def _require_gpu(t):
+    if getattr(t, "_hn_planes", None) is not None:
+        raise RuntimeError("heatnet_amd: a plane tensor (fp16 hi / lo images, see PlaneTensor in ops.py) reached an operator "
+                           "that reads fp32; only conv_bn_act / the residual input of bn take that format")
     if not t.is_cuda:
         raise RuntimeError("heatnet_amd operators run on the MI355X only (got a %s tensor); there is no CPU fallback"
                            % t.device)
@@ -589,6 +592,42 @@ class _ConvTimer:
             _conv_prof.append((self.kind, self.flops, self.e0, self.e1, self.shape, self.bytes, self.kname))
 
 
+def _weight_operands(w_in, w, stride, pad, dil, lm, need_dgrad, s):
+    """(planes of w, flipped / transposed fp32 weights, their planes) for a layer whose arithmetic is `lm` -- (None, None, None)
+    under "f32".  Weight operands of the bf16x3 / bf16 / f16x2 kernels: the 16-bit planes of w for the forward and -- when a data
+    gradient will follow -- the flipped / transposed weights (fp32 and planes) for dgrad, all made by ONE launch.  They are
+    kept on the parameter and reused inside a frozen_weights() scope (second pass of a confusion-maximisation step,
+    evaluation loops)."""
+    if lm not in _PLANE_MATHS:
+        return None, None, None
+    lib = _lib.load()
+    cout, cin, kh, kw = w.shape
+    fmt = 1 if lm == "f16x2" else 0
+    want_t = _layer_math("dgrad", cin, cout, kh, kw) in _PLANE_MATHS and need_dgrad
+    leaf = _leaf(w_in) if w is w_in else None
+    key = (w.data_ptr(), w._version, _frozen_scope, stride, pad, dil, fmt)
+    prep = getattr(leaf, "_hn_prep", None) if (leaf is not None and _frozen_depth > 0) else None
+    if prep is None or prep[0] != key or (want_t and prep[2] is None):
+        nw = w.numel()
+        wx3 = torch.empty(3 * x3_plane(nw), device=w.device, dtype=torch.int16)
+        if want_t:
+            wt = torch.empty(nw, device=w.device, dtype=torch.float32)
+            wtx3 = torch.empty(3 * x3_plane(nw), device=w.device, dtype=torch.int16)
+            flip = lib.hn_weight_flip_transpose_h2 if fmt else lib.hn_weight_flip_transpose
+            check(flip(_ptr(w), _ptr(wx3), _ptr(wt), _ptr(wtx3), cout, kh, kw, cin, stride, pad, dil, s),
+                  "hn_weight_flip_transpose")
+        else:
+            wt = wtx3 = None
+            check((lib.hn_split_f16x2 if fmt else lib.hn_split_bf16x3)(_ptr(w), _ptr(wx3), nw, s), "hn_split_planes")
+        prep = (key, wx3, wt, wtx3)
+        if leaf is not None and _frozen_depth > 0:
+            leaf._hn_prep = prep
+            _prep_registry.touch(leaf, (stride, pad, dil), wx3, wt, wtx3, fmt)  # next scope: one batched launch
+    elif leaf is not None:
+        _prep_registry.touch(leaf, (stride, pad, dil), prep[1], prep[2], prep[3], fmt)
+    return prep[1], prep[2], prep[3]
+
+
 # ------------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------------
@@ -616,38 +655,8 @@ class _Conv2d(torch.autograd.Function):
             stats = None
         d = _desc(n, h, wd, cin, ldx, ho, wo, cout, cout, kh, kw, stride, pad, dil)
         s = _stream()
-        ctx.wt = ctx.wtx3 = None
-        wx3 = None
         lm = _layer_math("fwd", cin, cout, kh, kw)  # this layer's arithmetic (f16x2 layers: one plane format for all kinds)
-        fmt = 1 if lm == "f16x2" else 0
-        if lm in _PLANE_MATHS:
-            # Weight operands of the bf16x3 / bf16 / f16x2 kernels: the 16-bit planes of w for the forward and -- when a data
-            # gradient will follow -- the flipped / transposed weights (fp32 and planes) for dgrad, all made by ONE launch.
-            # They are kept on the parameter and reused inside a frozen_weights() scope (second pass of a confusion-
-            # maximisation step, evaluation loops).
-            want_t = _layer_math("dgrad", cin, cout, kh, kw) in _PLANE_MATHS and ctx.needs_input_grad[0]
-            leaf = _leaf(w_in) if w is w_in else None
-            key = (w.data_ptr(), w._version, _frozen_scope, stride, pad, dil, fmt)
-            prep = getattr(leaf, "_hn_prep", None) if (leaf is not None and _frozen_depth > 0) else None
-            if prep is None or prep[0] != key or (want_t and prep[2] is None):
-                nw = w.numel()
-                wx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16)
-                if want_t:
-                    wt = torch.empty(nw, device=x.device, dtype=torch.float32)
-                    wtx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16)
-                    flip = lib.hn_weight_flip_transpose_h2 if fmt else lib.hn_weight_flip_transpose
-                    check(flip(_ptr(w), _ptr(wx3), _ptr(wt), _ptr(wtx3), cout, kh, kw, cin, stride, pad, dil, s),
-                          "hn_weight_flip_transpose")
-                else:
-                    wt = wtx3 = None
-                    check((lib.hn_split_f16x2 if fmt else lib.hn_split_bf16x3)(_ptr(w), _ptr(wx3), nw, s), "hn_split_planes")
-                prep = (key, wx3, wt, wtx3)
-                if leaf is not None and _frozen_depth > 0:
-                    leaf._hn_prep = prep
-                    _prep_registry.touch(leaf, (stride, pad, dil), wx3, wt, wtx3, fmt)  # next scope: one batched launch
-            elif leaf is not None:
-                _prep_registry.touch(leaf, (stride, pad, dil), prep[1], prep[2], prep[3], fmt)
-            _, wx3, ctx.wt, ctx.wtx3 = prep
+        wx3, ctx.wt, ctx.wtx3 = _weight_operands(w_in, w, stride, pad, dil, lm, ctx.needs_input_grad[0], s)
         ctx.lm = lm
         ctx.x_scale = None
         if lm == "f16x2" and _h2_covers(0, d) and x.data_ptr() % 16 == 0:
@@ -956,6 +965,10 @@ class BnWorkspace:
         self.device = device
         buf = torch.zeros(STAT_REPLICAS * (4 * c + 1), device=device, dtype=torch.float64)
         self.stats, self.bwd = buf[:STAT_REPLICAS * 2 * c], buf[STAT_REPLICAS * 2 * c:]
+        # plane-tensor path: range keys of the conv output (forward) and per-channel max |du| (backward); zero between uses
+        # (consumed and re-zeroed by hn_bn_finalize_range / hn_bn_act_bwd_reduce_range; a stale value only loosens a bound)
+        rng = torch.zeros(STAT_REPLICAS * 3 * c, device=device, dtype=torch.int32)
+        self.keys, self.gmax = rng[:STAT_REPLICAS * 2 * c], rng[STAT_REPLICAS * 2 * c:]
         # host-side guards: set while an accumulator may hold partial sums (between the kernel that adds into it and the
         # kernel that consumes + re-zeroes it); if an exception interrupts that window, the next user clears it first
         self.stats_open = self.bwd_open = False
@@ -982,6 +995,316 @@ def bn_act(y, stats, gamma, beta, running_mean, running_var, residual=None, prel
         z._hn_scale = (z._version, z_scale)
     return z
 
+
+
+# ------------------------------------------------------------------------------------------------------
+# plane tensors + the fused conv -> BatchNorm -> activation node (f16x2 arithmetic)
+# ------------------------------------------------------------------------------------------------------
+# A PLANE TENSOR is a torch.Tensor with the logical shape, dtype (fp32) and NHWC strides of the activation it stands for whose
+# BYTES are two fp16 images [2][N*H*W][C]: hi = fp16(t * s), lo = fp16(t * s - hi), s the power of two derived from the scale
+# slot in `t._hn_planes` (include/heatnet_hip.h, "PLANE TENSORS").  It is what the f16x2 kernels otherwise build in registers
+# for every tile that touches an element; written once by the pass that produces the tensor, the convolutions that consume it
+# (csrc/conv_igemm4.hip, conv_wgrad4 in csrc/conv_wgrad.hip) are pure LDS-DMA + MFMA loops.  Only `conv_bn_act` and the
+# residual input of a fused BatchNorm accept plane tensors; every other operator refuses them (`_require_gpu`).  An fp32 tensor
+# may carry a plane TWIN (`t._hn_twin`: same values, both formats) -- layer outputs that are also returned to the caller.
+PLANES = os.environ.get("HEATNET_PLANES", "1") != "0"  # A/B knob: 0 = fp32 tensors everywhere, operands split in the kernels
+
+
+_last_fused = {}  # side channel from _ConvBnAct.forward to its wrapper (the output's scale slot and plane twin)
+
+
+def is_planes(t):
+    return getattr(t, "_hn_planes", None) is not None
+
+
+class _PlanesToTensor(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        return planes_to_tensor(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def as_f32(t):
+    """The activation as an ordinary fp32 tensor: a plane tensor is converted (one pass; gradients pass through unchanged)."""
+    if t is not None and is_planes(t):
+        slot = t._hn_planes
+        out = _PlanesToTensor.apply(t)
+        out._hn_scale = (out._version, slot)
+        return out
+    return t
+
+
+def planes_of(t):
+    """(plane tensor, scale slot) of an activation: itself, its twin, or a twin made now (hn_absmax_scale unless the tensor
+    carries a scale + hn_tensor_to_planes) and remembered on the tensor."""
+    slot = getattr(t, "_hn_planes", None)
+    if slot is not None:
+        return t, slot
+    twin = getattr(t, "_hn_twin", None)
+    if twin is not None and twin[0] == t._version:
+        return twin[1], twin[1]._hn_planes
+    x, ldx = as_nhwc(t)
+    n, c, h, w = x.shape
+    slot = tensor_scale(x, ldx, owner=t)
+    pt = new_nhwc(n, c, h, w, x.device)
+    check(_lib.load().hn_tensor_to_planes(_ptr(x), ldx, n * h * w, c, _ptr(slot), _ptr(pt), n * h * w * c, c, _stream()),
+          "hn_tensor_to_planes")
+    pt._hn_planes = slot
+    t._hn_twin = (t._version, pt)
+    return pt, slot
+
+
+def planes_to_tensor(t):
+    """fp32 values of a plane tensor (diagnostics / tests)."""
+    slot = t._hn_planes
+    n, c, h, w = t.shape
+    out = new_nhwc(n, c, h, w, t.device)
+    check(_lib.load().hn_planes_to_tensor(_ptr(t), n * h * w * c, c, _ptr(slot), _ptr(out), c, n * h * w, c, _stream()),
+          "hn_planes_to_tensor")
+    return out
+
+
+def _plane_variants(cout):
+    # tiles of conv_igemm4: 1 = 128 x 64, 0 = 128 x 128 (two workgroups per CU), 2 = 128 x 256, 3 = 256 x 128 (eight waves)
+    return [1] if cout <= 64 else [0, 1, 2, 3]
+
+
+def _wgrad_plane_candidates(cout, cin):
+    tms = (0, 1) if cout % 128 == 0 else (0,)
+    tns = (0, 1) if cin % 128 == 0 else (0,)
+    return [(split, 4 * tm + 16 * tn) for tm in tms for tn in tns for split in (0, -2, -3, -4)]
+
+
+def fused_conv_bn_ok(x, conv_w, stride, pad, dil, bn_training, shape=None):
+    """Does the fused plane-tensor node cover this conv -> BatchNorm pair?  (f16x2 layer, batch statistics, whole 64-channel
+    blocks both ways, enough pixels that neither the forward nor the data gradient would want split-K)  `shape`: the input's
+    (N, C, H, W) when it differs from x's (a resampling in between)."""
+    if not (PLANES and CONV_MATH == "f16x2" and not _MATH_F32_KINDS and bn_training and x.is_cuda and x.dim() == 4):
+        return False
+    cout, cin, kh, kw = conv_w.shape
+    n, c_in, h, w = shape if shape is not None else x.shape
+    if c_in != cin or cin % 64 != 0 or cout % 64 != 0 or _layer_math("fwd", cin, cout, kh, kw) != "f16x2":
+        return False
+    ho, wo = conv_out_size(h, kh, stride, pad, dil), conv_out_size(w, kw, stride, pad, dil)
+    if h * w < 128 or ho * wo < 128 or n * ho * wo <= 2048 or n * h * w <= 2048 * (4 if stride == 2 else 1):
+        return False
+    if stride not in (1, 2) or (stride == 2 and dil % 2 == 0):
+        return False
+    return n * h * w * cin * 2 < 0xFFFF0000 and n * ho * wo * cout * 2 < 0xFFFF0000 - 64 * cout * 2
+
+
+class _ConvBnAct(torch.autograd.Function):
+    """z = act(bn(conv(x, w) + b) [+ residual]) [* drop_mask] as ONE autograd node; x (and the residual) may be plane tensors,
+    z is written as fp32, as a plane tensor, or both; the gradient dy between the BatchNorm backward and the convolution's
+    backward kernels never leaves the node and is a plane tensor.  cm/models/extractors.py:84-102, cm/models/pspnet.py:28-40."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, residual, prelu_w, cfg):
+        lib = _lib.load()
+        (stride, pad, dil, act, leaky, momentum, eps, ws, drop_mask, passthrough, out_mode, mask_max) = cfg
+        s = _stream()
+        xp, x_slot = planes_of(x)
+        n, cin, h, wd = xp.shape
+        w_in, w = w, weight_ohwi(w)
+        cout, _, kh, kw = w.shape
+        ho, wo = conv_out_size(h, kh, stride, pad, dil), conv_out_size(wd, kw, stride, pad, dil)
+        npix = n * ho * wo
+        dev = xp.device
+        wh, ctx.wt, ctx.wth = _weight_operands(w_in, w, stride, pad, dil, "f16x2", ctx.needs_input_grad[0], s)
+        y = new_nhwc(n, cout, ho, wo, dev)
+        d = _desc(n, h, wd, cin, cin, ho, wo, cout, cout, kh, kw, stride, pad, dil)
+        ws.open_stats()
+        xplane = n * h * wd * cin
+
+        def launch(v, st, keys):
+            check(lib.hn_conv2d_fwd_planes(_ptr(xp), xplane, _ptr(x_slot), _ptr(wh), _ptr(b), _ptr(y), _ptr(st), _ptr(keys),
+                                           ctypes.byref(d), ACT_NONE, 0.0, v, s), "hn_conv2d_fwd_planes")
+        var = _pick("fwd.planes", d, _plane_variants(cout), lambda v: launch(v, None, None))
+        with _ConvTimer("fwd", d, lambda: _plan_name(0, d, 3, _variant(var, 0, 0, 4))):
+            launch(var, ws.stats, ws.keys)
+        # batch statistics -> normalisation constants, and the bound of |z| (the scale z is written with)
+        par = torch.empty(5 * cout, device=dev, dtype=torch.float32)  # mean | invstd | scale | shift | max |xhat|
+        mean, invstd, scale, shift, xhat = (par[i * cout:(i + 1) * cout] for i in range(5))
+        res_p = res_f = None
+        res_slot = None
+        ldr = 0
+        if residual is not None:
+            if act in (ACT_PRELU, ACT_LEAKY):
+                raise RuntimeError("conv_bn_act: a residual input is only supported with ReLU / no activation")
+            if is_planes(residual):
+                res_p, res_slot = residual, residual._hn_planes
+            else:
+                res_f, ldr = as_nhwc(residual)
+                res_slot = tensor_scale(res_f, ldr, owner=residual)
+        z_slot = _new_scale_slot(dev)
+        check(lib.hn_bn_finalize_range(_ptr(ws.stats), _ptr(ws.keys), npix, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                       _ptr(running_var), momentum, eps, _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift),
+                                       _ptr(xhat), cout, act, _ptr(prelu_w), leaky, _ptr(res_slot), mask_max, _ptr(z_slot), s),
+              "hn_bn_finalize_range")
+        ws.stats_open = False
+        zf = new_nhwc(n, cout, ho, wo, dev) if out_mode != "planes" else None
+        zp = new_nhwc(n, cout, ho, wo, dev) if out_mode != "f32" else None
+        if drop_mask is not None:
+            drop_mask = drop_mask.contiguous()
+        rbits = None
+        if act == ACT_RELU and residual is not None and RELU_BITS and any(ctx.needs_input_grad):
+            rbits = torch.empty(npix * (cout // 4), device=dev, dtype=torch.uint8)
+        if zp is not None:
+            check(lib.hn_bn_act_fwd_planes(_ptr(y), cout, _ptr(scale), _ptr(shift), _ptr(res_f), ldr, _ptr(res_p), npix * cout, cout,
+                                           _ptr(res_slot) if res_p is not None else None, _ptr(zf), cout, _ptr(zp), npix * cout,
+                                           cout, _ptr(z_slot), npix, cout, act, _ptr(prelu_w), leaky, _ptr(drop_mask), ho * wo,
+                                           _ptr(rbits), s), "hn_bn_act_fwd_planes")
+            zp._hn_planes = z_slot
+        else:
+            if res_p is not None:
+                raise RuntimeError("conv_bn_act: a plane-tensor residual needs a plane (or dual) output")
+            check(lib.hn_bn_act_fwd(_ptr(y), cout, _ptr(scale), _ptr(shift), _ptr(res_f), ldr, _ptr(zf), cout, npix, cout, act,
+                                    _ptr(prelu_w), leaky, _ptr(drop_mask), ho * wo, None, _ptr(rbits), s), "hn_bn_act_fwd")
+        ctx.cfg = (stride, pad, dil, act, leaky, passthrough, residual is not None, out_mode)
+        ctx.ws, ctx.drop_mask, ctx.x_slot = ws, drop_mask, x_slot
+        ctx.leaves = (_leaf(w_in), _leaf(b), _leaf(gamma), _leaf(beta), _leaf(prelu_w))
+        # z itself is needed by the backward only for a ReLU behind a residual add without the byte mask
+        keep_z = zf if (act == ACT_RELU and residual is not None and rbits is None and zf is not None) else None
+        if act == ACT_RELU and residual is not None and rbits is None and zf is None and any(ctx.needs_input_grad):
+            raise RuntimeError("conv_bn_act: plane-only output behind a residual ReLU needs the byte mask (C % 4, HEATNET_RELU_BITS)")
+        ctx.save_for_backward(xp, w, y, par, gamma, prelu_w, rbits, keep_z)
+        out = zf if zf is not None else zp
+        _last_fused["slot"], _last_fused["twin"] = z_slot, (zp if zf is not None else None)
+        if passthrough:
+            return out, x.view_as(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dz, *extra):
+        lib = _lib.load()
+        xp, w, y, par, gamma, prelu_w, rbits, z = ctx.saved_tensors
+        stride, pad, dil, act, leaky, passthrough, has_res, out_mode = ctx.cfg
+        dskip = extra[0] if (passthrough and extra) else None
+        s = _stream()
+        n, cin, h, wd = xp.shape
+        cout, _, kh, kw = w.shape
+        _, _, ho, wo = y.shape
+        npix = n * ho * wo
+        dev = y.device
+        dz, lddz = as_nhwc(dz)
+        mean, invstd, scale, shift, xhat = (par[i * cout:(i + 1) * cout] for i in range(5))
+        ws = ctx.ws
+        ws.open_bwd()
+        lw, lbias, lg, lb, lp = ctx.leaves
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        # ---- BatchNorm backward: reductions (+ the bound of |dy|), then dy as a plane tensor ----
+        dpar = torch.empty(2 * cout + 1, device=dev, dtype=torch.float32)
+        sg = grad_slot(lg) if (lg is not None and ctx.needs_input_grad[3]) else None
+        sb = grad_slot(lb) if (lb is not None and ctx.needs_input_grad[4]) else None
+        sp = grad_slot(lp) if (lp is not None and prelu_w is not None and ctx.needs_input_grad[8]) else None
+        used = [t for t in (sg, sb, sp) if t is not None]
+        if len({first for _, first in used}) > 1:
+            sg = sb = sp = None
+            used = []
+        accumulate = bool(used) and not used[0][1]
+        dy_slot = _new_scale_slot(dev)
+        check(lib.hn_bn_act_bwd_reduce_range(_ptr(dz), lddz, _ptr(z), cout, _ptr(y), cout, _ptr(mean), _ptr(invstd), _ptr(scale),
+                                             _ptr(shift), npix, cout, act, _ptr(prelu_w), leaky, _ptr(ws.bwd), _ptr(dpar),
+                                             _ptr(sg[0]) if sg else None, _ptr(sb[0]) if sb else None,
+                                             _ptr(sp[0]) if sp else None, int(accumulate), _ptr(ctx.drop_mask), ho * wo,
+                                             _ptr(rbits), _ptr(ws.gmax), _ptr(gamma), _ptr(xhat), npix, 1, _ptr(dy_slot), s),
+              "hn_bn_act_bwd_reduce_range")
+        ws.bwd_open = False
+        dres = new_nhwc(n, cout, ho, wo, dev) if (has_res and ctx.needs_input_grad[7]) else None
+        dx = dw_out = db = None
+        if need_x or need_w or dres is not None:
+            dyp = new_nhwc(n, cout, ho, wo, dev)
+            check(lib.hn_bn_act_bwd_apply_planes(_ptr(dz), lddz, _ptr(z), cout, _ptr(y), cout, _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                                 _ptr(scale), _ptr(shift), _ptr(dpar), npix, 1, _ptr(dyp), npix * cout, cout,
+                                                 _ptr(dy_slot), _ptr(dres), cout, npix, cout, act, _ptr(prelu_w), leaky,
+                                                 _ptr(ctx.drop_mask), ho * wo, _ptr(rbits), s), "hn_bn_act_bwd_apply_planes")
+        d = _desc(n, h, wd, cin, cin, ho, wo, cout, cout, kh, kw, stride, pad, dil)
+        # ---- data gradient ----
+        if need_x:
+            dx = new_nhwc(n, cin, h, wd, dev)
+            add, ldadd = (None, 0) if dskip is None else as_nhwc(dskip)
+
+            def launch(v, ad, ld):
+                check(lib.hn_conv2d_dgrad_planes(_ptr(dyp), npix * cout, _ptr(dy_slot), _ptr(ctx.wth), _ptr(dx), _ptr(ad), ld,
+                                                 ctypes.byref(d), v, s), "hn_conv2d_dgrad_planes")
+            var = _pick("dgrad.planes", d, _plane_variants(cin), lambda v: launch(v, None, 0))
+            with _ConvTimer("dgrad", d, lambda: _plan_name(1, d, 3, _variant(var, 0, 0, 4))):
+                launch(var, add, ldadd)
+        elif dskip is not None:
+            dx = dskip
+        # ---- weight gradient ----
+        if need_w:
+            slot = grad_slot(lw) if lw is not None else None
+            flags = 0
+            if slot is not None and weight_ohwi(slot[0]) is slot[0]:
+                dw = slot[0]
+                flags = 1 if slot[1] else 2
+                dw_out = dw if slot[1] else None
+            else:
+                dw_out = dw = torch.empty((cout, kh, kw, cin), device=dev, dtype=torch.float32).permute(0, 3, 1, 2)
+            xplane = n * h * wd * cin
+
+            def wgrad(dst, sp_, v, fl):
+                check(lib.hn_conv2d_wgrad_planes(_ptr(xp), xplane, _ptr(ctx.x_slot), _ptr(dyp), npix * cout, _ptr(dy_slot), _ptr(dst),
+                                                 ctypes.byref(d), sp_, v, fl, s), "hn_conv2d_wgrad_planes")
+            if DETERMINISTIC:
+                splits = max(1, min(32, npix // 4096))
+                wsp = _det_workspace(dev, splits * dw.numel())
+                with _ConvTimer("wgrad", d, "conv_wgrad4_kernel"):
+                    check(lib.hn_conv2d_wgrad_det_planes(_ptr(xp), xplane, _ptr(ctx.x_slot), _ptr(dyp), npix * cout, _ptr(dy_slot),
+                                                         _ptr(dw), ctypes.byref(d), splits, 0, flags & 2, _ptr(wsp), s),
+                          "hn_conv2d_wgrad_det_planes")
+            else:
+                split, var = _pick("wgrad.planes", d, _wgrad_plane_candidates(cout, cin),
+                                   lambda sv: wgrad(_tune_scratch(dw) if flags else dw, sv[0], sv[1], 0))
+                with _ConvTimer("wgrad", d, "conv_wgrad4_kernel"):
+                    wgrad(dw, split, var, flags)
+        if lbias is not None and ctx.needs_input_grad[2]:
+            # the output is normalised with batch statistics: the bias cancels, its gradient is exactly zero
+            bslot = grad_slot(lbias, accumulate_ok=False)
+            db = bslot[0] if bslot is not None else torch.zeros(cout, device=dev, dtype=torch.float32)
+        elif ctx.needs_input_grad[2]:
+            db = torch.zeros(cout, device=dev, dtype=torch.float32)
+
+        def out(slot_, fallback, needed):
+            if not needed:
+                return None
+            if slot_ is None:
+                return fallback
+            return slot_[0] if slot_[1] else None
+        dgamma = out(sg, dpar[cout:2 * cout], ctx.needs_input_grad[3])
+        dbeta = out(sb, dpar[0:cout], ctx.needs_input_grad[4])
+        dprelu = out(sp, dpar[2 * cout:2 * cout + 1], prelu_w is not None and ctx.needs_input_grad[8])
+        return dx, dw_out, db, dgamma, dbeta, None, None, dres, dprelu, None
+
+
+def conv_bn_act_fused(x, w, b, gamma, beta, running_mean, running_var, residual, prelu_w, stride, pad, dil, act, leaky, momentum,
+                      eps, ws, drop_mask, passthrough, out_mode, mask_max):
+    """See _ConvBnAct.  out_mode: "f32" | "planes" | "dual" (fp32 tensor carrying its plane twin)."""
+    cfg = (int(stride), int(pad), int(dil), int(act), float(leaky), float(momentum), float(eps), ws, drop_mask, bool(passthrough),
+           out_mode, float(mask_max))
+    out = _ConvBnAct.apply(x, w, b, gamma, beta, running_mean, running_var, residual, prelu_w, cfg)
+    z, skip = out if passthrough else (out, None)
+    slot, twin = _last_fused.pop("slot"), _last_fused.pop("twin")
+    if out_mode == "planes":
+        z._hn_planes = slot
+    else:
+        z._hn_scale = (z._version, slot)  # (a bound of max |z|: valid wherever a scale is taken)
+        if twin is not None:
+            z._hn_twin = (z._version, twin)
+    if passthrough:
+        if is_planes(x):
+            skip._hn_planes = x._hn_planes
+        else:
+            tw = getattr(x, "_hn_twin", None)
+            if tw is not None:
+                skip._hn_twin = (skip._version, tw[1])
+            _inherit_scale(skip, x)
+        return z, skip
+    return z
 
 _in_consts = {}
 
@@ -1143,6 +1466,41 @@ class _Bilinear(torch.autograd.Function):
         return dx, None, None
 
 
+class _BilinearUp2Planes(torch.autograd.Function):
+    """F.upsample(x2, bilinear) written as a plane tensor with the input's scale slot (cm/models/pspnet.py:36-37: the
+    upsampled map is read by the block's convolution only)."""
+
+    @staticmethod
+    def forward(ctx, x, slot):
+        lib = _lib.load()
+        x, ldx = as_nhwc(x)
+        n, c, h, w = x.shape
+        y = new_nhwc(n, c, 2 * h, 2 * w, x.device)
+        check(lib.hn_bilinear_up2_planes(_ptr(x), ldx, _ptr(slot), _ptr(y), n * 4 * h * w * c, c, n, h, w, c, _stream()),
+              "hn_bilinear_up2_planes")
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        n, c, h, w = ctx.shape
+        dy, lddy = as_nhwc(dy)
+        dx = new_nhwc(n, c, h, w, dy.device)
+        check(lib.hn_bilinear_bwd(_ptr(dy), lddy, _ptr(dx), c, n, h, w, c, 2 * h, 2 * w, _stream()), "hn_bilinear_bwd")
+        return dx, None
+
+
+def bilinear_up2_planes(x):
+    """Exact x2 bilinear upsampling as a plane tensor (for conv_bn_act only)."""
+    x = as_f32(x)
+    xn, ldx = as_nhwc(x)
+    slot = tensor_scale(xn, ldx, owner=x)
+    y = _BilinearUp2Planes.apply(x, slot)
+    y._hn_planes = slot
+    return y
+
+
 def bilinear(x, size):
     if (CONV_MATH == "f16x2" and x.is_cuda and x.dim() == 4 and getattr(x, "_hn_scale", None) is None and
             int(size[0]) * int(size[1]) > x.shape[2] * x.shape[3] and x.shape[1] % 32 == 0):
@@ -1254,7 +1612,16 @@ class _Concat(torch.autograd.Function):
 
 
 def concat(xs):
-    return _Concat.apply(*xs)
+    xs = [as_f32(x) for x in xs]
+    out = _Concat.apply(*xs)
+    hits = [getattr(x, "_hn_scale", None) for x in xs]
+    if all(h is not None and h[0] == x._version for h, x in zip(hits, xs)):
+        # slot words are bit patterns of non-negative floats: their elementwise maximum bounds the concatenation
+        m = hits[0][1]
+        for h in hits[1:]:
+            m = torch.maximum(m, h[1])
+        out._hn_scale = (out._version, m)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -59,10 +59,16 @@ class PSPUpsample(nn.Module):
     def forward(self, x, drop=None):
         """`drop`: the Dropout2d layer that follows this block in PSPNet; its channel mask is applied in the BN/PReLU
         kernel's output pass instead of by a pass of its own."""
-        p = ops.bilinear(x, (2 * x.size(2), 2 * x.size(3)))
-        mask = drop.mask_for(x.size(0), self.conv[0].out_channels, x.device) if drop is not None else None
-        return conv_bn_act(p, self.conv[0], self.conv[1], ops.ACT_PRELU, prelu_weight=self.conv[2].weight,
-                           drop_mask=mask)
+        conv, bn = self.conv[0], self.conv[1]
+        n, c, h, w = x.shape
+        s_, p_, d_ = conv.geometry()
+        if ops.fused_conv_bn_ok(x, conv.weight, s_, p_, d_, bn.training or bn.running_mean is None, shape=(n, c, 2 * h, 2 * w)):
+            p = ops.bilinear_up2_planes(x)  # read by the convolution only: written as its f16x2 operand
+        else:
+            p = ops.bilinear(x, (2 * h, 2 * w))
+        mask = drop.mask_for(n, conv.out_channels, x.device) if drop is not None else None
+        mask_max = 1.0 / (1.0 - drop.p) if mask is not None else 1.0
+        return conv_bn_act(p, conv, bn, ops.ACT_PRELU, prelu_weight=self.conv[2].weight, drop_mask=mask, mask_max=mask_max)
 
 
 class PSPNet(nn.Module):

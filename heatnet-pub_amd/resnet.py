@@ -30,10 +30,20 @@ def _shortcut(block, x):
 
 def _first_conv(block, x):
     """conv1 + bn1 + ReLU of a residual block.  When a gradient will flow, `x` is re-bound to conv1's pass-through
-    alias, so the skip connection's gradient is added inside conv1's dgrad kernel rather than by a separate pass."""
+    alias, so the skip connection's gradient is added inside conv1's dgrad kernel rather than by a separate pass.
+    The result is only ever read by conv2: a plane tensor where the fused f16x2 node covers the layer."""
     if x.requires_grad:
-        return conv_bn_act(x, block.conv1, block.bn1, ops.ACT_RELU, passthrough=True)
-    return conv_bn_act(x, block.conv1, block.bn1, ops.ACT_RELU), x
+        return conv_bn_act(x, block.conv1, block.bn1, ops.ACT_RELU, passthrough=True, out="planes")
+    return conv_bn_act(x, block.conv1, block.bn1, ops.ACT_RELU, out="planes"), x
+
+
+def run_layer(layer, x):
+    """nn.Sequential of residual blocks: the tensors BETWEEN the blocks are read by the next block only (its conv1, its
+    residual add, its downsample conv) and travel as plane tensors; the layer's output is an fp32 tensor with a plane twin."""
+    blocks = list(layer)
+    for i, blk in enumerate(blocks):
+        x = blk(x, out="planes" if i + 1 < len(blocks) else "dual")
+    return x
 
 
 class BasicBlock(nn.Module):
@@ -49,9 +59,9 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
-        out, x = _first_conv(self, x)
-        return conv_bn_act(out, self.conv2, self.bn2, ops.ACT_RELU, residual=_shortcut(self, x))
+    def forward(self, x, out="f32"):
+        y, x = _first_conv(self, x)
+        return conv_bn_act(y, self.conv2, self.bn2, ops.ACT_RELU, residual=_shortcut(self, x), out=out)
 
 
 class Bottleneck(nn.Module):
@@ -69,10 +79,10 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
-        out, x = _first_conv(self, x)
-        out = conv_bn_act(out, self.conv2, self.bn2, ops.ACT_RELU)
-        return conv_bn_act(out, self.conv3, self.bn3, ops.ACT_RELU, residual=_shortcut(self, x))
+    def forward(self, x, out="f32"):
+        y, x = _first_conv(self, x)
+        y = conv_bn_act(y, self.conv2, self.bn2, ops.ACT_RELU, out="planes")
+        return conv_bn_act(y, self.conv3, self.bn3, ops.ACT_RELU, residual=_shortcut(self, x), out=out)
 
 
 class ResNet(nn.Module):
@@ -136,15 +146,15 @@ class ResNet(nn.Module):
         if not self.late_fusion and modal_2 is not None:
             modal_1 = ops.concat([modal_1, modal_2])  # early fusion: one 4-channel stem
         x_1 = self._stem(self.conv1, self.bn1, modal_1)
-        x_2 = self.layer1(x_1)
-        x_3 = self.layer2(x_2)
+        x_2 = run_layer(self.layer1, x_1)
+        x_3 = run_layer(self.layer2, x_2)
         if self.late_fusion and modal_2 is not None:
             t_1 = self._stem(self.conv1_2, self.bn1_2, modal_2)
-            t_2 = self.layer1_2(t_1)
-            t_3 = self.layer2_2(t_2)
+            t_2 = run_layer(self.layer1_2, t_1)
+            t_3 = run_layer(self.layer2_2, t_2)
             x_3 = ops.concat([x_3, t_3])
-        x_4 = self.layer3(x_3)
-        x_5 = self.layer4(x_4)
+        x_4 = run_layer(self.layer3, x_3)
+        x_5 = run_layer(self.layer4, x_4)
         if not self.dual:
             return x_5, x_4
         if self.late_fusion:

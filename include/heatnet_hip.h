@@ -225,6 +225,43 @@ int hn_conv2d_fwd_scaled_range(const float* x, const float* x_scale, const float
 int hn_conv2d_dgrad_planes(const void* dy_planes, int64_t plane_elems, const float* dy_scale, const void* wt_h2, float* dx,
                            const float* addend, int ldadd, const HnConvDesc* d, int variant, void* stream);
 
+/* hn_bn_finalize that also consumes (and re-zeroes) the `range_keys` the producing convolution accumulated, publishes into
+ * `z_slot` (zero on entry) the bound of |act(y*scale + shift [+ residual]) * mask| over the tensor -- exact when there is no
+ * residual: the extremes of a channel sit at the ends of its range -- and stores max |xhat| per channel in xhat_max [C] (for
+ * the backward bound).  res_slot: the residual's scale slot or NULL; mask_max: the largest Dropout2d factor (1 without). */
+int hn_bn_finalize_range(double* stats, uint32_t* range_keys, int64_t count, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                         float* scale, float* shift, float* xhat_max, int C, int act, const float* slope, float leaky_slope,
+                         const float* res_slot, float mask_max, float* z_slot, void* stream);
+/* hn_bn_act_fwd writing z as a plane tensor with the scale of z_slot (final before the call: hn_bn_finalize_range); the fp32
+ * `z` is optional (NULL: planes only).  The residual may be an fp32 tensor (residual, ldr) or a plane tensor (res_planes,
+ * res_plane_elems, ldrp, res_slot), not both. */
+int hn_bn_act_fwd_planes(const float* y, int ldy, const float* scale, const float* shift, const float* residual, int ldr,
+                         const void* res_planes, int64_t res_plane_elems, int ldrp, const float* res_slot, float* z, int ldz,
+                         void* z_planes, int64_t z_plane_elems, int ldzp, const float* z_slot, int64_t npix, int C, int act,
+                         const float* slope, float leaky_slope, const float* mask, int64_t hw, unsigned char* relu_bits,
+                         void* stream);
+/* hn_bn_act_bwd_reduce that also finds max |du| per channel (du_max: HN_STAT_REPLICAS * C words, zero on entry, zero again
+ * on return) and publishes into dy_slot (zero on entry) the bound |gamma invstd| (max|du| + |dbeta| / count +
+ * max|xhat| |dgamma| / count) of the gradient hn_bn_act_bwd_apply_planes is about to write. */
+int hn_bn_act_bwd_reduce_range(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* mean,
+                               const float* invstd, const float* scale, const float* shift, int64_t npix, int C, int act,
+                               const float* slope, float leaky_slope, double* sums, float* dparams, float* dgamma_out,
+                               float* dbeta_out, float* dslope_out, int out_accumulate, const float* mask, int64_t hw,
+                               const unsigned char* relu_bits, uint32_t* du_max, const float* gamma, const float* xhat_max,
+                               int64_t count, int training, float* dy_slot, void* stream);
+/* hn_bn_act_bwd_apply writing dy as a plane tensor with the scale of dy_slot */
+int hn_bn_act_bwd_apply_planes(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* mean,
+                               const float* invstd, const float* gamma, const float* scale, const float* shift,
+                               const float* dparams, int64_t count, int training, void* dy_planes, int64_t dy_plane_elems,
+                               int lddp, const float* dy_slot, float* dres, int lddr, int64_t npix, int C, int act,
+                               const float* slope, float leaky_slope, const float* mask, int64_t hw,
+                               const unsigned char* relu_bits, void* stream);
+/* F.upsample(x2, bilinear) (cm/models/pspnet.py:36) written as a plane tensor with the INPUT's scale slot (a bound: the
+ * weights are convex). */
+int hn_bilinear_up2_planes(const float* x, int ldx, const float* slot, void* y_planes, int64_t plane_elems, int ldp, int N,
+                           int Hin, int Win, int C, void* stream);
+
 /* Weight gradient with BOTH operands as plane tensors (d->ldx / d->ldy = their pixel strides in fp16 elements); split_k,
  * flags and the deterministic form as for hn_conv2d_wgrad / hn_conv2d_wgrad_det; `variant`: only the tile fields
  * (4 * tm + 16 * tn, 1 = 64-wide, 0 / 2 = 128-wide where the channel counts allow). */

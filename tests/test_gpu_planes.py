@@ -225,3 +225,98 @@ def test_wgrad_planes_bitwise(dev, case):
     # refusal: Cout % 64 != 0
     d32 = _lib.HnConvDesc(n, h, w_, cin, cin, ho, wo, cout - 32, cout, k, k, stride, pad, dil)
     assert lib.hn_conv2d_wgrad_planes(P(xh), xplane, P(xs), P(gh), gplane, P(gs), P(dw1), ctypes.byref(d32), 0, 0, 0, s) == -4
+
+
+FUSED_CASES = [  # cin, cout, k, stride, dil, act, residual ("f32" | "planes" | None), mask, out
+    (64, 128, 1, 1, 1, "relu", None, False, "planes"),
+    (128, 128, 3, 1, 2, "relu", None, False, "planes"),
+    (128, 256, 1, 1, 1, "relu", "f32", False, "dual"),
+    (128, 256, 1, 1, 1, "relu", "planes", False, "planes"),
+    (128, 128, 3, 2, 1, "relu", None, False, "f32"),
+    (64, 256, 1, 2, 1, "none", None, False, "f32"),
+    (128, 64, 3, 1, 1, "prelu", None, True, "f32"),
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES, ids=str)
+def test_fused_conv_bn_act_matches_unfused(dev, case):
+    """layers.conv_bn_act through the fused plane-tensor node (conv_igemm4 + range-bounded scales + plane-writing BatchNorm
+    passes + conv_wgrad4) against the same call with HEATNET_PLANES off (fp32 tensors, operands split in the kernels): outputs,
+    input / residual / parameter gradients and running statistics.  Without a residual the bound equals the maximum, both
+    paths use the same scales and the convolution outputs agree bitwise; with one the scale may differ by a factor of two."""
+    import torch.nn as nn
+    from heatnet_amd import layers, ops
+    cin, cout, k, stride, dil, act, res_kind, use_mask, out_mode = case
+    n, h, w_ = 2, 72, 80
+    pad = dil * (k - 1) // 2
+    ho, wo = ops.conv_out_size(h, k, stride, pad, dil), ops.conv_out_size(w_, k, stride, pad, dil)
+    acts = {"relu": ops.ACT_RELU, "prelu": ops.ACT_PRELU, "none": ops.ACT_NONE}
+    torch.manual_seed(5)
+
+    def run(planes):
+        prev = ops.PLANES
+        ops.PLANES = planes
+        try:
+            conv = layers.HnConv2d(cin, cout, k, stride=stride, padding=pad, dilation=dil, bias=(act == "prelu")).to(dev)
+            bn = layers.HnBatchNorm2d(cout).to(dev)
+            prelu = nn.Parameter(torch.full((1,), 0.25, device=dev)) if act == "prelu" else None
+            g = torch.Generator().manual_seed(7)
+            with torch.no_grad():
+                conv.weight.copy_((torch.randn(conv.weight.shape, generator=g) / np.sqrt(cin * k * k)).to(dev))
+                if conv.bias is not None:
+                    conv.bias.copy_(torch.randn(cout, generator=g).to(dev))
+                bn.weight.copy_((torch.rand(cout, generator=g) + 0.5).to(dev))
+                bn.bias.copy_((torch.randn(cout, generator=g) * 0.3).to(dev))
+            x = F.relu(torch.randn(n, cin, h, w_, generator=g)).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+            res = None
+            res_leaf = None
+            if res_kind is not None:
+                res_leaf = torch.randn(n, cout, ho, wo, generator=g).abs().to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+                res = res_leaf * 1.0  # a non-leaf, as in the network
+                if res_kind == "planes" and planes:
+                    # what a preceding fused block hands over: a plane tensor
+                    class _ToPlanes(torch.autograd.Function):
+                        @staticmethod
+                        def forward(ctx, t):
+                            pt, slot = ops.planes_of(t)
+                            return pt.clone()
+
+                        @staticmethod
+                        def backward(ctx, g_):
+                            return g_
+                    pt, slot = ops.planes_of(res)
+                    res = _ToPlanes.apply(res)
+                    res._hn_planes = slot
+            mask = None
+            if use_mask:
+                mask = (torch.rand(n, cout, generator=g) > 0.3).float().to(dev) / 0.7
+            z = layers.conv_bn_act(x * 1.0, conv, bn, acts[act], residual=res, prelu_weight=prelu, drop_mask=mask,
+                                   out=out_mode, mask_max=1 / 0.7 if use_mask else 1.0)
+            zf = ops.planes_to_tensor(z) if ops.is_planes(z) else z.detach()
+            twin = getattr(z, "_hn_twin", None)
+            if twin is not None:
+                assert float((ops.planes_to_tensor(twin[1]) - z.detach()).abs().max()) <= 2.0 ** -21 * float(z.detach().abs().max())
+            gz = (torch.randn(n, cout, ho, wo, generator=g) * 1e-3).to(dev).contiguous(memory_format=torch.channels_last)
+            z.backward(gz)
+            outs = dict(z=zf, dx=x.grad, dw=conv.weight.grad, dgamma=bn.weight.grad, dbeta=bn.bias.grad,
+                        rm=bn.running_mean.clone(), rv=bn.running_var.clone())
+            if res_leaf is not None:
+                outs["dres"] = res_leaf.grad
+            if prelu is not None:
+                outs["dprelu"] = prelu.grad
+                outs["db"] = conv.bias.grad
+            return {k_: v.detach().float().cpu() for k_, v in outs.items()}
+        finally:
+            ops.PLANES = prev
+    prev_math = ops.set_conv_math("f16x2")
+    try:
+        a, b = run(True), run(False)
+    finally:
+        ops.set_conv_math(prev_math)
+    for key in b:
+        ref = b[key]
+        tol = 2e-6 if key in ("z", "rm", "rv") else 2e-5
+        if key == "dprelu":
+            tol = 1e-3  # one scalar: a sum of 10^5 cancelling terms
+        err = float((a[key] - ref).abs().max())
+        assert err <= tol * max(float(ref.abs().max()), 1e-30), (key, err, float(ref.abs().max()))
