@@ -48,14 +48,17 @@ KERNEL_LABEL = {"f32": "conv_igemm_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x
                 "bf16x3": "conv_igemm_kernel<..,MATH_X3> / conv_wgrad_x3_kernel (6 x v_mfma_f32_16x16x32_bf16 per fp32 "
                           "product; peak = dense bf16 MFMA peak / 6)",
                 "bf16": "conv_igemm2_kernel<..,1,..> / conv_wgrad_x3_kernel<..,1> (one v_mfma_f32_16x16x32_bf16 per product)",
-                "f16x2": "conv_igemm_kernel<..,MATH_H2> / conv_wgrad_x3_kernel<..,2> (3 x v_mfma_f32_16x16x32_f16 per fp32 "
-                         "product; peak = dense fp16 MFMA peak / 3)"}
+                "f16x2": "conv_igemm4_kernel / conv_wgrad4_kernel on plane tensors (all LDS-DMA), conv_igemm{,3}_kernel<..,MATH_H2> / "
+                         "conv_wgrad_x3_kernel<..,2> elsewhere (3 x v_mfma_f32_16x16x32_f16 per fp32 product; peak = dense fp16 "
+                         "MFMA peak / 3)"}
 CONV_MATH_NOTE = {"f32": "f32: v_mfma_f32_32x32x2_f32 on the fp32 operands",
                   "bf16x3": "bf16x3: fp32 operands split exactly into 3 bf16 terms in-kernel, 6 bf16 MFMAs per product, fp32 "
                             "accumulate; error vs fp64 equal to the fp32 MFMA's (profiles/r01_bf16x3_probe.txt)",
-                  "f16x2": "f16x2: fp32 operands scaled per tensor by a power of two and split into 2 fp16 terms in-kernel, 3 "
-                           "fp16 MFMAs per product, fp32 accumulate; error vs fp64 at or below the fp32 MFMA's "
-                           "(profiles/r02_f16x2_accuracy.txt); Cin % 32 != 0 layers on the fp32 MFMA",
+                  "f16x2": "f16x2: fp32 RESULTS from two fp16 terms per operand -- every operand tensor scaled by one power of two "
+                           "(from a bound of its magnitude) and split into hi + lo fp16, by the pass that produces it (plane "
+                           "tensors) or in the kernel; 3 fp16 MFMAs per product, fp32 accumulate; error vs fp64 at or below the "
+                           "fp32 MFMA's (profiles/r02_f16x2_accuracy.txt); elements > 2^18 below their tensor's maximum lose "
+                           "bits (HEATNET_CONV_MATH=bf16x3 has no such range); Cin % 32 != 0 layers on the fp32 MFMA",
                   "bf16": "bf16 (REDUCED precision, BASELINE configs[4]): conv operands rounded to nearest bf16 in the "
                           "loaders, one bf16 MFMA per product, fp32 accumulate; activations in HBM, BatchNorm statistics, "
                           "master weights and optimizer fp32; stems / 13-class head (Cin % 32 != 0) on the fp32 MFMA"}
@@ -351,6 +354,7 @@ def main():
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
+        buckets.reset_exposed()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -360,10 +364,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    comm = None
     if distributed:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        # per rank: time the compute stream idled waiting for gradient collectives (what backward did not hide)
+        t = torch.tensor([elapsed, buckets.exposed_ms(args.steps)], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        comm = {"backend": backend, "world_size": dist.get_world_size(),  # as the process group (RCCL) sees it
+                "comm_exposed_ms": round(float(t[1].item()), 3), "buckets": len(buckets.buckets),
+                "bucket_mib": [round(b["flat"].numel() * 4 / 2 ** 20, 1) for b in buckets.buckets if b["armed"]],
+                "launched_in_backward": buckets.launched_in_backward,
+                "note": "comm_exposed_ms = max over ranks of the mean time per step the compute stream waited for the bucketed "
+                        "all-reduces in finish_step() (events on the compute stream)"}
 
     scale = (args.height * args.width * args.batch) / float(H * W * BS)
     roof = None
@@ -461,7 +473,8 @@ def main():
         out = {"metric": "training images/s at %dx%d RGB+IR, bs=%d/GPU" % (args.height, args.width, args.batch), "value": round(world * args.batch * args.steps / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "bf16" if ops.CONV_MATH == "bf16" else "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": "bf16" if ops.CONV_MATH == "bf16" else "f32", "arithmetic": ops.CONV_MATH,
+               "data": "synthetic", "distributed": comm,
                "config": {"workload": names[args.workload], "global_batch": world * args.batch, "height": args.height,
                           "width": args.width,
                           "parallelism": "dp%d" % world, "optimizer": "RMSprop lr=1e-4 (fused, flat arena)", "weights": "random init",

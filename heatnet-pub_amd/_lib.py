@@ -89,6 +89,7 @@ SIGNATURES = {
     "hn_set_deterministic": [c_int],
     "hn_get_deterministic": [],
     "hn_conv2d_fwd_affine": [P, P, P, P, P, P, P, P, DP, c_int, P],
+    "hn_conv2d_wgrad_plan": [DP, c_int, c_int, ctypes.c_char_p, c_int],
     "hn_conv2d_plan": [c_int, DP, c_int, c_int, ctypes.c_char_p, c_int],
     "hn_pyramid_pool_bwd": [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "hn_ce_fwd": [P, c_int, P, c_i64, c_int, c_i64, P, P],

@@ -128,10 +128,12 @@ struct AccMap {
 // Accumulators start at zero -- or at the addend (a gradient that reached this tensor through another branch): its
 // loads are issued ahead of the operand prologue and their latency disappears behind the first K steps, so the
 // epilogue stays a pure store loop.  The addend never overlaps the output (header contract).
-// `iscale` (f16x2: the product of the operand scales, a power of two): the accumulators live in the scaled domain.
+// `iscale`, `iscale2` (f16x2: the two operand scales, powers of two): the accumulators live in the scaled domain.  The two
+// factors are applied one after the other -- their product can leave the fp32 range (a gradient of ~1e-30 against weights of
+// ~0.1: 2^114 * 2^17) and 0 * inf would turn a zero of the addend into NaN.
 template <int TM, int TN, bool S16>
 __device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[TM][TN], const AccMap<TM, TN, S16>& am,
-                                              const int* rowinfo, int m0, float iscale = 1.f) {
+                                              const int* rowinfo, int m0, float iscale = 1.f, float iscale2 = 1.f) {
     if (p.addend != nullptr && p.cps == 0) {
         const float* __restrict__ add = p.addend;
 #pragma unroll
@@ -143,7 +145,7 @@ __device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[T
                     const int row = am.row(i, r), col = am.col(j, am.c2_of(r));
                     float v = 0.f;
                     if (m0 + row < p.M && col < p.K) v = add[(size_t)rowinfo[row * 4 + 3] * p.ldadd + col];
-                    acc[i][j][r] = v * iscale;
+                    acc[i][j][r] = v * iscale * iscale2;
                 }
             }
         }
@@ -161,10 +163,12 @@ __device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[T
 // The bias is loaded unconditionally (clamped index) and folded in BEFORE any store is issued, and full tiles take a
 // branch-free path: a conditional load inside the store loop makes hipcc wait vmcnt(0) -- i.e. for the previous store --
 // in front of every store.
-// `oscale` (f16x2: 1 / (operand scales), a power of two) takes the accumulators back to the tensor's own scale first.
+// `oscale`, `oscale2` (f16x2: the inverse operand scales, powers of two, applied one after the other -- see conv_init_acc)
+// take the accumulators back to the tensor's own scale first.
 template <int TM, int TN, bool S16, int BM = 64 * TM, int BN = 64 * TN, bool SCALED = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], const AccMap<TM, TN, S16>& am,
-                                              const int* rowinfo, int m0, int tile_m, int split, float oscale = 1.f) {
+                                              const int* rowinfo, int m0, int tile_m, int split, float oscale = 1.f,
+                                              float oscale2 = 1.f) {
     constexpr int NC = AccMap<TM, TN, S16>::NC;
     const int lane = am.lane, n0 = am.n0;
     if constexpr (SCALED) {
@@ -173,7 +177,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] *= oscale;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * oscale * oscale2;
     }
     if (p.cps > 0) {  // split-K partial
 #pragma unroll

@@ -250,12 +250,14 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_kernel(const ConvArgs 
 
     // f16x2: operand scales (powers of two): the gathered tensor is multiplied by a_s as it is split, the weight planes
     // were made from w * w_s; accumulators hold a_s * w_s times the result
-    float a_s = 1.f, o_s = 1.f, i_s = 1.f;
+    float a_s = 1.f, o_s = 1.f, i_s = 1.f, o_s2 = 1.f, i_s2 = 1.f;
     if constexpr (H2) {
         float a_inv;
         hn_h2_scales_of_slot(p.a_scale, a_s, a_inv);  // from the tensor's max |x| bit patterns
-        o_s = a_inv * p.w_scale[1];
-        i_s = a_s * p.w_scale[0];
+        o_s = a_inv;
+        o_s2 = p.w_scale[1];
+        i_s = a_s;
+        i_s2 = p.w_scale[0];
     }
     auto store_lds = [&](int buf, const auto& sva, const auto& svb) {
         if constexpr (X3) {  // single LDS stage: split each staged 16 B (4 consecutive k) into 3 x 8 B of bf16
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_kernel(const ConvArgs 
     const int lr = lane & 31, lh = lane >> 5;
     const AccMap<TM, TN, S16> am{wm, wn, lane, n0};
     f32x16 acc[TM][TN];
-    conv_init_acc<TM, TN, S16>(p, acc, am, rowinfo, m0, i_s);
+    conv_init_acc<TM, TN, S16>(p, acc, am, rowinfo, m0, i_s, i_s2);
     const int total_chunks = (p.Kdim + BK - 1) / BK;
     const int kc_first = p.cps > 0 ? split * p.cps : 0;
     const int nchunks = p.cps > 0 ? min(p.cps, total_chunks - kc_first) : total_chunks;  // >= 1 by construction
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_kernel(const ConvArgs 
     k_step(kc & 1, std::false_type{}, std::false_type{});
     }
 
-    conv_epilogue<TM, TN, S16, BM, BN, H2>(p, acc, am, rowinfo, m0, tile_m, split, o_s);
+    conv_epilogue<TM, TN, S16, BM, BN, H2>(p, acc, am, rowinfo, m0, tile_m, split, o_s, o_s2);
 }
 
 template <int TM, int TN, int MODE, int BK, int MATH = MATH_F32, int WN = 2>

@@ -58,12 +58,14 @@ __global__ __launch_bounds__(512, (conv2_waves<TM, TN, NS, BK>())) void conv_ige
     __syncthreads();
 
     constexpr bool H2 = NS == 2;
-    float a_s = 1.f, o_s = 1.f, i_s = 1.f;  // f16x2 operand scales (conv_igemm.hip)
+    float a_s = 1.f, o_s = 1.f, i_s = 1.f, o_s2 = 1.f, i_s2 = 1.f;  // f16x2 operand scales (conv_igemm.hip)
     if constexpr (H2) {
         float a_inv;
         hn_h2_scales_of_slot(p.a_scale, a_s, a_inv);
-        o_s = a_inv * p.w_scale[1];
-        i_s = a_s * p.w_scale[0];
+        o_s = a_inv;
+        o_s2 = p.w_scale[1];
+        i_s = a_s;
+        i_s2 = p.w_scale[0];
     }
     const int total_chunks = p.Kdim / BK;  // a step never straddles a tap: C % BK == 0
     const int kc_first = p.cps > 0 ? split * p.cps : 0;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(512, (conv2_waves<TM, TN, NS, BK>())) void conv_ige
     // ---- consumers: LDS -> fragments -> MFMA -> epilogue --------------------------------------------------------
     const AccMap<TM, TN, true> am{wm, wn, lane, n0};
     f32x16 acc[TM][TN];
-    conv_init_acc<TM, TN, true>(p, acc, am, rowinfo, m0, i_s);
+    conv_init_acc<TM, TN, true>(p, acc, am, rowinfo, m0, i_s, i_s2);
 
     // lane -> (row lane & 15, k group lane >> 4) of a 16-row block; every block starts at a multiple of 16 rows
     const int frag_off = (lane & 15) * ROW + (((lane >> 4) ^ x3_kflip(lane & 15)) * 16);
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(512, (conv2_waves<TM, TN, NS, BK>())) void conv_ige
         }
         if (kc < nchunks) step(stage0);
     }
-    conv_epilogue<TM, TN, true, 64 * TM, 64 * TN, H2>(p, acc, am, rowinfo, m0, tile_m, split, o_s);
+    conv_epilogue<TM, TN, true, 64 * TM, 64 * TN, H2>(p, acc, am, rowinfo, m0, tile_m, split, o_s, o_s2);
 }
 
 template <int TM, int TN, int NS, int BK>

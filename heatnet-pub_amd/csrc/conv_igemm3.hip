@@ -68,12 +68,14 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm3_kernel(const ConvArgs
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     conv_fill_rowinfo<BM>(p, rowinfo, m0, tid);
     __syncthreads();
-    float a_s = 1.f, o_s = 1.f, i_s = 1.f;  // f16x2 operand scales (conv_igemm.hip)
+    float a_s = 1.f, o_s = 1.f, i_s = 1.f, o_s2 = 1.f, i_s2 = 1.f;  // f16x2 operand scales (conv_igemm.hip)
     if constexpr (H2) {
         float a_inv;
         hn_h2_scales_of_slot(p.a_scale, a_s, a_inv);
-        o_s = a_inv * p.w_scale[1];
-        i_s = a_s * p.w_scale[0];
+        o_s = a_inv;
+        o_s2 = p.w_scale[1];
+        i_s = a_s;
+        i_s2 = p.w_scale[0];
     }
 
     // ---- A operand: 128 rows x 8 pieces of 16 B per K step ------------------------------------------------------
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm3_kernel(const ConvArgs
 
     const AccMap<TM, TN, true> am{wm, wn, lane, n0};
     f32x16 acc[TM][TN];
-    conv_init_acc<TM, TN, true>(p, acc, am, rowinfo, m0, i_s);
+    conv_init_acc<TM, TN, true>(p, acc, am, rowinfo, m0, i_s, i_s2);
 
     const int frag = (lane & 15) * X3_ROW + (((lane >> 4) ^ x3_kflip(lane & 15)) * 16);
     const char* a_frag = As + wm * TM * 32 * X3_ROW + frag;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm3_kernel(const ConvArgs
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last, out-of-range fetches)
 
-    conv_epilogue<TM, TN, true, BM, BN, H2>(p, acc, am, rowinfo, m0, tile_m, 0, o_s);
+    conv_epilogue<TM, TN, true, BM, BN, H2>(p, acc, am, rowinfo, m0, tile_m, 0, o_s, o_s2);
 }
 
 template <int NS, int WN, int SETS>

@@ -69,8 +69,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
     __syncthreads();
     float a_s, a_inv;
     hn_h2_scales_of_slot(p.a_scale, a_s, a_inv);
-    const float o_s = a_inv * p.w_scale[1];
-    const float i_s = a_s * p.w_scale[0];
+    const float o_s = a_inv, o_s2 = p.w_scale[1];  // applied one after the other (conv_common.h)
+    const float i_s = a_s, i_s2 = p.w_scale[0];
 
     // ---- A operand: this lane's rows of the wave's 16-row blocks, source piece after the swizzle ------------------
     const int l_row = lane >> 2;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
 
     const AccMap<TM, TN, true> am{wm, wn, lane, n0};
     f32x16 acc[TM][TN];
-    conv_init_acc<TM, TN, true>(p, acc, am, rowinfo, m0, i_s);
+    conv_init_acc<TM, TN, true>(p, acc, am, rowinfo, m0, i_s, i_s2);
 
     const int frag = (lane & 15) * 64 + (((lane >> 4) ^ hsw((lane >> 2) & 3)) * 16);
     const int a_frag = wm * TM * 32 * 64 + frag;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last, out-of-range DMAs)
 
-    conv_epilogue<TM, TN, true, BM, BN, true>(p, acc, am, rowinfo, m0, tile_m, 0, o_s);
+    conv_epilogue<TM, TN, true, BM, BN, true>(p, acc, am, rowinfo, m0, tile_m, 0, o_s, o_s2);
 }
 
 template <int WM, int WN, int TM, int TN, int NST>

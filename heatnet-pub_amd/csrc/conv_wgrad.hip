@@ -12,6 +12,7 @@
 // pixel tails zero-filled by the hardware range check, pixel coordinates advanced incrementally -- no integer
 // division in the loop), WG_VEC (same with plain global loads, for tensors beyond 4 GiB), WG_SCALAR (any
 // channel count / alignment: 7x7x3 stem, 13- and 1-channel heads).
+#include <cstdio>
 #include <type_traits>
 
 #include "hn_common.h"
@@ -1203,6 +1204,45 @@ extern "C" int hn_conv2d_wgrad_det_planes(const void* x_planes, int64_t x_plane_
     HN_LAUNCH(wgrad_slab_reduce_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0,
               static_cast<hipStream_t>(stream), workspace, dw, n, (int)s, accumulate);
     HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+// The kernel instantiation a weight-gradient launch runs, as rocprofv3 prints it (per-instantiation accounting in bench.py).
+// mode 0: hn_conv2d_wgrad (arithmetic from the variant / library default), 1: hn_conv2d_wgrad_scaled, 2: hn_conv2d_wgrad_planes;
+// 16-byte aligned operands assumed.  Mirrors the dispatch in wgrad_impl / wgrad_planes_impl.
+extern "C" int hn_conv2d_wgrad_plan(const HnConvDesc* d, int mode, int variant, char* name, int name_len) {
+    if (d == nullptr || name == nullptr || name_len <= 0 || mode < 0 || mode > 2 || variant < 0) return HN_EINVAL;
+    const int bk_sel = variant & 3, tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3, math_sel = variant >> 6;
+    if (mode == 2) {
+        if (d->Cin % 64 != 0 || d->Cout % 64 != 0) return HN_ESHAPE;
+        const bool wm = d->Cout % 128 == 0 && tm_sel != 1, wn = d->Cin % 128 == 0 && tn_sel != 1;
+        snprintf(name, name_len, "conv_wgrad4_kernel<%d, %d>", wm ? 2 : 1, wn ? 2 : 1);
+        return HN_OK;
+    }
+    bool wide_m = d->Cout > 64;
+    if (tm_sel) wide_m = tm_sel == 2;
+    const long long x_bytes = (((long long)d->N * d->Hin * d->Win - 1) * d->ldx + d->Cin) * 4;
+    const long long dy_bytes = (((long long)d->N * d->Hout * d->Wout - 1) * d->ldy + d->Cout) * 4;
+    if (d->ldx % 4 == 0 && d->ldy % 4 == 0 && d->Cout % 4 == 0 && d->Cin % 64 == 0) {
+        bool wide_n = d->Cin % 128 == 0;
+        if (tn_sel == 1) wide_n = false;
+        const bool buf_ok = x_bytes < 0xFFFF0000ll && dy_bytes + 64ll * d->ldy * 4 < 0xFFFF0000ll;
+        const int math = mode == 1 ? HN_MATH_F16X2 : (math_sel ? math_sel - 1 : hn_get_conv_math());
+        if (math != HN_MATH_F32 && buf_ok && d->Cout % 64 == 0) {
+            if (d->Cout % 128 != 0) wide_m = false;
+            snprintf(name, name_len, "conv_wgrad_x3_kernel<%d, %d, %d>", wide_m ? 2 : 1, wide_n ? 2 : 1,
+                     math == HN_MATH_F16X2 ? 2 : (math == HN_MATH_BF16 ? 1 : 3));
+            return HN_OK;
+        }
+        if (math == HN_MATH_F16X2) return HN_ESHAPE;
+        snprintf(name, name_len, "conv_wgrad_kernel<%d, %d, %d, %d>", wide_m ? 2 : 1, wide_n ? 2 : 1, buf_ok ? WG_VEC_BUF : WG_VEC,
+                 (buf_ok && bk_sel == 2) ? 16 : 32);
+        return HN_OK;
+    }
+    if (mode == 1) return HN_ESHAPE;
+    bool wide_n = d->KH * d->KW * d->Cin > 64;
+    if (tn_sel) wide_n = tn_sel == 2;
+    snprintf(name, name_len, "conv_wgrad_kernel<%d, %d, %d, 32>", wide_m ? 2 : 1, wide_n ? 2 : 1, WG_SCALAR);
     return HN_OK;
 }
 

@@ -328,45 +328,53 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
 // `gmax` (optional, with dy_slot): per-channel max |du| replicas from the reduction kernel (consumed and re-zeroed here) ->
 // bound of |dy| = |gamma invstd| (max|du| + |dbeta| / count + max|xhat| |dgamma| / count) over the channels, published into
 // dy_slot BEFORE the apply pass writes dy as a plane tensor with that scale.
+__global__ __launch_bounds__(256) void bn_bwd_finish_range_kernel(
+    double* __restrict__ in, float* __restrict__ out, int n, int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ dslope, int accumulate, unsigned* __restrict__ gmax, const float* __restrict__ gamma,
+    const float* __restrict__ invstd, const float* __restrict__ xhat_max, float inv_count, float* __restrict__ dy_slot) {
+    // 16 lanes per channel (one per replica); channel index C stands for the PReLU slope sum (entry 2C)
+    static_assert(HN_STAT_REPLICAS == 16, "lane layout");
+    const int r = threadIdx.x & 15, c = blockIdx.x * 16 + (threadIdx.x >> 4);
+    double a = 0.0, b = 0.0;
+    unsigned g = 0u;
+    if (c < C) {
+        double* pi = in + (size_t)r * n + c;
+        unsigned* pg = gmax + (size_t)r * C + c;
+        a = pi[0]; b = pi[C]; g = pg[0];
+        pi[0] = 0.0; pi[C] = 0.0; pg[0] = 0u;
+    } else if (c == C) {
+        double* pi = in + (size_t)r * n + 2 * C;
+        a = pi[0];
+        pi[0] = 0.0;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+        g = max(g, (unsigned)__shfl_xor((int)g, o));
+    }
+    unsigned bits = 0u;
+    if (r == 0 && c <= C) {
+        const float va = (float)a, vb = (float)b;
+        if (c < C) {
+            out[c] = va;
+            out[C + c] = vb;
+            if (dbeta != nullptr) dbeta[c] = accumulate ? dbeta[c] + va : va;
+            if (dgamma != nullptr) dgamma[c] = accumulate ? dgamma[c] + vb : vb;
+            const float bound = fabsf(gamma[c] * invstd[c]) * (__uint_as_float(g) + fabsf(va) * inv_count + xhat_max[c] * fabsf(vb) * inv_count);
+            bits = __float_as_uint(bound) & 0x7fffffffu;
+        } else {
+            out[2 * C] = va;
+            if (dslope != nullptr) *dslope = accumulate ? *dslope + va : va;
+        }
+    }
+    hn_absmax_publish(bits, dy_slot);
+}
+
 __global__ void f64_to_f32_reset_kernel(double* __restrict__ in, float* __restrict__ out, int n, int C,
                                         float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dslope,
-                                        int accumulate, unsigned* __restrict__ gmax = nullptr,
-                                        const float* __restrict__ gamma = nullptr, const float* __restrict__ invstd = nullptr,
-                                        const float* __restrict__ xhat_max = nullptr, float inv_count = 0.f,
-                                        float* __restrict__ dy_slot = nullptr) {
+                                        int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gmax != nullptr) {  // (uniform) thread i < C finishes BOTH sums of channel i (no other thread touches them), 2C: dslope
-        unsigned bits = 0u;
-        if (i < C || i == 2 * C) {
-            const int e1 = i < C ? C + i : i;  // second entry of this thread (the channel's dgamma sum); dslope: itself
-            double a = 0.0, b = 0.0;
-            unsigned g = 0u;
-#pragma unroll
-            for (int r = 0; r < HN_STAT_REPLICAS; ++r) {
-                a += in[(size_t)r * n + i];
-                in[(size_t)r * n + i] = 0.0;
-                if (i < C) {
-                    b += in[(size_t)r * n + e1];
-                    in[(size_t)r * n + e1] = 0.0;
-                    g = max(g, gmax[(size_t)r * C + i]);
-                    gmax[(size_t)r * C + i] = 0u;
-                }
-            }
-            const float va = (float)a, vb = (float)b;
-            out[i] = va;
-            if (i < C) {
-                out[e1] = vb;
-                if (dbeta != nullptr) dbeta[i] = accumulate ? dbeta[i] + va : va;
-                if (dgamma != nullptr) dgamma[i] = accumulate ? dgamma[i] + vb : vb;
-                const float bound = fabsf(gamma[i] * invstd[i]) * (__uint_as_float(g) + fabsf(va) * inv_count + xhat_max[i] * fabsf(vb) * inv_count);
-                bits = __float_as_uint(bound) & 0x7fffffffu;
-            } else if (dslope != nullptr) {
-                *dslope = accumulate ? *dslope + va : va;
-            }
-        }
-        hn_absmax_publish(bits, dy_slot);
-        return;
-    }
     if (i < n) {
         double a = 0.0;
 #pragma unroll
@@ -485,29 +493,32 @@ __global__ void bn_finalize_kernel(double* __restrict__ stats, double inv_count,
 // the statistics (per channel max y and max -y, replicated; consumed and re-zeroed here); the bound of
 // |act(bn(y) [+ residual]) * mask| over all channels is published into z_slot and max |xhat| per channel is kept for the
 // backward bound.
-__global__ void bn_finalize_range_kernel(double* __restrict__ stats, unsigned* __restrict__ keys, double inv_count, double unbias,
-                                         const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
-                                         float* running_var, float momentum, float eps, float* __restrict__ mean,
-                                         float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
-                                         float* __restrict__ xhat_max, int C, int act, const float* slope_p, float leaky,
-                                         const float* __restrict__ res_slot, float mask_max, float* __restrict__ z_slot) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_finalize_range_kernel(
+    double* __restrict__ stats, unsigned* __restrict__ keys, double inv_count, double unbias, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps, float* __restrict__ mean,
+    float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ xhat_max, int C, int act,
+    const float* slope_p, float leaky, const float* __restrict__ res_slot, float mask_max, float* __restrict__ z_slot) {
+    // 16 lanes per channel, one per replica of the accumulators: one memory round trip, then a 4-step cross-lane reduction
+    static_assert(HN_STAT_REPLICAS == 16, "lane layout");
+    const int r = threadIdx.x & 15, c = blockIdx.x * 16 + (threadIdx.x >> 4);
     const float rmax = res_slot != nullptr ? slot_max(res_slot) : 0.f;
-    unsigned bits = 0u;
+    double s1 = 0.0, s2 = 0.0;
+    unsigned k0 = 0u, k1 = 0u;
     if (c < C) {
-        double s1 = 0.0, s2 = 0.0;
-        unsigned k0 = 0u, k1 = 0u;
+        double* ps = stats + (size_t)r * 2 * C + c;
+        unsigned* pk = keys + (size_t)r * 2 * C + c;
+        s1 = ps[0]; s2 = ps[C]; k0 = pk[0]; k1 = pk[C];
+        ps[0] = 0.0; ps[C] = 0.0; pk[0] = 0u; pk[C] = 0u;  // consumed: zero for the next convolution epilogue
+    }
 #pragma unroll
-        for (int r = 0; r < HN_STAT_REPLICAS; ++r) {
-            s1 += stats[(size_t)r * 2 * C + c];
-            s2 += stats[(size_t)r * 2 * C + C + c];
-            stats[(size_t)r * 2 * C + c] = 0.0;
-            stats[(size_t)r * 2 * C + C + c] = 0.0;
-            k0 = max(k0, keys[(size_t)r * 2 * C + c]);
-            k1 = max(k1, keys[(size_t)r * 2 * C + C + c]);
-            keys[(size_t)r * 2 * C + c] = 0u;
-            keys[(size_t)r * 2 * C + C + c] = 0u;
-        }
+    for (int o = 8; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+        k0 = max(k0, (unsigned)__shfl_xor((int)k0, o));
+        k1 = max(k1, (unsigned)__shfl_xor((int)k1, o));
+    }
+    unsigned bits = 0u;
+    if (c < C && r == 0) {
         const double m = s1 * inv_count;
         double var = s2 * inv_count - m * m;
         if (var < 0.0) var = 0.0;
@@ -764,7 +775,7 @@ extern "C" int hn_bn_finalize_range(double* stats, uint32_t* range_keys, int64_t
         return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-    HN_LAUNCH(bn_finalize_range_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, range_keys, 1.0 / (double)count, unbias, gamma,
+    HN_LAUNCH(bn_finalize_range_kernel, dim3((C + 15) / 16), dim3(256), 0, s, stats, range_keys, 1.0 / (double)count, unbias, gamma,
               beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, xhat_max, C, act, slope, leaky_slope,
               res_slot, mask_max, z_slot);
     HN_CHECK_LAUNCH();
@@ -851,8 +862,12 @@ int bn_bwd_reduce_impl(const float* dz, int lddz, const float* z, int ldz, const
     }
 #undef HN_LAUNCH_REDUCE
     HN_CHECK_LAUNCH();
-    HN_LAUNCH(f64_to_f32_reset_kernel, dim3((2 * C + 1 + 255) / 256), dim3(256), 0, s, sums, dparams, 2 * C + 1, C, dgamma_out,
-              dbeta_out, dslope_out, out_accumulate, gmax, gamma, invstd, xhat_max, inv_count, dy_slot);
+    if (gmax != nullptr)
+        HN_LAUNCH(bn_bwd_finish_range_kernel, dim3((C + 1 + 15) / 16), dim3(256), 0, s, sums, dparams, 2 * C + 1, C, dgamma_out,
+                  dbeta_out, dslope_out, out_accumulate, gmax, gamma, invstd, xhat_max, inv_count, dy_slot);
+    else
+        HN_LAUNCH(f64_to_f32_reset_kernel, dim3((2 * C + 1 + 255) / 256), dim3(256), 0, s, sums, dparams, 2 * C + 1, C, dgamma_out,
+                  dbeta_out, dslope_out, out_accumulate);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

@@ -30,12 +30,19 @@ class GradBuckets:
     unchanged) -- the rehearsal of the RCCL path, its communication stream and its event ordering on a one-GPU box."""
 
     def __init__(self, params=None, bucket_bytes=64 << 20, process_group=None, average=True, arenas=None,
-                 always_exchange=False):
+                 always_exchange=False, tail_bytes=8 << 20):
+        """`tail_bytes`: size of the bucket that holds the FIRST-registered parameters (the stems, layer1): backward reaches
+        them last, so their all-reduce is the one nothing can hide behind -- it is kept short, the others large."""
+        tail_bytes = min(tail_bytes, bucket_bytes)
         self.group = process_group
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.exchange = self.world > 1 or (always_exchange and dist.is_initialized())
         self.launched = 0  # collectives issued so far (diagnostics / tests)
+        self.launched_in_backward = 0  # ... of the current step by the time finish_step() was entered
+        self._step_launched = 0
+        self._exposed = []  # per step: (start, end) events on the compute stream around the wait for the collectives
+        self._exposed_cpu = []  # CPU tensors: wall seconds spent waiting in finish_step()
         self.buckets = []  # dicts: flat, params, pending, work
         self.arenas = list(arenas) if arenas is not None else None
         if arenas is not None:
@@ -54,22 +61,25 @@ class GradBuckets:
                 ends = a.offsets[1:] + [a.numel]  # parameter slots are padded to 256 B; padding stays zero
                 for p, end in zip(a.params, ends):
                     cur.append(p)
-                    if (end - start) * 4 >= bucket_bytes:
+                    if (end - start) * 4 >= (tail_bytes if start == 0 else bucket_bytes):
                         self._adopt(a.grad[start:end], cur, a)
                         start, cur = end, []
                 if cur:
                     self._adopt(a.grad[start:a.numel], cur, a)
         else:
-            order = list(reversed(self.params))  # backward reaches the last-registered parameters first
-            cur, cur_bytes = [], 0
-            for p in order:
+            # cut in registration order (first bucket short, see tail_bytes), fill in reverse: backward reaches the
+            # last-registered parameters first
+            groups, cur, cur_bytes = [], [], 0
+            for p in self.params:
                 cur.append(p)
                 cur_bytes += p.numel() * 4
-                if cur_bytes >= bucket_bytes:
-                    self._seal(cur)
+                if cur_bytes >= (tail_bytes if not groups else bucket_bytes):
+                    groups.append(cur)
                     cur, cur_bytes = [], 0
             if cur:
-                self._seal(cur)
+                groups.append(cur)
+            for g in reversed(groups):
+                self._seal(list(reversed(g)))
         self._hooks = []
         self._index = {}
         for bi, b in enumerate(self.buckets):
@@ -138,6 +148,7 @@ class GradBuckets:
         if not any_armed:
             raise RuntimeError("GradBuckets: no trainable parameters in this phase")
         self._active = True
+        self._step_launched = 0
 
     def _on_grad(self, p):
         if not self._active:
@@ -150,6 +161,7 @@ class GradBuckets:
             self._launch(b)
 
     def _launch(self, b):
+        self._step_launched += 1  # (counted at world size 1 too: the hook protocol is what tests inspect)
         if not self.exchange:
             return
         self.launched += 1
@@ -170,16 +182,49 @@ class GradBuckets:
         """Call after backward: launches buckets that never filled (unused parameters keep zero gradients) and makes
         the compute stream wait for every collective before the optimizer reads the gradients."""
         self._active = False
+        self.launched_in_backward = self._step_launched
         for b in self.buckets:
             if b["armed"] and b["pending"] != 0 and b["work"] is None:
                 b["pending"] = 0
                 self._launch(b)
+        # exposed communication = what the compute stream idles here: events around the wait (GPU), wall time (CPU)
+        ev0 = ev1 = None
+        t0 = None
+        if self.exchange:
+            if self.on_gpu:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(torch.cuda.current_stream(self.device))
+            else:
+                import time
+                t0 = time.perf_counter()
         for b in self.buckets:
             if b["work"] is not None:
                 b["work"].wait()
                 b["work"] = None
         if self.on_gpu and self.exchange:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+            ev1.record(torch.cuda.current_stream(self.device))
+            self._exposed.append((ev0, ev1))
+            del self._exposed[:-256]
+        elif t0 is not None:
+            import time
+            self._exposed_cpu.append(time.perf_counter() - t0)
+            del self._exposed_cpu[:-256]
+
+    def exposed_ms(self, last=None):
+        """Mean time per step the compute stream spent waiting for gradient collectives in finish_step() (the communication
+        backward did not hide), over the last `last` steps (default: all recorded, at most 256).  Synchronises."""
+        if self.on_gpu:
+            pairs = self._exposed[-last:] if last else self._exposed
+            if not pairs:
+                return 0.0
+            torch.cuda.synchronize(self.device)
+            return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+        vals = self._exposed_cpu[-last:] if last else self._exposed_cpu
+        return 1e3 * sum(vals) / len(vals) if vals else 0.0
+
+    def reset_exposed(self):
+        self._exposed, self._exposed_cpu = [], []
 
     def remove(self):
         for h in self._hooks:

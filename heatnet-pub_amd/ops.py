@@ -568,6 +568,13 @@ def _plan_name(kind, d, has_planes, variant):
     return buf.value.decode() if rc >= 0 else "conv_igemm_kernel<?>"
 
 
+def _wgrad_plan_name(d, mode, variant):
+    """The kernel instantiation hn_conv2d_wgrad (mode 0) / _scaled (1) / _planes (2) runs, as rocprofv3 names it."""
+    buf = ctypes.create_string_buffer(128)
+    rc = _lib.load().hn_conv2d_wgrad_plan(ctypes.byref(d), mode, variant, buf, 128)
+    return buf.value.decode() if rc >= 0 else "conv_wgrad_kernel<?>"
+
+
 class _ConvTimer:
     """HIP events on the launch stream (torch's current stream) around one conv-kernel launch."""
 
@@ -711,12 +718,19 @@ class _Conv2d(torch.autograd.Function):
         d = _desc(n, h, wd, cin, ldx, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
         dx = dw = db = None
         fork = None
-        if OVERLAP and _conv_prof is None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
-            fork = torch.cuda.Event()
-            fork.record()  # dy (and the activation backward that produced it) is complete up to here
         lm = ctx.lm  # the layer's arithmetic as decided (and its weight planes made) at forward time
         h2_layer = lm == "f16x2"
         dy_scale = None
+        if OVERLAP and _conv_prof is None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            if h2_layer:
+                # everything the side-stream weight gradient reads must be queued BEFORE the fork event: the operand scales
+                # (an hn_absmax_scale pass, and the zero fill of a fresh slot chunk, run on the main stream)
+                if dy.data_ptr() % 16 == 0:
+                    dy_scale = tensor_scale(dy, lddy)
+                if ctx.x_scale is None and x.data_ptr() % 16 == 0:
+                    ctx.x_scale = tensor_scale(x, ldx)
+            fork = torch.cuda.Event()
+            fork.record()  # dy (and the activation backward that produced it) and the scales are complete up to here
         if ctx.needs_input_grad[0]:
             nw = cin * kh * kw * cout
             wt, wtx3 = ctx.wt, ctx.wtx3  # prepared by the forward (plane arithmetics), else made here
@@ -731,7 +745,7 @@ class _Conv2d(torch.autograd.Function):
             dd = _desc(n, h, wd, cin, cin, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
             add, ldadd = (None, 0) if dskip is None else as_nhwc(dskip)
             if h2_layer and wtx3 is not None and _h2_covers(1, dd) and dy.data_ptr() % 16 == 0:
-                dy_scale = tensor_scale(dy, lddy)
+                dy_scale = dy_scale if dy_scale is not None else tensor_scale(dy, lddy)
 
                 def launch(v, ad, ld):
                     check(lib.hn_conv2d_dgrad_scaled(_ptr(dy), _ptr(dy_scale), _ptr(wt), _ptr(wtx3), _ptr(dx), _ptr(ad), ld,
@@ -790,7 +804,7 @@ class _Conv2d(torch.autograd.Function):
                 splits = max(1, min(32, npix // 4096))
                 wsp = _det_workspace(x.device, splits * dw.numel())
                 var = _variant(1, 0, 0, _MATH_CODES[wm])
-                with _ConvTimer("wgrad", d, "conv_wgrad_*"):
+                with _ConvTimer("wgrad", d, lambda: _wgrad_plan_name(d, 1 if h2_w else 0, var)):
                     wgrad_det(splits, var, flags & 2, wsp)
                 split = None
             else:
@@ -805,7 +819,7 @@ class _Conv2d(torch.autograd.Function):
                 wgrad(dw, split, var, flags, ctypes.c_void_p(side.cuda_stream))
                 main.wait_stream(side)
             else:
-                with _ConvTimer("wgrad", d, "conv_wgrad_*"):
+                with _ConvTimer("wgrad", d, lambda: _wgrad_plan_name(d, 1 if h2_w else 0, var)):
                     wgrad(dw, split, var, flags)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             slot = grad_slot(ctx.b_leaf, accumulate_ok=False) if ctx.b_leaf is not None else None
@@ -1253,14 +1267,14 @@ class _ConvBnAct(torch.autograd.Function):
             if DETERMINISTIC:
                 splits = max(1, min(32, npix // 4096))
                 wsp = _det_workspace(dev, splits * dw.numel())
-                with _ConvTimer("wgrad", d, "conv_wgrad4_kernel"):
+                with _ConvTimer("wgrad", d, lambda: _wgrad_plan_name(d, 2, 0)):
                     check(lib.hn_conv2d_wgrad_det_planes(_ptr(xp), xplane, _ptr(ctx.x_slot), _ptr(dyp), npix * cout, _ptr(dy_slot),
                                                          _ptr(dw), ctypes.byref(d), splits, 0, flags & 2, _ptr(wsp), s),
                           "hn_conv2d_wgrad_det_planes")
             else:
                 split, var = _pick("wgrad.planes", d, _wgrad_plane_candidates(cout, cin),
                                    lambda sv: wgrad(_tune_scratch(dw) if flags else dw, sv[0], sv[1], 0))
-                with _ConvTimer("wgrad", d, "conv_wgrad4_kernel"):
+                with _ConvTimer("wgrad", d, lambda: _wgrad_plan_name(d, 2, var)):
                     wgrad(dw, split, var, flags)
         if lbias is not None and ctx.needs_input_grad[2]:
             # the output is normalised with batch statistics: the bias cancels, its gradient is exactly zero

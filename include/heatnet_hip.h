@@ -291,6 +291,10 @@ int hn_conv2d_dgrad(const float* dy, const float* wt, const void* wt_x3, float* 
 int hn_conv2d_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant,
                     int flags, void* stream);
 
+/* Which kernel a weight-gradient launch runs, by its rocprofv3 name (per-instantiation accounting): mode 0 = hn_conv2d_wgrad,
+ * 1 = hn_conv2d_wgrad_scaled, 2 = hn_conv2d_wgrad_planes; HN_ESHAPE where that entry point would refuse the geometry. */
+int hn_conv2d_wgrad_plan(const HnConvDesc* d, int mode, int variant, char* name, int name_len);
+
 /* Deterministic form (see hn_set_deterministic): the `split_k` (> 0) reduction splits store their partial results to
  * `workspace` (split_k * Cout*KH*KW*Cin floats, caller-owned) with plain stores and a second kernel adds them to dw in a
  * fixed order -- no float atomics, bitwise reproducible.  flags as above (HN_WGRAD_ACCUMULATE: dw += in the same fixed

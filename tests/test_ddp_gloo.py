@@ -215,3 +215,57 @@ def test_param_buckets_refuse_a_changed_trainable_set():
     m.body[0].weight.requires_grad = False
     with pytest.raises(RuntimeError, match="was frozen"):
         b.begin_step()
+
+
+# ---- what backward hides: bucket sizes, launches inside backward, exposed communication -------------------------------------
+
+def _overlap_worker(rank, world, port, ret, use_arena):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from heatnet_amd import ddp, optim
+    torch.manual_seed(0)
+    m = nn.Sequential(nn.Linear(16, 64), nn.ReLU(), nn.Linear(64, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                      nn.Linear(256, 8))  # every parameter is used: every bucket fills inside backward
+    kw = dict(bucket_bytes=64 << 10, tail_bytes=2 << 10)
+    if use_arena:
+        arena = optim.ParamArena(list(m.parameters()))
+        b = ddp.GradBuckets(arenas=[arena], **kw)
+    else:
+        b = ddp.GradBuckets(list(m.parameters()), **kw)
+    first = id(next(m.parameters()))
+    tail = [bk for bk in b.buckets if first in [id(p) for p in bk["params"]]][0]
+    sizes = [bk["flat"].numel() * 4 for bk in b.buckets]
+    opt = torch.optim.SGD(m.parameters(), lr=0.01)
+    in_bwd = []
+    for _ in range(3):
+        if use_arena:
+            arena.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=False)
+        b.begin_step()
+        m(torch.randn(4, 16)).pow(2).mean().backward()
+        launched_when_backward_returned = b._step_launched
+        b.finish_step()
+        in_bwd.append((launched_when_backward_returned, b.launched_in_backward))
+    ret[rank] = (sizes, tail["flat"].numel() * 4, in_bwd, b.exposed_ms(), b.world)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_arena", [False, True])
+def test_all_buckets_but_none_wait_for_finish_step_and_the_last_arriving_is_small(use_arena):
+    """The bucket that holds the first-registered parameters (reached last by backward) is cut at `tail_bytes`; with every
+    parameter in use, every bucket's all-reduce is issued from the arrival hooks BEFORE backward returns (finish_step() has
+    nothing left to launch); exposed_ms() reports the wait; the group size is what the process group says."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_overlap_worker, args=(world, _free_port(), ret, use_arena), nprocs=world, join=True)
+    for rank in range(world):
+        sizes, tail, in_bwd, exposed, seen = ret[rank]
+        assert len(sizes) >= 3
+        assert tail == min(sizes) and tail <= (2 << 10) + 64 * 16 * 4 + 1024   # tail_bytes + one parameter (+ slot padding)
+        assert max(sizes) >= (64 << 10)
+        for before_finish, recorded in in_bwd:
+            assert before_finish == recorded == len(sizes)
+        assert exposed >= 0.0 and seen == world

@@ -1034,3 +1034,41 @@ def test_bn_relu_byte_mask_equals_reading_z(dev, c):
         ops.RELU_BITS = prev
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("act", ["none", "leaky"])
+def test_overlap_knob_f16x2_weight_gradient(dev, act):
+    """HEATNET_OVERLAP=1 (wgrad on a side stream beside dgrad) under f16x2: the operand scales the side stream reads -- found by
+    hn_absmax_scale passes on the MAIN stream for gradients that do not come out of a BatchNorm backward -- are queued before
+    the fork event (they were not; the weight gradient could read a zero / partial scale).  Same gradients as
+    without the knob, over repeated runs with fresh scale slots."""
+    ops = _ops()
+    n, cin, h, w, cout, k = 2, 128, 40, 44, 192, 3
+    x = rnd(n, cin, h, w, seed=91)
+    wt = rnd(cout, cin, k, k, seed=92, scale=1.0 / np.sqrt(cin * k * k))
+    gy = rnd(n, cout, h, w, seed=93) * 1e-5  # small gradients: a missing scale would flush them to fp16 subnormals
+    prev_math = ops.set_conv_math("f16x2")
+    prev_overlap = ops.OVERLAP
+    results = {}
+    try:
+        for overlap in (False, True):
+            ops.OVERLAP = overlap
+            outs = []
+            for rep in range(4 if overlap else 1):
+                xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+                wd = wt.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+                if act == "leaky":
+                    y = ops.conv2d(xd, wd, None, 1, 1, 1, act=ops.ACT_LEAKY, slope=0.2)
+                else:
+                    y = ops.conv2d(xd, wd, None, 1, 1, 1)
+                y.backward(gy.to(dev))
+                torch.cuda.synchronize()
+                outs.append((xd.grad.clone(), wd.grad.clone()))
+            results[overlap] = outs
+    finally:
+        ops.OVERLAP = prev_overlap
+        ops.set_conv_math(prev_math)
+    dx0, dw0 = results[False][0]
+    for dx1, dw1 in results[True]:
+        assert torch.equal(dx0, dx1)
+        close(dw1, dw0, atol=2e-5 * float(dw0.abs().max()), what="dw (float atomics)")
