@@ -455,9 +455,15 @@ def main():
             o2 = optim.FlatRMSprop(a2, lr=1e-4)
             s2 = make_step(wl, m2, o2, batch, None)
             s2()  # priming (kernel-variant lookups, allocator growth)
-            others[wl] = dict(timed(s2, args.batch), unit="pairs/s", dtype="f32",
+            others[wl] = dict(timed(s2, args.batch), unit="pairs/s", dtype="f32", arithmetic=ops.CONV_MATH,
                               workload="configs[2]: confusion-maximisation %s iteration (day+night passes, 6 critics)"
                                        % ("train_seg" if wl == "confmax_seg" else "train_critic"))
+            if not args.no_roofline:  # the same roofline block as the headline's, for this workload's conv launches
+                r2 = measure_conv_roofline(s2, 2, wl, scale=scale, geom=(args.batch, args.height, args.width))
+                others[wl]["roofline"] = {k: r2[k] for k in ("bound", "achieved", "peak", "unit", "frac", "conv_ms_per_step",
+                                                             "conv_tflop_per_step", "reference_op_tflop_per_step",
+                                                             "achieved_vs_reference_op_count", "launches_per_step",
+                                                             "traffic", "by_kind")}
             del s2, o2, a2, m2
             torch.cuda.empty_cache()
     base = None

@@ -82,6 +82,7 @@ SIGNATURES = {
     "hn_bn_act_bwd_apply_planes": [P, c_int, P, c_int, P, c_int, P, P, P, P, P, P, c_i64, c_int, P, c_i64, c_int, P, P, c_int,
                                    c_i64, c_int, c_int, P, c_float, P, c_i64, P, P],
     "hn_bilinear_up2_planes": [P, c_int, P, P, c_i64, c_int, c_int, c_int, c_int, c_int, P],
+    "hn_range_census": [P, P, c_i64, c_int, P, c_i64, c_int, P, P],
     "hn_thermal_augment": [P, P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P, P],
     "hn_thermal_resize": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "hn_set_conv_math": [c_int],

@@ -550,11 +550,12 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
     pl.bk = 32;
     if (a.xh != nullptr) {
         // the gathered operand arrives as fp16 planes: only the all-DMA schedule (conv_igemm4.hip) reads that format.
-        // bk_sel = its tile (0: 128 x 128, or 128 x 64 when there are at most 64 output channels; 1: 128 x 64; 2: 128 x 256;
-        // 3: 256 x 128)
+        // variant & 15 = its tile (0: 128 x 128, or 128 x 64 when there are at most 64 output channels; 1 .. 6: launch_conv4)
         if (math != HN_MATH_F16X2 || !conv4_covers(a)) return HN_ESHAPE;
         pl.family = FAM_V4; pl.math = MATH_H2; pl.mode = MODE_VEC_BUF;
-        pl.wn = bk_sel == 0 ? (a.K <= 64 ? 1 : 0) : bk_sel;
+        const int tile = variant & 15;
+        if (tile > 6) return HN_EINVAL;
+        pl.wn = tile == 0 ? (a.K <= 64 ? 1 : 0) : tile;
         return HN_OK;
     }
     if (math == HN_MATH_F16X2) {

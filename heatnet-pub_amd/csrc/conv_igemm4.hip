@@ -49,6 +49,7 @@ struct T4 {
     static constexpr int QA = BM / 16 / NW, QB = BN / 16 / NW;  // 16-row blocks per wave and stage (per plane)
     static constexpr int LDS = NST * STAGE + BM * 16;
     static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "row blocks must divide over the waves");
+    static_assert(2 * (QA + QB) * (NST - 2) < 64, "vmcnt immediate");
 };
 
 template <int WM, int WN, int TM, int TN, int NST>
@@ -236,12 +237,18 @@ bool conv4_covers(const ConvArgs& a) {
 }
 
 // tile: 0 = 128 x 128 (four waves, two workgroups per CU), 1 = 128 x 64 (four waves 4 x 1), 2 = 128 x 256 (eight waves, three
-// stages, one workgroup per CU), 3 = 256 x 128 (eight waves 4 x 2, three stages)
+// stages, one workgroup per CU), 3 = 256 x 128 (eight waves 4 x 2, three stages); 4 = 128 x 64, 5 = 64 x 128, 6 = 64 x 64 with
+// THREE (6: four) stages and two workgroups per CU: the DMA runs two (three) K steps ahead -- for the layers whose K steps
+// carry little matrix work per byte (1x1 convolutions with few channels on one side), where a distance of one step leaves
+// every step waiting out the memory latency
 int launch_conv4(const ConvArgs& a, int tile, hipStream_t stream) {
     switch (tile) {
         case 1: return launch4<4, 1, 1, 2, 2>(a, stream);
         case 2: return launch4<2, 4, 2, 2, 3>(a, stream);
         case 3: return launch4<4, 2, 2, 2, 3>(a, stream);
+        case 4: return launch4<4, 1, 1, 2, 3>(a, stream);
+        case 5: return launch4<2, 2, 1, 2, 3>(a, stream);
+        case 6: return launch4<2, 2, 1, 1, 4>(a, stream);
         default: return launch4<2, 2, 2, 2, 2>(a, stream);
     }
 }
@@ -251,6 +258,9 @@ const char* conv4_kernel_name(int tile) {
         case 1: return "conv_igemm4_kernel<4, 1, 1, 2, 2>";
         case 2: return "conv_igemm4_kernel<2, 4, 2, 2, 3>";
         case 3: return "conv_igemm4_kernel<4, 2, 2, 2, 3>";
+        case 4: return "conv_igemm4_kernel<4, 1, 1, 2, 3>";
+        case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 3>";
+        case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4>";
         default: return "conv_igemm4_kernel<2, 2, 2, 2, 2>";
     }
 }

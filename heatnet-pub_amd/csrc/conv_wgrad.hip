@@ -770,7 +770,7 @@ __device__ __forceinline__ int x3_piece_at(int k, int pp) {
     return (((pp >> 2) ^ swz) << 2) | ((pp & 3) ^ (((k >> 3) & 1) << 1));
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int NST = 2>
 __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) {
     constexpr int BKP = 32;
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -843,13 +843,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) 
     const long long wrap_h = (long long)p.H * p.W * p.ldx - (long long)p.Ho * step_h;
 
     int fetch_chunk = c_begin;
-    auto dma_chunk = [&](char* st) {  // chunk fetch_chunk -> stage st (zeros past M / outside the image); advances
+    auto dma_chunk = [&](char* st) {  // chunk fetch_chunk -> stage st (zeros past M / outside the image / past this split); advances
         const int p0 = fetch_chunk * BKP;
+        const bool live = fetch_chunk < c_end;
         const unsigned adv = (unsigned)((long long)p0 * p.ldy * 2);
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
             const unsigned off = a_voff[q] + adv;
-            const unsigned vo = off < a_voff[q] ? 0xFFFFFFFFu : off;
+            const unsigned vo = (off < a_voff[q] || !live) ? 0xFFFFFFFFu : off;
             char* dst = st + (wave + 4 * q) * 1024;
             wg_dma16(rsrc_d0, dst, vo);
             wg_dma16(rsrc_d1, dst + PLANE_A, vo);
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) 
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
             const int k = (wave + 4 * q) * ROWS_B + lane / PPR_B;
-            const bool ok = (p0 + k < p.M) & ((unsigned)hq[q] < (unsigned)p.H) & ((unsigned)wq[q] < (unsigned)p.W);
+            const bool ok = live & (p0 + k < p.M) & ((unsigned)hq[q] < (unsigned)p.H) & ((unsigned)wq[q] < (unsigned)p.W);
             const unsigned vo = ok ? (unsigned)(xoff[q] * 2) : x_records;
             char* dst = st + 2 * PLANE_A + (wave + 4 * q) * 1024;
             wg_dma16(rsrc_x0, dst, vo);
@@ -948,15 +949,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) 
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
+    // NST stages, the DMA runs NST - 1 reduction steps ahead (every step issues the same number of DMAs -- out of range past
+    // the end of the split -- so that the counted wait below always means "chunk kc has landed")
+    constexpr int PER_STEP = 2 * (QA + QB);
+    static_assert(PER_STEP * (NST - 2) < 64, "vmcnt immediate");
     const int nch = c_end - c_begin;
     if (nch > 0) {
-        dma_chunk(lds);
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st) dma_chunk(lds + st * STAGE);
+        int st_cur = 0, st_free = NST - 1;
         for (int kc = 0; kc < nch; ++kc) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk kc has landed (this wave's pieces)
-            barrier();                                         // ... everybody's; the other stage is free
-            if (kc + 1 < nch) dma_chunk(lds + ((kc + 1) & 1) * STAGE);
-            k32(lds + (kc & 1) * STAGE);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP * (NST - 2)) : "memory");  // chunk kc has landed (this wave's pieces)
+            barrier();                                                                   // ... everybody's; stage st_free is free
+            dma_chunk(lds + st_free * STAGE);
+            k32(lds + st_cur * STAGE);
+            st_free = st_cur;
+            st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
     const bool full = (co0 + BM <= p.K) && (n0 + BN <= p.Kdim);
@@ -995,12 +1005,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) 
 template <int TM, int TN, int MODE, int BKP, int X3 = 0>
 int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    // X3 == 4: plane tensors, two LDS stages of two fp16 planes per operand (conv_wgrad4_kernel)
-    constexpr int lds = X3 == 4 ? 2 * 2 * BKP * (BM + BN) * 2
-                                : (X3 ? X3 * BKP * (BM + BN) * 2 : 2 * BKP * (BM + BN) * (int)sizeof(float));
-    const void* kern = X3 == 4 ? reinterpret_cast<const void*>(conv_wgrad4_kernel<TM, TN>)
-                               : (X3 ? reinterpret_cast<const void*>(conv_wgrad_x3_kernel<TM, TN, (X3 && X3 != 4) ? X3 : 3>)
-                                     : reinterpret_cast<const void*>(conv_wgrad_kernel<TM, TN, MODE, BKP>));
+    // X3 == 4 / 5: plane tensors, two / three LDS stages of two fp16 planes per operand (conv_wgrad4_kernel)
+    constexpr bool P4 = X3 == 4 || X3 == 5;
+    constexpr int NST4 = X3 == 5 ? 3 : 2;
+    constexpr int lds = P4 ? NST4 * 2 * BKP * (BM + BN) * 2
+                           : (X3 ? X3 * BKP * (BM + BN) * 2 : 2 * BKP * (BM + BN) * (int)sizeof(float));
+    const void* kern = P4 ? reinterpret_cast<const void*>(conv_wgrad4_kernel<TM, TN, NST4>)
+                          : (X3 ? reinterpret_cast<const void*>(conv_wgrad_x3_kernel<TM, TN, (X3 && !P4) ? X3 : 3>)
+                                : reinterpret_cast<const void*>(conv_wgrad_kernel<TM, TN, MODE, BKP>));
     static std::atomic<unsigned long long> configured{0};
     if (hn_ensure_dynamic_lds(kern, lds, configured) != HN_OK) return HN_ELAUNCH;
     a.ntm = (a.K + BM - 1) / BM;
@@ -1024,8 +1036,8 @@ int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     if (a.atomic && !a.dw_zeroed && !a.accumulate) {
         if (hipMemsetAsync(a.dw, 0, (size_t)a.K * a.Kdim * sizeof(float), stream) != hipSuccess) return HN_ELAUNCH;
     }
-    if constexpr (X3 == 4) HN_LAUNCH((conv_wgrad4_kernel<TM, TN>), dim3(tiles * split_k), dim3(256), lds, stream, a);
-    else if constexpr (X3 != 0) HN_LAUNCH((conv_wgrad_x3_kernel<TM, TN, (X3 && X3 != 4) ? X3 : 3>), dim3(tiles * split_k), dim3(256), lds, stream, a);
+    if constexpr (P4) HN_LAUNCH((conv_wgrad4_kernel<TM, TN, NST4>), dim3(tiles * split_k), dim3(256), lds, stream, a);
+    else if constexpr (X3 != 0) HN_LAUNCH((conv_wgrad_x3_kernel<TM, TN, (X3 && !P4) ? X3 : 3>), dim3(tiles * split_k), dim3(256), lds, stream, a);
     else HN_LAUNCH((conv_wgrad_kernel<TM, TN, MODE, BKP>), dim3(tiles * split_k), dim3(256), lds, stream, a);
     HN_CHECK_LAUNCH();
     return HN_OK;
@@ -1171,6 +1183,10 @@ int wgrad_planes_impl(const void* xh, long long xh_plane, const float* x_scale, 
     bool wide_m = d->Cout % 128 == 0, wide_n = d->Cin % 128 == 0;
     if (tm_sel == 1) wide_m = false;
     if (tn_sel == 1) wide_n = false;
+    // variant & 3 == 2: three LDS stages (the DMA two reduction steps ahead) where the tile leaves room for them with two
+    // workgroups per CU, i.e. not on 128 x 128
+    if ((variant & 3) == 2 && !(wide_m && wide_n))
+        return dispatch_wgrad<WG_VEC_BUF, 32, 5>(a, wide_m, wide_n, split_k, static_cast<hipStream_t>(stream));
     return dispatch_wgrad<WG_VEC_BUF, 32, 4>(a, wide_m, wide_n, split_k, static_cast<hipStream_t>(stream));
 }
 }  // namespace
@@ -1216,7 +1232,7 @@ extern "C" int hn_conv2d_wgrad_plan(const HnConvDesc* d, int mode, int variant, 
     if (mode == 2) {
         if (d->Cin % 64 != 0 || d->Cout % 64 != 0) return HN_ESHAPE;
         const bool wm = d->Cout % 128 == 0 && tm_sel != 1, wn = d->Cin % 128 == 0 && tn_sel != 1;
-        snprintf(name, name_len, "conv_wgrad4_kernel<%d, %d>", wm ? 2 : 1, wn ? 2 : 1);
+        snprintf(name, name_len, "conv_wgrad4_kernel<%d, %d, %d>", wm ? 2 : 1, wn ? 2 : 1, (bk_sel == 2 && !(wm && wn)) ? 3 : 2);
         return HN_OK;
     }
     bool wide_m = d->Cout > 64;

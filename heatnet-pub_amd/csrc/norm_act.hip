@@ -701,6 +701,48 @@ __global__ __launch_bounds__(256) void from_planes_kernel(const unsigned short* 
     }
 }
 
+// f16x2 range census of one operand tensor (fp32 with its slot, or a plane tensor): out[0] += elements that are not zero,
+// out[1] += those of them below 2^-18 of the slot's magnitude bound, i.e. |t * s| < 2^-3 -- their `lo` term is an fp16
+// subnormal and they carry fewer than 22 significant bits (include/heatnet_hip.h).
+template <int V, bool PL>
+__global__ __launch_bounds__(256) void range_census_kernel(const float* __restrict__ x, const unsigned short* __restrict__ hi,
+                                                          long long plane, int ld, const float* __restrict__ slot, int64_t npix,
+                                                          int C, unsigned long long* __restrict__ out) {
+    float s, inv;
+    hn_h2_scales_of_slot(slot, s, inv);
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    unsigned nz = 0u, low = 0u;
+    if (c < C) {
+        for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
+            float v[V];
+            if constexpr (PL) ld_planes<V>(hi + pix * ld + c, plane, v, 1.f);  // (hi + lo: the scaled value)
+            else {
+                ldv<V>(x + pix * ld + c, v);
+#pragma unroll
+                for (int i = 0; i < V; ++i) v[i] *= s;
+            }
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float a = fabsf(v[i]);
+                nz += a > 0.f;
+                low += a > 0.f && a < 0.125f;
+            }
+        }
+    }
+    __shared__ unsigned red[2][4];
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    for (int o = 32; o > 0; o >>= 1) {
+        nz += __shfl_xor(nz, o);
+        low += __shfl_xor(low, o);
+    }
+    if ((t & 63) == 0) { red[0][t >> 6] = nz; red[1][t >> 6] = low; }
+    __syncthreads();
+    if (t == 0) {
+        atomicAdd(out, (unsigned long long)red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(out + 1, (unsigned long long)red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
 bool bad_rows(int64_t npix, int C, std::initializer_list<int> lds) {
     if (npix <= 0 || C <= 0) return true;
     for (int ld : lds)
@@ -1084,6 +1126,27 @@ extern "C" int hn_planes_to_tensor(const void* planes, int64_t plane_elems, int 
         pl = plan_rows(npix, C, {reinterpret_cast<const void*>(uintptr_t(1))}, {ldx});
     const unsigned short* ph = static_cast<const unsigned short*>(planes);
     HN_LAUNCH_V(pl, from_planes_kernel, ph, (long long)plane_elems, ldp, scale, x, ldx, npix, C);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_range_census(const float* x, const void* planes, int64_t plane_elems, int ld, const float* scale, int64_t npix,
+                               int C, uint64_t* out, void* stream) {
+    if ((x == nullptr) == (planes == nullptr) || !scale || !out || bad_rows(npix, C, {ld})) return HN_EINVAL;
+    if (planes && plane_elems < (npix - 1) * ld + C) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned short* ph = static_cast<const unsigned short*>(planes);
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(out);
+    if (planes) {
+        const bool v4 = (reinterpret_cast<uintptr_t>(planes) & 7u) == 0 && plane_elems % 4 == 0 && ld % 4 == 0;
+        const RowLaunch pl = plan_rows(npix, C, {v4 ? nullptr : reinterpret_cast<const void*>(uintptr_t(1))}, {4}, 1024);
+        if (pl.V == 4) HN_LAUNCH((range_census_kernel<4, true>), pl.grid, pl.block, 0, s, x, ph, (long long)plane_elems, ld, scale, npix, C, o);
+        else HN_LAUNCH((range_census_kernel<1, true>), pl.grid, pl.block, 0, s, x, ph, (long long)plane_elems, ld, scale, npix, C, o);
+    } else {
+        const RowLaunch pl = plan_rows(npix, C, {x}, {ld}, 1024);
+        if (pl.V == 4) HN_LAUNCH((range_census_kernel<4, false>), pl.grid, pl.block, 0, s, x, ph, 0ll, ld, scale, npix, C, o);
+        else HN_LAUNCH((range_census_kernel<1, false>), pl.grid, pl.block, 0, s, x, ph, 0ll, ld, scale, npix, C, o);
+    }
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

@@ -188,13 +188,93 @@ def _math(kind):
     return "f32" if kind in _MATH_F32_KINDS else CONV_MATH
 
 
-def _layer_math(kind, cin, cout, kh, kw):
+def _layer_math(kind, cin, cout, kh, kw, leaf=None):
     """Arithmetic of one launch kind of one layer: "f16x2" only where both reductions of the layer (forward: KH*KW*Cin,
-    data gradient: KH*KW*Cout) have at least H2_MIN_K terms, else "bf16x3" -- one format of weight planes per layer."""
+    data gradient: KH*KW*Cout) have at least H2_MIN_K terms, else "bf16x3" -- one format of weight planes per layer.
+    `leaf`: the layer's weight parameter -- a layer the range guard moved off f16x2 (`_hn_no_f16x2`) runs bf16x3."""
     m = _math(kind)
-    if m == "f16x2" and (kh * kw * min(cin, cout) < H2_MIN_K or cin % 32 != 0 or cin * cout * kh * kw < 256):
+    if m == "f16x2" and (kh * kw * min(cin, cout) < H2_MIN_K or cin % 32 != 0 or cin * cout * kh * kw < 256 or
+                         getattr(leaf, "_hn_no_f16x2", False)):
         return "bf16x3"
     return m
+
+
+# ---- f16x2 range guard ---------------------------------------------------------------------------------------------------
+# f16x2 keeps 22 significant bits of an operand element only if it lies within 2^-18 of its tensor's magnitude bound; a
+# tensor with a heavy tail (a few huge values over many tiny, non-zero ones) loses bits on the small ones, bf16x3 does not.
+# HEATNET_F16X2_GUARD=<fraction> (e.g. 0.05) turns on a census of every f16x2 operand (hn_range_census: non-zero elements,
+# and those below bound * 2^-18) -- one extra pass over each operand, a diagnostic / safety mode, not the fast path -- and
+# `range_guard_update()` (called by train_step every GUARD_EVERY iterations) moves every layer whose activation or gradient
+# operand had more than that fraction of its non-zero elements in the lossy range over to bf16x3, for good.
+# HEATNET_F16X2_CENSUS=1 only counts (tools/trained_state_f16x2.py); `range_report()` reads the counters.
+RANGE_GUARD = float(os.environ.get("HEATNET_F16X2_GUARD", "0") or 0.0)
+RANGE_CENSUS = RANGE_GUARD > 0 or os.environ.get("HEATNET_F16X2_CENSUS", "0") == "1"
+GUARD_EVERY = int(os.environ.get("HEATNET_F16X2_GUARD_EVERY", "25"))
+_census = {}  # id(weight leaf) -> [weakref, geometry, counters (int64 [2 operands][nonzero, low])]
+guard_moved = []  # (geometry, fraction activations, fraction gradients) of the layers moved to bf16x3 so far
+
+
+def set_range_census(on):
+    global RANGE_CENSUS
+    prev, RANGE_CENSUS = RANGE_CENSUS, bool(on) or RANGE_GUARD > 0
+    return prev
+
+
+def _census_operand(leaf, which, x, planes, ld, slot, npix, c):
+    """Count operand `which` (0: the activation operand of forward / wgrad, 1: the gradient operand of dgrad / wgrad)."""
+    if leaf is None:
+        return
+    e = _census.get(id(leaf))
+    if e is None or e[0]() is not leaf:
+        e = _census[id(leaf)] = [weakref.ref(leaf), tuple(leaf.shape), torch.zeros(4, device=slot.device, dtype=torch.int64)]
+    check(_lib.load().hn_range_census(_ptr(x), _ptr(planes), npix * ld if planes is not None else 0, ld, _ptr(slot), npix, c,
+                                      ctypes.c_void_p(e[2].data_ptr() + 16 * which), _stream()), "hn_range_census")
+
+
+def range_report(reset=False):
+    """[(weight shape, non-zero activations, fraction of them below bound * 2^-18, non-zero gradient elements, fraction)] per
+    f16x2 layer counted since the last reset.  Synchronises."""
+    rows = []
+    for key in list(_census):
+        ref, geom, cnt = _census[key]
+        leaf = ref()
+        if leaf is None:
+            del _census[key]
+            continue
+        v = cnt.tolist()
+        rows.append((geom, v[0], v[1] / v[0] if v[0] else 0.0, v[2], v[3] / v[2] if v[2] else 0.0, leaf))
+        if reset:
+            cnt.zero_()
+    return rows
+
+
+def range_guard_update(threshold=None):
+    """Move every layer with more than `threshold` (default HEATNET_F16X2_GUARD) of an operand's non-zero elements in f16x2's
+    lossy range to bf16x3; returns the layers moved by this call.  Counters start again."""
+    threshold = RANGE_GUARD if threshold is None else threshold
+    moved = []
+    for geom, _, fa, _, fg, leaf in range_report(reset=True):
+        if max(fa, fg) > threshold and not getattr(leaf, "_hn_no_f16x2", False):
+            leaf._hn_no_f16x2 = True
+            leaf._hn_prep = None  # weight planes of the other format are made on next use
+            moved.append((geom, fa, fg))
+    guard_moved.extend(moved)
+    return moved
+
+
+_guard_calls = 0
+
+
+def range_guard_tick():
+    """Called once per training iteration by train_step: every GUARD_EVERY calls the counters are read and layers moved."""
+    global _guard_calls
+    if RANGE_GUARD <= 0:
+        return
+    _guard_calls += 1
+    if _guard_calls % GUARD_EVERY == 0:
+        for geom, fa, fg in range_guard_update():
+            print("heatnet_amd: f16x2 range guard: conv %s -> bf16x3 (%.1f%% of the activation operand, %.1f%% of the gradient "
+                  "operand below bound * 2^-18)" % (geom, 100 * fa, 100 * fg), file=sys.stderr)
 
 
 def set_conv_math(name):
@@ -610,7 +690,7 @@ def _weight_operands(w_in, w, stride, pad, dil, lm, need_dgrad, s):
     lib = _lib.load()
     cout, cin, kh, kw = w.shape
     fmt = 1 if lm == "f16x2" else 0
-    want_t = _layer_math("dgrad", cin, cout, kh, kw) in _PLANE_MATHS and need_dgrad
+    want_t = _layer_math("dgrad", cin, cout, kh, kw, _leaf(w_in)) in _PLANE_MATHS and need_dgrad
     leaf = _leaf(w_in) if w is w_in else None
     key = (w.data_ptr(), w._version, _frozen_scope, stride, pad, dil, fmt)
     prep = getattr(leaf, "_hn_prep", None) if (leaf is not None and _frozen_depth > 0) else None
@@ -662,12 +742,14 @@ class _Conv2d(torch.autograd.Function):
             stats = None
         d = _desc(n, h, wd, cin, ldx, ho, wo, cout, cout, kh, kw, stride, pad, dil)
         s = _stream()
-        lm = _layer_math("fwd", cin, cout, kh, kw)  # this layer's arithmetic (f16x2 layers: one plane format for all kinds)
+        lm = _layer_math("fwd", cin, cout, kh, kw, _leaf(w_in))  # this layer's arithmetic (one plane format for all kinds)
         wx3, ctx.wt, ctx.wtx3 = _weight_operands(w_in, w, stride, pad, dil, lm, ctx.needs_input_grad[0], s)
         ctx.lm = lm
         ctx.x_scale = None
         if lm == "f16x2" and _h2_covers(0, d) and x.data_ptr() % 16 == 0:
             xs = ctx.x_scale = tensor_scale(x, ldx, owner=x_in)
+            if RANGE_CENSUS:
+                _census_operand(_leaf(w_in), 0, x, None, ldx, xs, n * h * wd, cin)
 
             def launch(v, st):
                 check(lib.hn_conv2d_fwd_scaled(_ptr(x), _ptr(xs), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), _ptr(st),
@@ -734,7 +816,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             nw = cin * kh * kw * cout
             wt, wtx3 = ctx.wt, ctx.wtx3  # prepared by the forward (plane arithmetics), else made here
-            dm = lm if lm != "f16x2" else _layer_math("dgrad", cin, cout, kh, kw)
+            dm = lm if lm != "f16x2" else _layer_math("dgrad", cin, cout, kh, kw, ctx.w_leaf)
             if wt is None:
                 wt = torch.empty(nw, device=x.device, dtype=torch.float32)
                 wtx3 = torch.empty(3 * x3_plane(nw), device=x.device, dtype=torch.int16) if dm in _PLANE_MATHS else None
@@ -746,6 +828,8 @@ class _Conv2d(torch.autograd.Function):
             add, ldadd = (None, 0) if dskip is None else as_nhwc(dskip)
             if h2_layer and wtx3 is not None and _h2_covers(1, dd) and dy.data_ptr() % 16 == 0:
                 dy_scale = dy_scale if dy_scale is not None else tensor_scale(dy, lddy)
+                if RANGE_CENSUS:
+                    _census_operand(ctx.w_leaf, 1, dy, None, lddy, dy_scale, npix, cout)
 
                 def launch(v, ad, ld):
                     check(lib.hn_conv2d_dgrad_scaled(_ptr(dy), _ptr(dy_scale), _ptr(wt), _ptr(wtx3), _ptr(dx), _ptr(ad), ld,
@@ -774,7 +858,7 @@ class _Conv2d(torch.autograd.Function):
                 dw_out = dw = torch.empty((cout, kh, kw, cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
             # f16x2 layer: the weight gradient too where its kernel covers the geometry (whole 64-channel blocks both ways),
             # with the input's scale from the forward and dY's from the data gradient above; elsewhere as under bf16x3
-            wm = lm if not h2_layer else _layer_math("wgrad", cin, cout, kh, kw)
+            wm = lm if not h2_layer else _layer_math("wgrad", cin, cout, kh, kw, ctx.w_leaf)
             h2_w = (h2_layer and wm == "f16x2" and cin % 64 == 0 and cout % 64 == 0 and ldx % 4 == 0 and lddy % 4 == 0 and
                     x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and
                     ((n * h * wd - 1) * ldx + cin) * 4 < 0xFFFF0000 and ((npix - 1) * lddy + cout + 64 * lddy) * 4 < 0xFFFF0000)
@@ -1081,15 +1165,27 @@ def planes_to_tensor(t):
     return out
 
 
-def _plane_variants(cout):
-    # tiles of conv_igemm4: 1 = 128 x 64, 0 = 128 x 128 (two workgroups per CU), 2 = 128 x 256, 3 = 256 x 128 (eight waves)
-    return [1] if cout <= 64 else [0, 1, 2, 3]
+def _plane_variants(cout, cred, taps):
+    """Tiles of conv_igemm4 offered to the tuner for `cout` output channels, `cred` reduction channels and `taps` filter taps:
+    0 = 128 x 128 (two workgroups per CU), 1 = 128 x 64, 2 = 128 x 256, 3 = 256 x 128 (eight waves, three stages); 4 = 128 x 64,
+    5 = 64 x 128, 6 = 64 x 64 with the DMA two / three K steps ahead -- for the layers with little matrix work per byte (1x1
+    convolutions, few channels), which otherwise wait out the memory latency every K step."""
+    if cout <= 64:
+        return [1, 4, 6]
+    light = taps == 1 or cred <= 128
+    return [0, 1, 2, 3] + ([4, 5, 6] if light else [])
 
 
 def _wgrad_plane_candidates(cout, cin):
     tms = (0, 1) if cout % 128 == 0 else (0,)
     tns = (0, 1) if cin % 128 == 0 else (0,)
-    return [(split, 4 * tm + 16 * tn) for tm in tms for tn in tns for split in (0, -2, -3, -4)]
+    cands = []
+    for tm in tms:
+        for tn in tns:
+            wide = cout % 128 == 0 and tm != 1 and cin % 128 == 0 and tn != 1
+            for bk in ((0,) if wide else (0, 2)):  # 2: three LDS stages (not on the 128 x 128 tile)
+                cands += [(split, bk + 4 * tm + 16 * tn) for split in (0, -2, -3, -4)]
+    return cands
 
 
 def fused_conv_bn_ok(x, conv_w, stride, pad, dil, bn_training, shape=None):
@@ -1100,7 +1196,7 @@ def fused_conv_bn_ok(x, conv_w, stride, pad, dil, bn_training, shape=None):
         return False
     cout, cin, kh, kw = conv_w.shape
     n, c_in, h, w = shape if shape is not None else x.shape
-    if c_in != cin or cin % 64 != 0 or cout % 64 != 0 or _layer_math("fwd", cin, cout, kh, kw) != "f16x2":
+    if c_in != cin or cin % 64 != 0 or cout % 64 != 0 or _layer_math("fwd", cin, cout, kh, kw, conv_w) != "f16x2":
         return False
     ho, wo = conv_out_size(h, kh, stride, pad, dil), conv_out_size(w, kw, stride, pad, dil)
     if h * w < 128 or ho * wo < 128 or n * ho * wo <= 2048 or n * h * w <= 2048 * (4 if stride == 2 else 1):
@@ -1132,11 +1228,13 @@ class _ConvBnAct(torch.autograd.Function):
         d = _desc(n, h, wd, cin, cin, ho, wo, cout, cout, kh, kw, stride, pad, dil)
         ws.open_stats()
         xplane = n * h * wd * cin
+        if RANGE_CENSUS:
+            _census_operand(_leaf(w_in), 0, None, xp, cin, x_slot, n * h * wd, cin)
 
         def launch(v, st, keys):
             check(lib.hn_conv2d_fwd_planes(_ptr(xp), xplane, _ptr(x_slot), _ptr(wh), _ptr(b), _ptr(y), _ptr(st), _ptr(keys),
                                            ctypes.byref(d), ACT_NONE, 0.0, v, s), "hn_conv2d_fwd_planes")
-        var = _pick("fwd.planes", d, _plane_variants(cout), lambda v: launch(v, None, None))
+        var = _pick("fwd.planes", d, _plane_variants(cout, cin, kh * kw), lambda v: launch(v, None, None))
         with _ConvTimer("fwd", d, lambda: _plan_name(0, d, 3, _variant(var, 0, 0, 4))):
             launch(var, ws.stats, ws.keys)
         # batch statistics -> normalisation constants, and the bound of |z| (the scale z is written with)
@@ -1236,6 +1334,8 @@ class _ConvBnAct(torch.autograd.Function):
                                                  _ptr(dy_slot), _ptr(dres), cout, npix, cout, act, _ptr(prelu_w), leaky,
                                                  _ptr(ctx.drop_mask), ho * wo, _ptr(rbits), s), "hn_bn_act_bwd_apply_planes")
         d = _desc(n, h, wd, cin, cin, ho, wo, cout, cout, kh, kw, stride, pad, dil)
+        if RANGE_CENSUS and (need_x or need_w):
+            _census_operand(lw, 1, None, dyp, cout, dy_slot, npix, cout)
         # ---- data gradient ----
         if need_x:
             dx = new_nhwc(n, cin, h, wd, dev)
@@ -1244,7 +1344,7 @@ class _ConvBnAct(torch.autograd.Function):
             def launch(v, ad, ld):
                 check(lib.hn_conv2d_dgrad_planes(_ptr(dyp), npix * cout, _ptr(dy_slot), _ptr(ctx.wth), _ptr(dx), _ptr(ad), ld,
                                                  ctypes.byref(d), v, s), "hn_conv2d_dgrad_planes")
-            var = _pick("dgrad.planes", d, _plane_variants(cin), lambda v: launch(v, None, 0))
+            var = _pick("dgrad.planes", d, _plane_variants(cin, cout, kh * kw), lambda v: launch(v, None, 0))
             with _ConvTimer("dgrad", d, lambda: _plan_name(1, d, 3, _variant(var, 0, 0, 4))):
                 launch(var, add, ldadd)
         elif dskip is not None:

@@ -131,6 +131,7 @@ def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_w
     if grad_sync is not None:
         grad_sync.finish_step()
     optimizer.step()
+    ops.range_guard_tick()
     losses["total"] = total.detach()
     return losses
 
@@ -149,4 +150,5 @@ def segmentation_step(model, optimizer, rgb, ir, labels, ignore_index=-100, grad
     if grad_sync is not None:
         grad_sync.finish_step()
     optimizer.step()
+    ops.range_guard_tick()  # HEATNET_F16X2_GUARD: layers with heavy-tailed operands leave the f16x2 arithmetic
     return loss.detach()

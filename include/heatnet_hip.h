@@ -262,6 +262,13 @@ int hn_bn_act_bwd_apply_planes(const float* dz, int lddz, const float* z, int ld
 int hn_bilinear_up2_planes(const float* x, int ldx, const float* slot, void* y_planes, int64_t plane_elems, int ldp, int N,
                            int Hin, int Win, int C, void* stream);
 
+/* f16x2 range census of one operand: out[0] += number of non-zero elements, out[1] += those of them more than 2^18 below the
+ * slot's magnitude (|t * s| < 2^-3: fewer than 22 significant bits survive the hi / lo split).  Give either the fp32 tensor
+ * `x` or the plane tensor (`planes`, plane_elems); `ld` is the pixel stride of whichever is given.  Diagnostics
+ * (HEATNET_F16X2_GUARD in heatnet-pub_amd/ops.py): layers whose operands exceed a threshold are moved to bf16x3. */
+int hn_range_census(const float* x, const void* planes, int64_t plane_elems, int ld, const float* scale, int64_t npix, int C,
+                    uint64_t* out, void* stream);
+
 /* Weight gradient with BOTH operands as plane tensors (d->ldx / d->ldy = their pixel strides in fp16 elements); split_k,
  * flags and the deterministic form as for hn_conv2d_wgrad / hn_conv2d_wgrad_det; `variant`: only the tile fields
  * (4 * tm + 16 * tn, 1 = 64-wide, 0 / 2 = 128-wide where the channel counts allow). */

@@ -58,8 +58,9 @@ def test_segnet_forward_matches_reference_fixture(dev, golden_dir, tag, late, co
     assert err < 1e-3, err
 
 
-def test_segnet_backward_matches_oracle(dev):
-    """Parameter gradients of forward + CE + backward.
+@pytest.mark.parametrize("conv_math", ["f32", "bf16x3", "f16x2"], indirect=True)
+def test_segnet_backward_matches_oracle(dev, conv_math):
+    """Parameter gradients of forward + CE + backward, under each of the three fp32-result arithmetics.
 
     At this size (8x12 maps, batch 2, train-mode BN) the fp32 CPU oracle itself is ~1e-2 (relative, per parameter)
     away from an fp64 run of the same oracle -- ReLU / max-pool decisions flip on fp32 noise -- so "equal to the CPU
@@ -563,11 +564,14 @@ def test_640x1408_forward_matches_oracle(dev, conv_math):
         assert rms < BF16_LOGIT_RMS_TOL and abs(ce - ref_ce) < BF16_CE_TOL and abs(mine - theirs) < BF16_MIOU_TOL
 
 
-@pytest.mark.parametrize("conv_math", ["bf16x3", "bf16"], indirect=True)
+@pytest.mark.parametrize("conv_math", ["f16x2", "bf16x3", "bf16"], indirect=True)
 def test_640x1408_batch8_properties(dev, conv_math):
     """configs[4] at its full per-GPU size (bs 8, 640x1408), through properties that need no CPU run of that size:
     (1) eval-mode logits of the batch equal, BIT FOR BIT, the logits of each image run alone (per-element accumulation
-        order does not depend on how output rows are tiled; deterministic mode: no split-K atomics on the pyramid levels),
+        order does not depend on how output rows are tiled; deterministic mode: no split-K atomics on the pyramid levels).
+        Under f16x2 (the default) an operand's power-of-two scale comes from the maximum over the TENSOR, i.e. over the batch:
+        where the batch's maximum falls into another binade than the single image's, elements are rounded at another
+        position -- there the property is equality within the parity tolerance of the logits (1e-3), not bit equality,
     (2) a training step (forward + CE + backward + fused RMSprop) produces finite loss and gradients, every parameter
         receives a gradient, the batch statistics written back are those of 8 images, and the CE of the near-uniform
         random-weight logits is ~ log(13)."""
@@ -581,7 +585,10 @@ def test_640x1408_batch8_properties(dev, conv_math):
             whole = net(rgb, ir)[0]
             for i in (0, 5):
                 one = net(rgb[i:i + 1], ir[i:i + 1])[0]
-                assert torch.equal(one[0], whole[i]), "image %d: batch-of-8 logits differ from the single-image run" % i
+                if conv_math == "f16x2":
+                    assert float((one[0] - whole[i]).abs().max()) < 1e-3, "image %d" % i
+                else:
+                    assert torch.equal(one[0], whole[i]), "image %d: batch-of-8 logits differ from the single-image run" % i
     finally:
         ops.set_deterministic(prev)
     net.train()

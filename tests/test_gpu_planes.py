@@ -86,7 +86,7 @@ PLANE_CONV_CASES = [  # n, cin, h, w, cout, k, stride, pad, dil
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("case", PLANE_CONV_CASES, ids=str)
 def test_conv_planes_forward_dgrad_bitwise(dev, case, tile):
     from heatnet_amd import _lib, ops
@@ -198,12 +198,12 @@ def test_wgrad_planes_bitwise(dev, case):
     d = _lib.HnConvDesc(n, h, w_, cin, cin, ho, wo, cout, cout, k, k, stride, pad, dil)
     dw0 = torch.empty(cout, k, k, cin, device=dev)
     _lib.check(lib.hn_conv2d_wgrad_scaled(P(x), P(xs), P(gy), P(gs), P(dw0), ctypes.byref(d), 1, 0, 0, s), "wgrad")
-    for tm, tn in ((0, 0), (1, 1), (2, 1), (1, 2)):
+    for tm, tn, bk in ((0, 0, 0), (1, 1, 0), (2, 1, 0), (1, 2, 0), (1, 1, 2), (2, 1, 2), (1, 2, 2)):  # bk 2: three LDS stages
         var = 4 * tm + 16 * tn
         dw0v = torch.empty_like(dw0)
         _lib.check(lib.hn_conv2d_wgrad_scaled(P(x), P(xs), P(gy), P(gs), P(dw0v), ctypes.byref(d), 1, var, 0, s), "wgrad")
         dw1 = torch.full_like(dw0, float("nan"))
-        _lib.check(lib.hn_conv2d_wgrad_planes(P(xh), xplane, P(xs), P(gh), gplane, P(gs), P(dw1), ctypes.byref(d), 1, var, 0, s),
+        _lib.check(lib.hn_conv2d_wgrad_planes(P(xh), xplane, P(xs), P(gh), gplane, P(gs), P(dw1), ctypes.byref(d), 1, var + bk, 0, s),
                    "wgrad_planes")
         assert torch.equal(dw0v, dw1), (tm, tn)
         assert torch.equal(dw0, dw1)  # (tilings agree bitwise as well)
@@ -320,3 +320,56 @@ def test_fused_conv_bn_act_matches_unfused(dev, case):
             tol = 1e-3  # one scalar: a sum of 10^5 cancelling terms
         err = float((a[key] - ref).abs().max())
         assert err <= tol * max(float(ref.abs().max()), 1e-30), (key, err, float(ref.abs().max()))
+
+
+def test_f16x2_range_guard_moves_heavy_tailed_layers_to_bf16x3(dev):
+    """Per-ELEMENT accuracy on a heavy-tailed gradient operand, and the guard that acts on it.  dY of a 1x1 convolution has
+    one magnitude per pixel, spread over 2^36; dX[p] depends on dY[p] alone, so each output row shows the precision its input
+    row kept.  f16x2 (one scale per tensor): rows within 2^-18 of the maximum are fp32-accurate, rows far below it lose bits
+    -- absolute error stays below max * 2^-36, relative error grows.  The census counts the lossy fraction; with the guard
+    the layer moves to bf16x3, whose per-row relative error is fp32-grade for EVERY row."""
+    import torch.nn as nn
+    from heatnet_amd import ops
+    n, cin, h, w_, cout = 2, 128, 40, 44, 128
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, cin, h, w_, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / np.sqrt(cin)
+    expo = torch.linspace(0, -36, n * h * w_).reshape(n, 1, h, w_)         # per-pixel magnitude 2^0 ... 2^-36
+    gy = torch.randn(n, cout, h, w_, generator=g) * torch.exp2(expo)
+    ref = torch.einsum("nkhw,kc->nchw", gy.double(), wt.double()[:, :, 0, 0])  # dX in fp64
+
+    def run():
+        xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+        y = ops.conv2d(xd, wparam, None, 1, 0, 1)
+        y.backward(gy.to(dev).contiguous(memory_format=torch.channels_last))
+        return xd.grad.detach().cpu().double()
+
+    def row_rel(dx):
+        num = (dx - ref).pow(2).sum(1).sqrt().reshape(-1)
+        den = ref.pow(2).sum(1).sqrt().reshape(-1)
+        return num / den
+
+    prev_math = ops.set_conv_math("f16x2")
+    prev_census = ops.set_range_census(True)
+    try:
+        wparam = nn.Parameter(wt.to(dev).contiguous(memory_format=torch.channels_last))
+        dx = run()
+        rel = row_rel(dx)
+        mags = torch.exp2(expo).reshape(-1)
+        near = mags >= 2.0 ** -14                      # comfortably inside the 2^-18 window (row norms vary by a few bits)
+        assert float(rel[near].max()) < 2e-6
+        assert float(rel[mags < 2.0 ** -30].max()) > 1e-4   # the documented loss: these rows keep < 10 bits
+        assert float((dx - ref).abs().max()) < float(ref.abs().max()) * 2.0 ** -20
+        rows = [r for r in ops.range_report() if r[5] is wparam]
+        assert len(rows) == 1
+        _, nz_a, frac_a, nz_g, frac_g, _ = rows[0]
+        assert nz_g == gy.numel() and 0.4 < frac_g < 0.75   # over half the rows lie more than 2^18 below the maximum
+        assert frac_a < 1e-3                                 # the Gaussian activation operand is fine
+        moved = ops.range_guard_update(threshold=0.05)
+        assert [m[0] for m in moved] == [tuple(wparam.shape)] and wparam._hn_no_f16x2
+        rel2 = row_rel(run())                                # now on bf16x3
+        assert float(rel2.max()) < 2e-6
+    finally:
+        ops.set_range_census(prev_census)
+        ops.set_conv_math(prev_math)
+        ops._census.clear()

@@ -86,8 +86,7 @@ def main():
                 if lib.hn_conv2d_fwd_scaled(P(x), P(xs), P(wt), P(wh), None, P(y), None, ctypes.byref(d), 0, 0.0, v, s) == 0:
                     res[name] = timeit(lambda: lib.hn_conv2d_fwd_scaled(P(x), P(xs), P(wt), P(wh), None, P(y), None, ctypes.byref(d), 0, 0.0, v, s))
             new = {}
-            for tile in (0, 1, 2, 3):
-                v = tile if tile else (1 if cout <= 64 else 0)
+            for tile in (0, 1, 2, 3, 4, 5, 6):
                 if tile == 0 and cout <= 64:
                     continue
                 if lib.hn_conv2d_fwd_planes(P(xh), xplane, P(xs), P(wh), None, P(y), None, None, ctypes.byref(d), 0, 0.0, tile, s) == 0:
@@ -101,7 +100,7 @@ def main():
                 if lib.hn_conv2d_dgrad_scaled(P(dy), P(gs), P(wtf), P(wth), P(dx), None, 0, ctypes.byref(d), v, s) == 0:
                     res[name] = timeit(lambda: lib.hn_conv2d_dgrad_scaled(P(dy), P(gs), P(wtf), P(wth), P(dx), None, 0, ctypes.byref(d), v, s))
             new = {}
-            for tile in (0, 1, 2, 3):
+            for tile in (0, 1, 2, 3, 4, 5, 6):
                 if tile == 0 and cin <= 64:
                     continue
                 if lib.hn_conv2d_dgrad_planes(P(gh), gplane, P(gs), P(wth), P(dx), None, 0, ctypes.byref(d), tile, s) == 0:
@@ -114,7 +113,7 @@ def main():
             for sp in (0, -2, -3):
                 if lib.hn_conv2d_wgrad_scaled(P(x), P(xs), P(dy), P(gs), P(dw), ctypes.byref(d), sp, 0, 0, s) == 0:
                     res[sp] = timeit(lambda: lib.hn_conv2d_wgrad_scaled(P(x), P(xs), P(dy), P(gs), P(dw), ctypes.byref(d), sp, 0, 0, s))
-                for var in (0, 1):
+                for var in (0, 2, 4 + 2, 16 + 2, 4 + 16 + 2):
                     if lib.hn_conv2d_wgrad_planes(P(xh), xplane, P(xs), P(gh), gplane, P(gs), P(dw), ctypes.byref(d), sp, var, 0, s) == 0:
                         new[(sp, var)] = timeit(lambda: lib.hn_conv2d_wgrad_planes(P(xh), xplane, P(xs), P(gh), gplane, P(gs), P(dw), ctypes.byref(d), sp, var, 0, s))
             if res and new:
