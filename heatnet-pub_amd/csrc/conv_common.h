@@ -324,7 +324,7 @@ int launch_conv2(const ConvArgs& a, bool tall, bool wide, int ns, hipStream_t st
 // conv_igemm4.hip: f16x2 with both operands as fp16 planes, everything by LDS-DMA
 bool conv4_covers(const ConvArgs& a);
 int launch_conv4(const ConvArgs& a, int tile, hipStream_t stream);
-const char* conv4_kernel_name(int tile);
+const char* conv4_kernel_name(int tile, bool bf16);
 // conv_igemm3.hip: bf16x3, 128 x 256 tile, weight operand by LDS-DMA
 bool conv3_covers(const ConvArgs& a, int planes, bool wide);
 int launch_conv3(const ConvArgs& a, int planes, bool wide, hipStream_t stream);

@@ -551,8 +551,10 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
     if (a.xh != nullptr) {
         // the gathered operand arrives as fp16 planes: only the all-DMA schedule (conv_igemm4.hip) reads that format.
         // variant & 15 = its tile (0: 128 x 128, or 128 x 64 when there are at most 64 output channels; 1 .. 6: launch_conv4)
-        if (math != HN_MATH_F16X2 || !conv4_covers(a)) return HN_ESHAPE;
-        pl.family = FAM_V4; pl.math = MATH_H2; pl.mode = MODE_VEC_BUF;
+        // (fp16 hi / lo planes with scales under f16x2, one bf16 plane without under bf16)
+        if (!(math == HN_MATH_F16X2 && a.a_scale != nullptr) && !(math == HN_MATH_BF16 && a.a_scale == nullptr)) return HN_ESHAPE;
+        if (!conv4_covers(a)) return HN_ESHAPE;
+        pl.family = FAM_V4; pl.math = math == HN_MATH_BF16 ? MATH3_BF16 : MATH_H2; pl.mode = MODE_VEC_BUF;
         const int tile = variant & 15;
         if (tile > 6) return HN_EINVAL;
         pl.wn = tile == 0 ? (a.K <= 64 ? 1 : 0) : tile;
@@ -627,7 +629,7 @@ int dispatch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
 // the kernel's name as rocprofv3 prints it (tools/pmc_aggregate.py keys), for per-instantiation accounting
 void plan_name(const ConvPlan& pl, char* buf, int n) {
     const int tm = pl.tall ? 2 : 1, tn = pl.wide ? 2 : 1;
-    if (pl.family == FAM_V4) snprintf(buf, n, "%s", conv4_kernel_name(pl.wn));
+    if (pl.family == FAM_V4) snprintf(buf, n, "%s", conv4_kernel_name(pl.wn, pl.math == MATH3_BF16));
     else if (pl.family == FAM_V3) {
         const int planes = pl.math == MATH_H2 ? 2 : (pl.math == MATH3_BF16 ? 1 : 3);
         const bool small = planes != 3 && pl.wn != 4;  // the 128 x 128 four-wave tile with two A staging sets
@@ -1039,7 +1041,8 @@ int conv2d_fwd_impl(const float* x, const float* x_scale, const float* w, const 
     a.minmax = minmax;
     if (minmax != nullptr && (stats == nullptr || act != HN_ACT_NONE)) return HN_EINVAL;
     if (xh != nullptr) {  // plane tensor: the all-DMA kernels only (no split-K on that path)
-        if (x_scale == nullptr || xh_plane <= 0) return HN_EINVAL;
+        if (xh_plane <= 0 || w_x3 == nullptr) return HN_EINVAL;
+        if (x_scale == nullptr) variant = (variant & 63) | (3 << 6);  // one bf16 plane: the mixed-precision bf16 arithmetic
         a.xh = static_cast<const unsigned short*>(xh);
         a.xh_plane = xh_plane;
         a.x_bytes = (((long long)d->N * d->Hin * d->Win - 1) * d->ldx + d->Cin) * 2;
@@ -1081,7 +1084,7 @@ extern "C" int hn_conv2d_fwd_scaled(const float* x, const float* x_scale, const 
 extern "C" int hn_conv2d_fwd_planes(const void* x_planes, int64_t plane_elems, const float* x_scale, const void* w_h2,
                                     const float* bias, float* y, double* stats, uint32_t* range_keys, const HnConvDesc* d,
                                     int act, float slope, int variant, void* stream) {
-    if (x_planes == nullptr || x_scale == nullptr || w_h2 == nullptr) return HN_EINVAL;
+    if (x_planes == nullptr || w_h2 == nullptr) return HN_EINVAL;  // (x_scale == NULL: one bf16 plane, w_h2 = bf16x3 planes)
     return conv2d_fwd_impl(nullptr, x_scale, nullptr, w_h2, bias, y, stats, d, act, slope, variant, stream, x_planes, plane_elems,
                            range_keys);
 }
@@ -1109,7 +1112,8 @@ int conv2d_dgrad_impl(const float* dy, const float* dy_scale, const float* wt, c
                       int ldadd, const HnConvDesc* d, int variant, void* stream, const void* dyh = nullptr,
                       long long dyh_plane = 0) {
     if ((dy == nullptr && dyh == nullptr) || (wt == nullptr && dyh == nullptr) || dx == nullptr) return HN_EINVAL;
-    if (dyh != nullptr && (dy_scale == nullptr || dyh_plane <= 0)) return HN_EINVAL;
+    if (dyh != nullptr && (wt_x3 == nullptr || dyh_plane <= 0)) return HN_EINVAL;
+    if (dyh != nullptr && dy_scale == nullptr) variant = (variant & 63) | (3 << 6);  // one bf16 plane
     if (dy_scale != nullptr) {
         if (wt_x3 == nullptr || variant < 0) return HN_EINVAL;
         variant = (variant & 63) | VARIANT_F16X2;
@@ -1225,7 +1229,7 @@ extern "C" int hn_conv2d_dgrad_scaled(const float* dy, const float* dy_scale, co
 extern "C" int hn_conv2d_dgrad_planes(const void* dy_planes, int64_t plane_elems, const float* dy_scale, const void* wt_h2,
                                       float* dx, const float* addend, int ldadd, const HnConvDesc* d, int variant,
                                       void* stream) {
-    if (dy_planes == nullptr || dy_scale == nullptr || wt_h2 == nullptr) return HN_EINVAL;
+    if (dy_planes == nullptr || wt_h2 == nullptr) return HN_EINVAL;
     return conv2d_dgrad_impl(nullptr, dy_scale, nullptr, wt_h2, dx, addend, ldadd, d, variant, stream, dy_planes, plane_elems);
 }
 

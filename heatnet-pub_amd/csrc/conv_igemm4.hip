@@ -39,22 +39,24 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
 
 __device__ __forceinline__ int hsw(int t) { return (4 - t) & 3; }  // {0, 3, 2, 1}
 
-// WM x WN waves, each TM x TN blocks of 32 x 32 outputs; NST LDS stages
-template <int WM, int WN, int TM, int TN, int NST>
+// WM x WN waves, each TM x TN blocks of 32 x 32 outputs; NST LDS stages; NPL planes per operand: 2 = f16x2 (hi / lo fp16, three
+// MFMAs per product), 1 = the mixed-precision bf16 arithmetic (ONE bf16 image per operand -- activations / gradients stored in
+// bf16 by the producing pass, plane 0 of the weight planes --, one v_mfma_f32_16x16x32_bf16 per product, no scales)
+template <int WM, int WN, int TM, int TN, int NST, int NPL = 2>
 struct T4 {
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN, NT = 64 * NW, BK = 32;
     static constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;  // bytes
-    static constexpr int A_BYTES = 2 * A_PLANE, B_BYTES = 2 * B_PLANE;
+    static constexpr int A_BYTES = NPL * A_PLANE, B_BYTES = NPL * B_PLANE;
     static constexpr int STAGE = A_BYTES + B_BYTES;
     static constexpr int QA = BM / 16 / NW, QB = BN / 16 / NW;  // 16-row blocks per wave and stage (per plane)
     static constexpr int LDS = NST * STAGE + BM * 16;
     static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "row blocks must divide over the waves");
-    static_assert(2 * (QA + QB) * (NST - 2) < 64, "vmcnt immediate");
+    static_assert(NPL * (QA + QB) * (NST - 2) < 64, "vmcnt immediate");
 };
 
-template <int WM, int WN, int TM, int TN, int NST>
+template <int WM, int WN, int TM, int TN, int NST, int NPL = 2>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_igemm4_kernel(const ConvArgs p) {
-    using T = T4<WM, WN, TM, TN, NST>;
+    using T = T4<WM, WN, TM, TN, NST, NPL>;
     constexpr int BM = T::BM, BN = T::BN, NW = T::NW, BK = T::BK, QA = T::QA, QB = T::QB;
     extern __shared__ __attribute__((aligned(16))) char smem4[];
     int* rowinfo = reinterpret_cast<int*>(smem4 + NST * T::STAGE);
@@ -68,10 +70,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     conv_fill_rowinfo<BM>(p, rowinfo, m0, tid);
     __syncthreads();
-    float a_s, a_inv;
-    hn_h2_scales_of_slot(p.a_scale, a_s, a_inv);
-    const float o_s = a_inv, o_s2 = p.w_scale[1];  // applied one after the other (conv_common.h)
-    const float i_s = a_s, i_s2 = p.w_scale[0];
+    float o_s = 1.f, o_s2 = 1.f, i_s = 1.f, i_s2 = 1.f;
+    if constexpr (NPL == 2) {
+        float a_s, a_inv;
+        hn_h2_scales_of_slot(p.a_scale, a_s, a_inv);
+        o_s = a_inv; o_s2 = p.w_scale[1];  // applied one after the other (conv_common.h)
+        i_s = a_s; i_s2 = p.w_scale[0];
+    }
 
     // ---- A operand: this lane's rows of the wave's 16-row blocks, source piece after the swizzle ------------------
     const int l_row = lane >> 2;
@@ -117,14 +122,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
             const unsigned vo = ok ? (unsigned)(aoff[q] + doff) : a_records;
             char* dst = stage + (wave + NW * q) * 1024;
             dma16(rsrc_a0, dst, vo, 0);
-            dma16(rsrc_a1, dst + T::A_PLANE, vo, 0);
+            if constexpr (NPL == 2) dma16(rsrc_a1, dst + T::A_PLANE, vo, 0);
         }
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
             const unsigned vo = live ? bvoff[q] : b_records;
             char* dst = stage + T::A_BYTES + (wave + NW * q) * 1024;
             dma16(rsrc_b0, dst, vo, (unsigned)(f_k0 * 2));
-            dma16(rsrc_b1, dst + T::B_PLANE, vo, (unsigned)(f_k0 * 2));
+            if constexpr (NPL == 2) dma16(rsrc_b1, dst + T::B_PLANE, vo, (unsigned)(f_k0 * 2));
         }
         f_c0 += BK;
         const int wrap_c = f_c0 >= p.C ? 1 : 0;
@@ -145,17 +150,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
     const int a_frag = wm * TM * 32 * 64 + frag;
     const int b_frag = T::A_BYTES + wn * TN * 32 * 64 + frag;
     auto mfma_phase = [&](const char* st) {
-        f16x8 fb[2 * TN][2];
+        using frag_t = std::conditional_t<NPL == 2, f16x8, bf16x8>;
+        frag_t fb[2 * TN][NPL];
 #pragma unroll
         for (int bj = 0; bj < 2 * TN; ++bj)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-                fb[bj][s2] = *reinterpret_cast<const f16x8*>(st + b_frag + s2 * T::B_PLANE + bj * 16 * 64);
+            for (int s2 = 0; s2 < NPL; ++s2)
+                fb[bj][s2] = *reinterpret_cast<const frag_t*>(st + b_frag + s2 * T::B_PLANE + bj * 16 * 64);
 #pragma unroll
         for (int bi = 0; bi < 2 * TM; ++bi) {
-            f16x8 fa[2];
+            frag_t fa[NPL];
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) fa[s2] = *reinterpret_cast<const f16x8*>(st + a_frag + s2 * T::A_PLANE + bi * 16 * 64);
+            for (int s2 = 0; s2 < NPL; ++s2) fa[s2] = *reinterpret_cast<const frag_t*>(st + a_frag + s2 * T::A_PLANE + bi * 16 * 64);
             // per accumulator the order is lo*hi, hi*lo, hi*hi (as in conv_igemm.hip); consecutive MFMAs go to different
             // accumulators
             f32x4 c[2 * TN];
@@ -165,12 +171,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
                 const f32x16& blk = acc[bi >> 1][bj >> 1];
                 c[bj] = f32x4{blk[sb], blk[sb + 1], blk[sb + 2], blk[sb + 3]};
             }
+            if constexpr (NPL == 2) {
 #pragma unroll
-            for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[bj][0], c[bj], 0, 0, 0);
+                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[bj][0], c[bj], 0, 0, 0);
 #pragma unroll
-            for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][1], c[bj], 0, 0, 0);
+                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][1], c[bj], 0, 0, 0);
 #pragma unroll
-            for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][0], c[bj], 0, 0, 0);
+                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][0], c[bj], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][0], c[bj], 0, 0, 0);
+            }
 #pragma unroll
             for (int bj = 0; bj < 2 * TN; ++bj) {
                 const int sb = 4 * (2 * (bi & 1) + (bj & 1));
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
         }
     };
 
-    constexpr int PER_STEP = 2 * (QA + QB);  // DMA instructions a wave issues per chunk
+    constexpr int PER_STEP = NPL * (QA + QB);  // DMA instructions a wave issues per chunk
     auto wait_landed = [] {  // everything but the newest NST - 2 chunks' DMAs of this wave
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP * (NST - 2)) : "memory");
     };
@@ -208,14 +219,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last, out-of-range DMAs)
 
-    conv_epilogue<TM, TN, true, BM, BN, true>(p, acc, am, rowinfo, m0, tile_m, 0, o_s, o_s2);
+    conv_epilogue<TM, TN, true, BM, BN, NPL == 2>(p, acc, am, rowinfo, m0, tile_m, 0, o_s, o_s2);
 }
 
-template <int WM, int WN, int TM, int TN, int NST>
+template <int WM, int WN, int TM, int TN, int NST, int NPL = 2>
 int launch4(const ConvArgs& a, hipStream_t stream) {
-    using T = T4<WM, WN, TM, TN, NST>;
+    using T = T4<WM, WN, TM, TN, NST, NPL>;
     static std::atomic<unsigned long long> configured{0};
-    if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm4_kernel<WM, WN, TM, TN, NST>), T::LDS, configured) != HN_OK)
+    if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm4_kernel<WM, WN, TM, TN, NST, NPL>), T::LDS, configured) != HN_OK)
         return HN_ELAUNCH;
     ConvArgs p = a;
     p.ntm = (a.M + T::BM - 1) / T::BM;
@@ -223,15 +234,16 @@ int launch4(const ConvArgs& a, hipStream_t stream) {
     static const int gm_env = getenv("HN_GROUP_M") ? atoi(getenv("HN_GROUP_M")) : 0;  // experiment knob
     p.gm = gm_env > 0 ? gm_env : (p.ntn >= (T::BN >= 256 ? 4 : 8) ? 8 : 1);
     if (p.gm > p.ntm) p.gm = p.ntm;
-    HN_LAUNCH((conv_igemm4_kernel<WM, WN, TM, TN, NST>), dim3(p.ntm * p.ntn), dim3(T::NT), T::LDS, stream, p);
+    HN_LAUNCH((conv_igemm4_kernel<WM, WN, TM, TN, NST, NPL>), dim3(p.ntm * p.ntn), dim3(T::NT), T::LDS, stream, p);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
 
 }  // namespace
 
+// (a_scale == NULL: the one-plane bf16 arithmetic)
 bool conv4_covers(const ConvArgs& a) {
-    return a.xh != nullptr && a.wx3 != nullptr && a.a_scale != nullptr && a.w_scale != nullptr && a.C % 32 == 0 && a.cps == 0 &&
+    return a.xh != nullptr && a.wx3 != nullptr && (a.a_scale == nullptr) == (a.w_scale == nullptr) && a.C % 32 == 0 && a.cps == 0 &&
            a.in_scale == nullptr && a.in_dil == 1 && a.ldx % 8 == 0 && hn_aligned16(a.xh) && a.xh_plane % 8 == 0 &&
            a.wx3_plane * 2 < (1ll << 32) && (long long)a.H * a.W >= 128 && 3ll * a.H * a.W * a.ldx * 2 < (1ll << 31);
 }
@@ -242,6 +254,17 @@ bool conv4_covers(const ConvArgs& a) {
 // carry little matrix work per byte (1x1 convolutions with few channels on one side), where a distance of one step leaves
 // every step waiting out the memory latency
 int launch_conv4(const ConvArgs& a, int tile, hipStream_t stream) {
+    if (a.a_scale == nullptr) {  // bf16, one plane: the same tiles with deeper pipelines (a stage is half the size)
+        switch (tile) {
+            case 1: return launch4<4, 1, 1, 2, 3, 1>(a, stream);
+            case 2: return launch4<2, 4, 2, 2, 4, 1>(a, stream);
+            case 3: return launch4<4, 2, 2, 2, 4, 1>(a, stream);
+            case 4: return launch4<4, 1, 1, 2, 4, 1>(a, stream);
+            case 5: return launch4<2, 2, 1, 2, 4, 1>(a, stream);
+            case 6: return launch4<2, 2, 1, 1, 4, 1>(a, stream);
+            default: return launch4<2, 2, 2, 2, 3, 1>(a, stream);
+        }
+    }
     switch (tile) {
         case 1: return launch4<4, 1, 1, 2, 2>(a, stream);
         case 2: return launch4<2, 4, 2, 2, 3>(a, stream);
@@ -253,15 +276,26 @@ int launch_conv4(const ConvArgs& a, int tile, hipStream_t stream) {
     }
 }
 
-const char* conv4_kernel_name(int tile) {
+const char* conv4_kernel_name(int tile, bool bf16) {
+    if (bf16) {
+        switch (tile) {
+            case 1: return "conv_igemm4_kernel<4, 1, 1, 2, 3, 1>";
+            case 2: return "conv_igemm4_kernel<2, 4, 2, 2, 4, 1>";
+            case 3: return "conv_igemm4_kernel<4, 2, 2, 2, 4, 1>";
+            case 4: return "conv_igemm4_kernel<4, 1, 1, 2, 4, 1>";
+            case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 4, 1>";
+            case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4, 1>";
+            default: return "conv_igemm4_kernel<2, 2, 2, 2, 3, 1>";
+        }
+    }
     switch (tile) {
-        case 1: return "conv_igemm4_kernel<4, 1, 1, 2, 2>";
-        case 2: return "conv_igemm4_kernel<2, 4, 2, 2, 3>";
-        case 3: return "conv_igemm4_kernel<4, 2, 2, 2, 3>";
-        case 4: return "conv_igemm4_kernel<4, 1, 1, 2, 3>";
-        case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 3>";
-        case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4>";
-        default: return "conv_igemm4_kernel<2, 2, 2, 2, 2>";
+        case 1: return "conv_igemm4_kernel<4, 1, 1, 2, 2, 2>";
+        case 2: return "conv_igemm4_kernel<2, 4, 2, 2, 3, 2>";
+        case 3: return "conv_igemm4_kernel<4, 2, 2, 2, 3, 2>";
+        case 4: return "conv_igemm4_kernel<4, 1, 1, 2, 3, 2>";
+        case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 3, 2>";
+        case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4, 2>";
+        default: return "conv_igemm4_kernel<2, 2, 2, 2, 2, 2>";
     }
 }
 

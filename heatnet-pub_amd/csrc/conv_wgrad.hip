@@ -770,12 +770,13 @@ __device__ __forceinline__ int x3_piece_at(int k, int pp) {
     return (((pp >> 2) ^ swz) << 2) | ((pp & 3) ^ (((k >> 3) & 1) << 1));
 }
 
-template <int TM, int TN, int NST = 2>
+// NPL = 1: the mixed-precision bf16 arithmetic on one bf16 image per operand (no scales, one MFMA per product).
+template <int TM, int TN, int NST = 2, int NPL = 2>
 __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) {
     constexpr int BKP = 32;
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int PLANE_A = BKP * BM * 2, PLANE_B = BKP * BN * 2;  // bytes per fp16 plane
-    constexpr int STAGE = 2 * (PLANE_A + PLANE_B);
+    constexpr int PLANE_A = BKP * BM * 2, PLANE_B = BKP * BN * 2;  // bytes per 16-bit plane
+    constexpr int STAGE = NPL * (PLANE_A + PLANE_B);
     constexpr int ROWS_A = 1024 / (2 * BM), ROWS_B = 1024 / (2 * BN);  // pixel rows one 1-KiB DMA covers
     constexpr int PPR_A = BM / 8, PPR_B = BN / 8;                       // 16-byte pieces per pixel row
     constexpr int QA = BKP / ROWS_A / 4, QB = BKP / ROWS_B / 4;         // DMA row groups per wave, plane and stage
@@ -794,10 +795,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) 
     const int c_begin = split * p.chunks_per_split;
     const int c_end = min(total_chunks, c_begin + p.chunks_per_split);
     const int hw = p.Ho * p.Wo;
-    float s_dy, s_x, i_dy, i_x;
-    hn_h2_scales_of_slot(p.dy_scale, s_dy, i_dy);
-    hn_h2_scales_of_slot(p.x_scale, s_x, i_x);
-    const float o_s = i_dy * i_x;
+    float o_s = 1.f, o_s2 = 1.f;
+    if constexpr (NPL == 2) {
+        float s_dy, s_x;
+        hn_h2_scales_of_slot(p.dy_scale, s_dy, o_s);
+        hn_h2_scales_of_slot(p.x_scale, s_x, o_s2);
+    }
 
     const int tap = n0 / p.C, ci0 = n0 - tap * p.C;  // a tile's column range lies inside one tap (C % BN == 0)
     const int vkh = tap / p.KW, vkw = tap - vkh * p.KW;
@@ -853,16 +856,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) 
             const unsigned vo = (off < a_voff[q] || !live) ? 0xFFFFFFFFu : off;
             char* dst = st + (wave + 4 * q) * 1024;
             wg_dma16(rsrc_d0, dst, vo);
-            wg_dma16(rsrc_d1, dst + PLANE_A, vo);
+            if constexpr (NPL == 2) wg_dma16(rsrc_d1, dst + PLANE_A, vo);
         }
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
             const int k = (wave + 4 * q) * ROWS_B + lane / PPR_B;
             const bool ok = live & (p0 + k < p.M) & ((unsigned)hq[q] < (unsigned)p.H) & ((unsigned)wq[q] < (unsigned)p.W);
             const unsigned vo = ok ? (unsigned)(xoff[q] * 2) : x_records;
-            char* dst = st + 2 * PLANE_A + (wave + 4 * q) * 1024;
+            char* dst = st + NPL * PLANE_A + (wave + 4 * q) * 1024;
             wg_dma16(rsrc_x0, dst, vo);
-            wg_dma16(rsrc_x1, dst + PLANE_B, vo);
+            if constexpr (NPL == 2) wg_dma16(rsrc_x1, dst + PLANE_B, vo);
             wo_[q] += BKP;
             wq[q] += BKP * p.stride;
             xoff[q] += BKP * step_w;
@@ -897,26 +900,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) 
 #pragma unroll
     for (int i = 0; i < 2 * TM; ++i) offA[i] = x3_off<BM>(krow, (wm * TM * 2 + i) * 16 + 4 * tp);
 #pragma unroll
-    for (int j = 0; j < 2 * TN; ++j) offB[j] = 2 * PLANE_A + x3_off<BN>(krow, (wn * TN * 2 + j) * 16 + 4 * tp);
+    for (int j = 0; j < 2 * TN; ++j) offB[j] = NPL * PLANE_A + x3_off<BN>(krow, (wn * TN * 2 + j) * 16 + 4 * tp);
 
     auto k32 = [&](const char* st) {
-        f16x8 fb[2 * TN][2];
+        bf16x8 fb[2 * TN][NPL];  // (fp16 bit patterns under NPL == 2: re-typed at the MFMA)
 #pragma unroll
         for (int bj = 0; bj < 2 * TN; ++bj)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
+            for (int s2 = 0; s2 < NPL; ++s2) {
                 const char* b = st + s2 * PLANE_B + offB[bj];
                 const bf16x4 lo = lds_read_tr(b), hi = lds_read_tr(b + 4 * (2 * BN));
-                fb[bj][s2] = __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                fb[bj][s2] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
         for (int bi = 0; bi < 2 * TM; ++bi) {
-            f16x8 fa[2];
+            bf16x8 fa[NPL];
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
+            for (int s2 = 0; s2 < NPL; ++s2) {
                 const char* a = st + s2 * PLANE_A + offA[bi];
                 const bf16x4 lo = lds_read_tr(a), hi = lds_read_tr(a + 4 * (2 * BM));
-                fa[s2] = __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                fa[s2] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
             f32x4 c[2 * TN];
 #pragma unroll
@@ -926,12 +929,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) 
                 c[bj] = f32x4{blk[sb], blk[sb + 1], blk[sb + 2], blk[sb + 3]};
             }
             // per accumulator: lo*hi, hi*lo, hi*hi (the register kernel's order); consecutive MFMAs hit different accumulators
+            if constexpr (NPL == 2) {
+                const f16x8 ah = __builtin_bit_cast(f16x8, fa[0]), al = __builtin_bit_cast(f16x8, fa[NPL - 1]);
 #pragma unroll
-            for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[bj][0], c[bj], 0, 0, 0);
+                for (int bj = 0; bj < 2 * TN; ++bj)
+                    c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, __builtin_bit_cast(f16x8, fb[bj][0]), c[bj], 0, 0, 0);
 #pragma unroll
-            for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][1], c[bj], 0, 0, 0);
+                for (int bj = 0; bj < 2 * TN; ++bj)
+                    c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, fb[bj][NPL - 1]), c[bj], 0, 0, 0);
 #pragma unroll
-            for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][0], c[bj], 0, 0, 0);
+                for (int bj = 0; bj < 2 * TN; ++bj)
+                    c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, fb[bj][0]), c[bj], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][0], c[bj], 0, 0, 0);
+            }
 #pragma unroll
             for (int bj = 0; bj < 2 * TN; ++bj) {
                 const int sb = 4 * (2 * (bi & 1) + (bj & 1));
@@ -951,7 +963,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) 
     };
     // NST stages, the DMA runs NST - 1 reduction steps ahead (every step issues the same number of DMAs -- out of range past
     // the end of the split -- so that the counted wait below always means "chunk kc has landed")
-    constexpr int PER_STEP = 2 * (QA + QB);
+    constexpr int PER_STEP = NPL * (QA + QB);
     static_assert(PER_STEP * (NST - 2) < 64, "vmcnt immediate");
     const int nch = c_end - c_begin;
     if (nch > 0) {
@@ -984,7 +996,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) 
                     const int n = n0 + (wn * TN + j) * 32 + 16 * ((r >> 2) & 1) + (lane & 15);
                     if (FULL || (n < p.Kdim && row < p.K)) {
                         float* dst = out + (size_t)row * p.Kdim + n;
-                        const float v = acc[i][j][r] * o_s;
+                        const float v = NPL == 2 ? acc[i][j][r] * o_s * o_s2 : acc[i][j][r];
                         if constexpr (ATOMIC) atomicAdd(dst, v);
                         else *dst = v;
                     }
@@ -1005,12 +1017,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) 
 template <int TM, int TN, int MODE, int BKP, int X3 = 0>
 int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    // X3 == 4 / 5: plane tensors, two / three LDS stages of two fp16 planes per operand (conv_wgrad4_kernel)
-    constexpr bool P4 = X3 == 4 || X3 == 5;
-    constexpr int NST4 = X3 == 5 ? 3 : 2;
-    constexpr int lds = P4 ? NST4 * 2 * BKP * (BM + BN) * 2
+    // X3 == 4 / 5: plane tensors, two / three LDS stages of two fp16 planes per operand (conv_wgrad4_kernel); 6 / 7: ONE bf16
+    // plane per operand (the mixed-precision bf16 arithmetic), three / four stages
+    constexpr bool P4 = X3 >= 4;
+    constexpr int NPL4 = X3 >= 6 ? 1 : 2;
+    constexpr int NST4 = X3 == 4 ? 2 : (X3 == 7 ? 4 : 3);
+    constexpr int lds = P4 ? NST4 * NPL4 * BKP * (BM + BN) * 2
                            : (X3 ? X3 * BKP * (BM + BN) * 2 : 2 * BKP * (BM + BN) * (int)sizeof(float));
-    const void* kern = P4 ? reinterpret_cast<const void*>(conv_wgrad4_kernel<TM, TN, NST4>)
+    const void* kern = P4 ? reinterpret_cast<const void*>(conv_wgrad4_kernel<TM, TN, NST4, NPL4>)
                           : (X3 ? reinterpret_cast<const void*>(conv_wgrad_x3_kernel<TM, TN, (X3 && !P4) ? X3 : 3>)
                                 : reinterpret_cast<const void*>(conv_wgrad_kernel<TM, TN, MODE, BKP>));
     static std::atomic<unsigned long long> configured{0};
@@ -1036,7 +1050,7 @@ int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     if (a.atomic && !a.dw_zeroed && !a.accumulate) {
         if (hipMemsetAsync(a.dw, 0, (size_t)a.K * a.Kdim * sizeof(float), stream) != hipSuccess) return HN_ELAUNCH;
     }
-    if constexpr (P4) HN_LAUNCH((conv_wgrad4_kernel<TM, TN, NST4>), dim3(tiles * split_k), dim3(256), lds, stream, a);
+    if constexpr (P4) HN_LAUNCH((conv_wgrad4_kernel<TM, TN, NST4, NPL4>), dim3(tiles * split_k), dim3(256), lds, stream, a);
     else if constexpr (X3 != 0) HN_LAUNCH((conv_wgrad_x3_kernel<TM, TN, (X3 && !P4) ? X3 : 3>), dim3(tiles * split_k), dim3(256), lds, stream, a);
     else HN_LAUNCH((conv_wgrad_kernel<TM, TN, MODE, BKP>), dim3(tiles * split_k), dim3(256), lds, stream, a);
     HN_CHECK_LAUNCH();
@@ -1150,9 +1164,10 @@ int wgrad_impl(const float* x, const float* x_scale, const float* dy, const floa
 int wgrad_planes_impl(const void* xh, long long xh_plane, const float* x_scale, const void* dyh, long long dyh_plane,
                       const float* dy_scale, float* dw, const HnConvDesc* d, int split_k, int variant, int flags, float* slab,
                       void* stream) {
-    if (xh == nullptr || dyh == nullptr || x_scale == nullptr || dy_scale == nullptr || dw == nullptr || d == nullptr ||
+    if (xh == nullptr || dyh == nullptr || (x_scale == nullptr) != (dy_scale == nullptr) || dw == nullptr || d == nullptr ||
         xh_plane <= 0 || dyh_plane <= 0 || variant < 0)
         return HN_EINVAL;
+    const bool bf16 = x_scale == nullptr;  // one bf16 plane per operand, no scales
     if (d->N <= 0 || d->Hin <= 0 || d->Win <= 0 || d->Cin <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0 ||
         d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->dil <= 0 || d->pad < 0 || d->ldx < d->Cin || d->ldy < d->Cout)
         return HN_EINVAL;
@@ -1185,6 +1200,9 @@ int wgrad_planes_impl(const void* xh, long long xh_plane, const float* x_scale, 
     if (tn_sel == 1) wide_n = false;
     // variant & 3 == 2: three LDS stages (the DMA two reduction steps ahead) where the tile leaves room for them with two
     // workgroups per CU, i.e. not on 128 x 128
+    if (bf16)  // (a stage is half the size: three stages everywhere, four on request)
+        return (variant & 3) == 2 ? dispatch_wgrad<WG_VEC_BUF, 32, 7>(a, wide_m, wide_n, split_k, static_cast<hipStream_t>(stream))
+                                  : dispatch_wgrad<WG_VEC_BUF, 32, 6>(a, wide_m, wide_n, split_k, static_cast<hipStream_t>(stream));
     if ((variant & 3) == 2 && !(wide_m && wide_n))
         return dispatch_wgrad<WG_VEC_BUF, 32, 5>(a, wide_m, wide_n, split_k, static_cast<hipStream_t>(stream));
     return dispatch_wgrad<WG_VEC_BUF, 32, 4>(a, wide_m, wide_n, split_k, static_cast<hipStream_t>(stream));
@@ -1232,7 +1250,10 @@ extern "C" int hn_conv2d_wgrad_plan(const HnConvDesc* d, int mode, int variant, 
     if (mode == 2) {
         if (d->Cin % 64 != 0 || d->Cout % 64 != 0) return HN_ESHAPE;
         const bool wm = d->Cout % 128 == 0 && tm_sel != 1, wn = d->Cin % 128 == 0 && tn_sel != 1;
-        snprintf(name, name_len, "conv_wgrad4_kernel<%d, %d, %d>", wm ? 2 : 1, wn ? 2 : 1, (bk_sel == 2 && !(wm && wn)) ? 3 : 2);
+        if (math_sel == 3)  // the one-plane bf16 arithmetic
+            snprintf(name, name_len, "conv_wgrad4_kernel<%d, %d, %d, 1>", wm ? 2 : 1, wn ? 2 : 1, bk_sel == 2 ? 4 : 3);
+        else
+            snprintf(name, name_len, "conv_wgrad4_kernel<%d, %d, %d, 2>", wm ? 2 : 1, wn ? 2 : 1, (bk_sel == 2 && !(wm && wn)) ? 3 : 2);
         return HN_OK;
     }
     bool wide_m = d->Cout > 64;

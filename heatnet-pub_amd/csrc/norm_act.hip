@@ -66,6 +66,31 @@ __device__ __forceinline__ void ld_planes(const unsigned short* __restrict__ hi,
     }
 }
 
+// One-plane bf16 tensors (the mixed-precision bf16 arithmetic, HN_MATH_BF16): element (pix, c) is bf16(t) at planes[pix * ldp + c];
+// no scale (bf16 has fp32's exponent range).  Selected by a NULL scale slot wherever a plane operand is described.
+typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+template <int V>
+__device__ __forceinline__ void st_bf16(unsigned short* __restrict__ p, const float (&v)[V]) {
+    if constexpr (V == 4) {
+        b16x4 h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = (__bf16)v[i];
+        *reinterpret_cast<b16x4*>(p) = h;
+    } else {
+        p[0] = __builtin_bit_cast(unsigned short, (__bf16)v[0]);
+    }
+}
+template <int V>
+__device__ __forceinline__ void ld_bf16(const unsigned short* __restrict__ p, float (&v)[V]) {
+    if constexpr (V == 4) {
+        const b16x4 h = *reinterpret_cast<const b16x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (float)h[i];
+    } else {
+        v[0] = (float)__builtin_bit_cast(__bf16, p[0]);
+    }
+}
+
 struct RowLaunch {
     dim3 grid, block;
     int V;
@@ -142,8 +167,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     unsigned amax = 0u;  // largest |z| written by this thread (f16x2 scale of the output, optional)
     float zs = 1.f, zi = 1.f, rs = 1.f, ri = 1.f;
-    if constexpr (ZP) hn_h2_scales_of_slot(zp.slot, zs, zi);
-    if constexpr (RP) hn_h2_scales_of_slot(rp.slot, rs, ri);
+    if constexpr (ZP) { if (zp.slot != nullptr) hn_h2_scales_of_slot(zp.slot, zs, zi); }
+    if constexpr (RP) { if (rp.slot != nullptr) hn_h2_scales_of_slot(rp.slot, rs, ri); }
     if (c < C) {
         float sc[V], sh[V];
         ldv<V>(scale + c, sc);
@@ -152,8 +177,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
         for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
             float v[V], r[V], o[V], m[V];
             ldv<V>(y + pix * ldy + c, v);
-            if constexpr (RP) ld_planes<V>(rp.hi + pix * rp.ld + c, rp.plane, r, ri);
-            else if (res != nullptr) ldv<V>(res + pix * ldr + c, r);
+            if constexpr (RP) {
+                if (rp.slot != nullptr) ld_planes<V>(rp.hi + pix * rp.ld + c, rp.plane, r, ri);
+                else ld_bf16<V>(rp.hi + pix * rp.ld + c, r);
+            } else if (res != nullptr) ldv<V>(res + pix * ldr + c, r);
             if (mask != nullptr) ldv<V>(mask + (pix / hw) * C + c, m);  // Dropout2d keep/(1-p) factor of (image, channel)
 #pragma unroll
             for (int i = 0; i < V; ++i) {
@@ -164,7 +191,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                 amax = max(amax, __float_as_uint(o[i]) & 0x7fffffffu);
             }
             if constexpr (ZP) {
-                st_planes<V>(zp.hi + pix * zp.ld + c, zp.plane, o, zs);
+                if (zp.slot != nullptr) st_planes<V>(zp.hi + pix * zp.ld + c, zp.plane, o, zs);
+                else st_bf16<V>(zp.hi + pix * zp.ld + c, o);
                 if (z != nullptr) stv<V>(z + pix * ldz + c, o);
             } else {
                 stv<V>(z + pix * ldz + c, o);
@@ -406,7 +434,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     unsigned amax = 0u;  // largest |dy| written by this thread (f16x2 scale of the output, optional)
     float ds = 1.f, di = 1.f;
-    if constexpr (DP) hn_h2_scales_of_slot(dp.slot, ds, di);
+    if constexpr (DP) { if (dp.slot != nullptr) hn_h2_scales_of_slot(dp.slot, ds, di); }
     if (c < C) {
     float sc[V], sh[V], mu[V], is[V], ga[V], m1[V], m2[V];
     ldv<V>(scale + c, sc);
@@ -452,8 +480,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
             o[i] = ga[i] * (du[i] - m1[i] - (yy[i] - mu[i]) * is[i] * m2[i]);
             amax = max(amax, __float_as_uint(o[i]) & 0x7fffffffu);
         }
-        if constexpr (DP) st_planes<V>(dp.hi + pix * dp.ld + c, dp.plane, o, ds);
-        else stv<V>(dy + pix * lddy + c, o);
+        if constexpr (DP) {
+            if (dp.slot != nullptr) st_planes<V>(dp.hi + pix * dp.ld + c, dp.plane, o, ds);
+            else st_bf16<V>(dp.hi + pix * dp.ld + c, o);
+        } else {
+            stv<V>(dy + pix * lddy + c, o);
+        }
         if (dres != nullptr) stv<V>(dres + pix * lddr + c, du);
     }
     }
@@ -676,27 +708,29 @@ template <int V>
 __global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ slot,
                                                        unsigned short* __restrict__ planes, long long plane, int ldp,
                                                        int64_t npix, int C) {
-    float s, inv;
-    hn_h2_scales_of_slot(slot, s, inv);
+    float s = 1.f, inv = 1.f;
+    if (slot != nullptr) hn_h2_scales_of_slot(slot, s, inv);
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (c >= C) return;
     for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
         float v[V];
         ldv<V>(x + pix * ldx + c, v);
-        st_planes<V>(planes + pix * ldp + c, plane, v, s);
+        if (slot != nullptr) st_planes<V>(planes + pix * ldp + c, plane, v, s);
+        else st_bf16<V>(planes + pix * ldp + c, v);
     }
 }
 template <int V>
 __global__ __launch_bounds__(256) void from_planes_kernel(const unsigned short* __restrict__ planes, long long plane, int ldp,
                                                          const float* __restrict__ slot, float* __restrict__ x, int ldx,
                                                          int64_t npix, int C) {
-    float s, inv;
-    hn_h2_scales_of_slot(slot, s, inv);
+    float s = 1.f, inv = 1.f;
+    if (slot != nullptr) hn_h2_scales_of_slot(slot, s, inv);
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (c >= C) return;
     for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
         float v[V];
-        ld_planes<V>(planes + pix * ldp + c, plane, v, inv);
+        if (slot != nullptr) ld_planes<V>(planes + pix * ldp + c, plane, v, inv);
+        else ld_bf16<V>(planes + pix * ldp + c, v);
         stv<V>(x + pix * ldx + c, v);
     }
 }
@@ -829,9 +863,9 @@ extern "C" int hn_bn_act_fwd_planes(const float* y, int ldy, const float* scale,
                                     int ldz, void* z_planes, int64_t z_plane_elems, int ldzp, const float* z_slot, int64_t npix,
                                     int C, int act, const float* slope, float leaky_slope, const float* mask, int64_t hw,
                                     unsigned char* relu_bits, void* stream) {
-    if (!y || !scale || !shift || !z_planes || !z_slot || act < 0 || act > 3 || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
+    if (!y || !scale || !shift || !z_planes || act < 0 || act > 3 || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;  // (z_slot NULL: bf16)
     if (residual && res_planes) return HN_EINVAL;
-    if (res_planes && (!res_slot || res_plane_elems < (npix - 1) * ldrp + C || ldrp < C)) return HN_EINVAL;
+    if (res_planes && (res_plane_elems < (npix - 1) * ldrp + C || ldrp < C)) return HN_EINVAL;
     if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
     if (bad_rows(npix, C, {ldy, ldzp}) || (z && ldz < C) || (residual && ldr < C) || z_plane_elems < (npix - 1) * ldzp + C)
         return HN_EINVAL;
@@ -992,7 +1026,7 @@ extern "C" int hn_bn_act_bwd_apply_planes(const float* dz, int lddz, const float
                                           int64_t dy_plane_elems, int lddp, const float* dy_slot, float* dres, int lddr,
                                           int64_t npix, int C, int act, const float* slope, float leaky_slope, const float* mask,
                                           int64_t hw, const unsigned char* relu_bits, void* stream) {
-    if (!dy_planes || !dy_slot || lddp < C || dy_plane_elems < (npix - 1) * lddp + C) return HN_EINVAL;
+    if (!dy_planes || lddp < C || dy_plane_elems < (npix - 1) * lddp + C) return HN_EINVAL;  // (dy_slot NULL: bf16)
     return bn_bwd_apply_impl(dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, dparams, count, training, nullptr, C, dres,
                              lddr, npix, C, act, slope, leaky_slope, mask, hw, nullptr, relu_bits, stream,
                              PlaneOut{static_cast<unsigned short*>(dy_planes), (long long)dy_plane_elems, lddp, dy_slot});
@@ -1105,7 +1139,7 @@ extern "C" int hn_copy(const float* x, int ldx, float* y, int ldy, int64_t npix,
 
 extern "C" int hn_tensor_to_planes(const float* x, int ldx, int64_t npix, int C, const float* scale, void* planes,
                                    int64_t plane_elems, int ldp, void* stream) {
-    if (!x || !scale || !planes || bad_rows(npix, C, {ldx, ldp}) || plane_elems < (npix - 1) * ldp + C) return HN_EINVAL;
+    if (!x || !planes || bad_rows(npix, C, {ldx, ldp}) || plane_elems < (npix - 1) * ldp + C) return HN_EINVAL;  // (scale NULL: bf16)
     hipStream_t s = static_cast<hipStream_t>(stream);
     RowLaunch pl = plan_rows(npix, C, {x}, {ldx});
     if (pl.V == 4 && (ldp % 4 != 0 || plane_elems % 4 != 0 || (reinterpret_cast<uintptr_t>(planes) & 7u) != 0)) {
@@ -1119,7 +1153,7 @@ extern "C" int hn_tensor_to_planes(const float* x, int ldx, int64_t npix, int C,
 
 extern "C" int hn_planes_to_tensor(const void* planes, int64_t plane_elems, int ldp, const float* scale, float* x, int ldx,
                                    int64_t npix, int C, void* stream) {
-    if (!x || !scale || !planes || bad_rows(npix, C, {ldx, ldp}) || plane_elems < (npix - 1) * ldp + C) return HN_EINVAL;
+    if (!x || !planes || bad_rows(npix, C, {ldx, ldp}) || plane_elems < (npix - 1) * ldp + C) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     RowLaunch pl = plan_rows(npix, C, {x}, {ldx});
     if (pl.V == 4 && (ldp % 4 != 0 || plane_elems % 4 != 0 || (reinterpret_cast<uintptr_t>(planes) & 7u) != 0))

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void bilinear_up2_fwd_kernel(const float* __re
                                                               int N, int H, int W, int C, unsigned short* __restrict__ yh = nullptr,
                                                               long long yplane = 0, const float* __restrict__ slot = nullptr) {
     float ps = 1.f, pi = 1.f;
-    if constexpr (PL) hn_h2_scales_of_slot(slot, ps, pi);
+    if constexpr (PL) { if (slot != nullptr) hn_h2_scales_of_slot(slot, ps, pi); }
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (c >= C) return;
     const int64_t npix = (int64_t)N * H * W;
@@ -355,7 +355,10 @@ __global__ __launch_bounds__(256) void bilinear_up2_fwd_kernel(const float* __re
                 const int64_t opix = ((int64_t)(n * 2 * H + 2 * h + dh) * Wo + 2 * w + dw);
                 if constexpr (PL) {
                     unsigned short* dst = yh + opix * ldy + c;
-                    if constexpr (V == 4) {
+                    if (slot == nullptr) {  // one bf16 plane
+#pragma unroll
+                        for (int i = 0; i < V; ++i) dst[i] = __builtin_bit_cast(unsigned short, (__bf16)o[i]);
+                    } else if constexpr (V == 4) {
                         h16x4s hh, ll;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
@@ -648,7 +651,7 @@ extern "C" int hn_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N
 
 extern "C" int hn_bilinear_up2_planes(const float* x, int ldx, const float* slot, void* y_planes, int64_t plane_elems, int ldp,
                                       int N, int Hin, int Win, int C, void* stream) {
-    if (!x || !slot || !y_planes || bad_geom(N, Hin, Win, C, 2 * Hin, 2 * Win, ldx, ldp)) return HN_EINVAL;
+    if (!x || !y_planes || bad_geom(N, Hin, Win, C, 2 * Hin, 2 * Win, ldx, ldp)) return HN_EINVAL;  // (slot NULL: bf16)
     if (plane_elems < ((int64_t)N * 4 * Hin * Win - 1) * ldp + C) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool v4 = (reinterpret_cast<uintptr_t>(y_planes) & 7u) == 0 && plane_elems % 4 == 0 && ldp % 4 == 0;

@@ -1128,36 +1128,49 @@ class _PlanesToTensor(torch.autograd.Function):
 def as_f32(t):
     """The activation as an ordinary fp32 tensor: a plane tensor is converted (one pass; gradients pass through unchanged)."""
     if t is not None and is_planes(t):
-        slot = t._hn_planes
+        slot = _plane_slot(t._hn_planes)
         out = _PlanesToTensor.apply(t)
-        out._hn_scale = (out._version, slot)
+        if slot is not None:
+            out._hn_scale = (out._version, slot)
         return out
     return t
 
 
-def planes_of(t):
-    """(plane tensor, scale slot) of an activation: itself, its twin, or a twin made now (hn_absmax_scale unless the tensor
+BF16_PLANE = "bf16"  # `_hn_planes` marker of a ONE-plane bf16 tensor (the mixed-precision bf16 arithmetic): bf16(t), no scale
+
+
+def _plane_slot(marker):
+    """The scale slot a kernel takes for a plane tensor's marker (None: one bf16 plane)."""
+    return None if isinstance(marker, str) else marker
+
+
+def planes_of(t, bf16=False):
+    """(plane tensor, marker) of an activation in the format of the current arithmetic (`bf16`: one bf16 plane; else fp16
+    hi / lo planes with a scale slot = the marker): itself, its twin, or a twin made now (hn_absmax_scale unless the tensor
     carries a scale + hn_tensor_to_planes) and remembered on the tensor."""
-    slot = getattr(t, "_hn_planes", None)
-    if slot is not None:
-        return t, slot
+    fits = lambda m: isinstance(m, str) == bf16
+    marker = getattr(t, "_hn_planes", None)
+    if marker is not None:
+        if fits(marker):
+            return t, marker
+        t = as_f32(t)  # a plane tensor of the other arithmetic (the arithmetic was switched between two layers)
     twin = getattr(t, "_hn_twin", None)
-    if twin is not None and twin[0] == t._version:
+    if twin is not None and twin[0] == t._version and fits(twin[1]._hn_planes):
         return twin[1], twin[1]._hn_planes
     x, ldx = as_nhwc(t)
     n, c, h, w = x.shape
-    slot = tensor_scale(x, ldx, owner=t)
+    marker = BF16_PLANE if bf16 else tensor_scale(x, ldx, owner=t)
     pt = new_nhwc(n, c, h, w, x.device)
-    check(_lib.load().hn_tensor_to_planes(_ptr(x), ldx, n * h * w, c, _ptr(slot), _ptr(pt), n * h * w * c, c, _stream()),
-          "hn_tensor_to_planes")
-    pt._hn_planes = slot
+    check(_lib.load().hn_tensor_to_planes(_ptr(x), ldx, n * h * w, c, _ptr(_plane_slot(marker)), _ptr(pt), n * h * w * c, c,
+                                          _stream()), "hn_tensor_to_planes")
+    pt._hn_planes = marker
     t._hn_twin = (t._version, pt)
-    return pt, slot
+    return pt, marker
 
 
 def planes_to_tensor(t):
     """fp32 values of a plane tensor (diagnostics / tests)."""
-    slot = t._hn_planes
+    slot = _plane_slot(t._hn_planes)
     n, c, h, w = t.shape
     out = new_nhwc(n, c, h, w, t.device)
     check(_lib.load().hn_planes_to_tensor(_ptr(t), n * h * w * c, c, _ptr(slot), _ptr(out), c, n * h * w, c, _stream()),
@@ -1176,14 +1189,15 @@ def _plane_variants(cout, cred, taps):
     return [0, 1, 2, 3] + ([4, 5, 6] if light else [])
 
 
-def _wgrad_plane_candidates(cout, cin):
+def _wgrad_plane_candidates(cout, cin, bf16=False):
     tms = (0, 1) if cout % 128 == 0 else (0,)
     tns = (0, 1) if cin % 128 == 0 else (0,)
     cands = []
     for tm in tms:
         for tn in tns:
             wide = cout % 128 == 0 and tm != 1 and cin % 128 == 0 and tn != 1
-            for bk in ((0,) if wide else (0, 2)):  # 2: three LDS stages (not on the 128 x 128 tile)
+            # bk 2: f16x2 -- three LDS stages instead of two (not on the 128 x 128 tile); bf16 -- four instead of three
+            for bk in ((0, 2) if (bf16 or not wide) else (0,)):
                 cands += [(split, bk + 4 * tm + 16 * tn) for split in (0, -2, -3, -4)]
     return cands
 
@@ -1192,11 +1206,11 @@ def fused_conv_bn_ok(x, conv_w, stride, pad, dil, bn_training, shape=None):
     """Does the fused plane-tensor node cover this conv -> BatchNorm pair?  (f16x2 layer, batch statistics, whole 64-channel
     blocks both ways, enough pixels that neither the forward nor the data gradient would want split-K)  `shape`: the input's
     (N, C, H, W) when it differs from x's (a resampling in between)."""
-    if not (PLANES and CONV_MATH == "f16x2" and not _MATH_F32_KINDS and bn_training and x.is_cuda and x.dim() == 4):
+    if not (PLANES and CONV_MATH in ("f16x2", "bf16") and not _MATH_F32_KINDS and bn_training and x.is_cuda and x.dim() == 4):
         return False
     cout, cin, kh, kw = conv_w.shape
     n, c_in, h, w = shape if shape is not None else x.shape
-    if c_in != cin or cin % 64 != 0 or cout % 64 != 0 or _layer_math("fwd", cin, cout, kh, kw, conv_w) != "f16x2":
+    if c_in != cin or cin % 64 != 0 or cout % 64 != 0 or _layer_math("fwd", cin, cout, kh, kw, conv_w) != CONV_MATH:
         return False
     ho, wo = conv_out_size(h, kh, stride, pad, dil), conv_out_size(w, kw, stride, pad, dil)
     if h * w < 128 or ho * wo < 128 or n * ho * wo <= 2048 or n * h * w <= 2048 * (4 if stride == 2 else 1):
@@ -1216,27 +1230,31 @@ class _ConvBnAct(torch.autograd.Function):
         lib = _lib.load()
         (stride, pad, dil, act, leaky, momentum, eps, ws, drop_mask, passthrough, out_mode, mask_max) = cfg
         s = _stream()
-        xp, x_slot = planes_of(x)
+        bf16 = CONV_MATH == "bf16"  # one bf16 plane per operand, no scales; else f16x2: fp16 hi / lo planes + scale slots
+        xp, x_mark = planes_of(x, bf16)
+        x_slot = _plane_slot(x_mark)
         n, cin, h, wd = xp.shape
         w_in, w = w, weight_ohwi(w)
         cout, _, kh, kw = w.shape
         ho, wo = conv_out_size(h, kh, stride, pad, dil), conv_out_size(wd, kw, stride, pad, dil)
         npix = n * ho * wo
         dev = xp.device
-        wh, ctx.wt, ctx.wth = _weight_operands(w_in, w, stride, pad, dil, "f16x2", ctx.needs_input_grad[0], s)
+        wh, ctx.wt, ctx.wth = _weight_operands(w_in, w, stride, pad, dil, CONV_MATH, ctx.needs_input_grad[0], s)
         y = new_nhwc(n, cout, ho, wo, dev)
         d = _desc(n, h, wd, cin, cin, ho, wo, cout, cout, kh, kw, stride, pad, dil)
         ws.open_stats()
         xplane = n * h * wd * cin
-        if RANGE_CENSUS:
+        if RANGE_CENSUS and not bf16:
             _census_operand(_leaf(w_in), 0, None, xp, cin, x_slot, n * h * wd, cin)
+        tag = ".bf16p" if bf16 else ".planes"
+        mcode = 3 if bf16 else 4
 
         def launch(v, st, keys):
             check(lib.hn_conv2d_fwd_planes(_ptr(xp), xplane, _ptr(x_slot), _ptr(wh), _ptr(b), _ptr(y), _ptr(st), _ptr(keys),
                                            ctypes.byref(d), ACT_NONE, 0.0, v, s), "hn_conv2d_fwd_planes")
-        var = _pick("fwd.planes", d, _plane_variants(cout, cin, kh * kw), lambda v: launch(v, None, None))
-        with _ConvTimer("fwd", d, lambda: _plan_name(0, d, 3, _variant(var, 0, 0, 4))):
-            launch(var, ws.stats, ws.keys)
+        var = _pick("fwd" + tag, d, _plane_variants(cout, cin, kh * kw), lambda v: launch(v, None, None))
+        with _ConvTimer("fwd", d, lambda: _plan_name(0, d, 3, _variant(var & 3, var >> 2, 0, mcode))):
+            launch(var, ws.stats, None if bf16 else ws.keys)
         # batch statistics -> normalisation constants, and the bound of |z| (the scale z is written with)
         par = torch.empty(5 * cout, device=dev, dtype=torch.float32)  # mean | invstd | scale | shift | max |xhat|
         mean, invstd, scale, shift, xhat = (par[i * cout:(i + 1) * cout] for i in range(5))
@@ -1246,16 +1264,21 @@ class _ConvBnAct(torch.autograd.Function):
         if residual is not None:
             if act in (ACT_PRELU, ACT_LEAKY):
                 raise RuntimeError("conv_bn_act: a residual input is only supported with ReLU / no activation")
-            if is_planes(residual):
-                res_p, res_slot = residual, residual._hn_planes
+            if is_planes(residual) and isinstance(residual._hn_planes, str) == bf16:
+                res_p, res_slot = residual, _plane_slot(residual._hn_planes)
             else:
-                res_f, ldr = as_nhwc(residual)
-                res_slot = tensor_scale(res_f, ldr, owner=residual)
-        z_slot = _new_scale_slot(dev)
-        check(lib.hn_bn_finalize_range(_ptr(ws.stats), _ptr(ws.keys), npix, _ptr(gamma), _ptr(beta), _ptr(running_mean),
-                                       _ptr(running_var), momentum, eps, _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift),
-                                       _ptr(xhat), cout, act, _ptr(prelu_w), leaky, _ptr(res_slot), mask_max, _ptr(z_slot), s),
-              "hn_bn_finalize_range")
+                res_f, ldr = as_nhwc(as_f32(residual))
+                res_slot = None if bf16 else tensor_scale(res_f, ldr, owner=residual)
+        if bf16:
+            z_slot = None
+            check(lib.hn_bn_finalize(_ptr(ws.stats), npix, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                     momentum, eps, _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift), cout, s), "hn_bn_finalize")
+        else:
+            z_slot = _new_scale_slot(dev)
+            check(lib.hn_bn_finalize_range(_ptr(ws.stats), _ptr(ws.keys), npix, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                           _ptr(running_var), momentum, eps, _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift),
+                                           _ptr(xhat), cout, act, _ptr(prelu_w), leaky, _ptr(res_slot), mask_max, _ptr(z_slot),
+                                           s), "hn_bn_finalize_range")
         ws.stats_open = False
         zf = new_nhwc(n, cout, ho, wo, dev) if out_mode != "planes" else None
         zp = new_nhwc(n, cout, ho, wo, dev) if out_mode != "f32" else None
@@ -1269,14 +1292,14 @@ class _ConvBnAct(torch.autograd.Function):
                                            _ptr(res_slot) if res_p is not None else None, _ptr(zf), cout, _ptr(zp), npix * cout,
                                            cout, _ptr(z_slot), npix, cout, act, _ptr(prelu_w), leaky, _ptr(drop_mask), ho * wo,
                                            _ptr(rbits), s), "hn_bn_act_fwd_planes")
-            zp._hn_planes = z_slot
+            zp._hn_planes = BF16_PLANE if bf16 else z_slot
         else:
             if res_p is not None:
                 raise RuntimeError("conv_bn_act: a plane-tensor residual needs a plane (or dual) output")
             check(lib.hn_bn_act_fwd(_ptr(y), cout, _ptr(scale), _ptr(shift), _ptr(res_f), ldr, _ptr(zf), cout, npix, cout, act,
                                     _ptr(prelu_w), leaky, _ptr(drop_mask), ho * wo, None, _ptr(rbits), s), "hn_bn_act_fwd")
         ctx.cfg = (stride, pad, dil, act, leaky, passthrough, residual is not None, out_mode)
-        ctx.ws, ctx.drop_mask, ctx.x_slot = ws, drop_mask, x_slot
+        ctx.ws, ctx.drop_mask, ctx.x_slot, ctx.bf16 = ws, drop_mask, x_slot, bf16
         ctx.leaves = (_leaf(w_in), _leaf(b), _leaf(gamma), _leaf(beta), _leaf(prelu_w))
         # z itself is needed by the backward only for a ReLU behind a residual add without the byte mask
         keep_z = zf if (act == ACT_RELU and residual is not None and rbits is None and zf is not None) else None
@@ -1284,7 +1307,7 @@ class _ConvBnAct(torch.autograd.Function):
             raise RuntimeError("conv_bn_act: plane-only output behind a residual ReLU needs the byte mask (C % 4, HEATNET_RELU_BITS)")
         ctx.save_for_backward(xp, w, y, par, gamma, prelu_w, rbits, keep_z)
         out = zf if zf is not None else zp
-        _last_fused["slot"], _last_fused["twin"] = z_slot, (zp if zf is not None else None)
+        _last_fused["slot"], _last_fused["twin"] = (BF16_PLANE if bf16 else z_slot), (zp if zf is not None else None)
         if passthrough:
             return out, x.view_as(x)
         return out
@@ -1317,13 +1340,22 @@ class _ConvBnAct(torch.autograd.Function):
             sg = sb = sp = None
             used = []
         accumulate = bool(used) and not used[0][1]
-        dy_slot = _new_scale_slot(dev)
-        check(lib.hn_bn_act_bwd_reduce_range(_ptr(dz), lddz, _ptr(z), cout, _ptr(y), cout, _ptr(mean), _ptr(invstd), _ptr(scale),
-                                             _ptr(shift), npix, cout, act, _ptr(prelu_w), leaky, _ptr(ws.bwd), _ptr(dpar),
-                                             _ptr(sg[0]) if sg else None, _ptr(sb[0]) if sb else None,
-                                             _ptr(sp[0]) if sp else None, int(accumulate), _ptr(ctx.drop_mask), ho * wo,
-                                             _ptr(rbits), _ptr(ws.gmax), _ptr(gamma), _ptr(xhat), npix, 1, _ptr(dy_slot), s),
-              "hn_bn_act_bwd_reduce_range")
+        bf16 = ctx.bf16
+        if bf16:
+            dy_slot = None
+            check(lib.hn_bn_act_bwd_reduce(_ptr(dz), lddz, _ptr(z), cout, _ptr(y), cout, _ptr(mean), _ptr(invstd), _ptr(scale),
+                                           _ptr(shift), npix, cout, act, _ptr(prelu_w), leaky, _ptr(ws.bwd), _ptr(dpar),
+                                           _ptr(sg[0]) if sg else None, _ptr(sb[0]) if sb else None,
+                                           _ptr(sp[0]) if sp else None, int(accumulate), _ptr(ctx.drop_mask), ho * wo,
+                                           _ptr(rbits), s), "hn_bn_act_bwd_reduce")
+        else:
+            dy_slot = _new_scale_slot(dev)
+            check(lib.hn_bn_act_bwd_reduce_range(_ptr(dz), lddz, _ptr(z), cout, _ptr(y), cout, _ptr(mean), _ptr(invstd),
+                                                 _ptr(scale), _ptr(shift), npix, cout, act, _ptr(prelu_w), leaky, _ptr(ws.bwd),
+                                                 _ptr(dpar), _ptr(sg[0]) if sg else None, _ptr(sb[0]) if sb else None,
+                                                 _ptr(sp[0]) if sp else None, int(accumulate), _ptr(ctx.drop_mask), ho * wo,
+                                                 _ptr(rbits), _ptr(ws.gmax), _ptr(gamma), _ptr(xhat), npix, 1, _ptr(dy_slot), s),
+                  "hn_bn_act_bwd_reduce_range")
         ws.bwd_open = False
         dres = new_nhwc(n, cout, ho, wo, dev) if (has_res and ctx.needs_input_grad[7]) else None
         dx = dw_out = db = None
@@ -1334,8 +1366,10 @@ class _ConvBnAct(torch.autograd.Function):
                                                  _ptr(dy_slot), _ptr(dres), cout, npix, cout, act, _ptr(prelu_w), leaky,
                                                  _ptr(ctx.drop_mask), ho * wo, _ptr(rbits), s), "hn_bn_act_bwd_apply_planes")
         d = _desc(n, h, wd, cin, cin, ho, wo, cout, cout, kh, kw, stride, pad, dil)
-        if RANGE_CENSUS and (need_x or need_w):
+        if RANGE_CENSUS and (need_x or need_w) and not bf16:
             _census_operand(lw, 1, None, dyp, cout, dy_slot, npix, cout)
+        tag = ".bf16p" if bf16 else ".planes"
+        mcode = 3 if bf16 else 4
         # ---- data gradient ----
         if need_x:
             dx = new_nhwc(n, cin, h, wd, dev)
@@ -1344,8 +1378,8 @@ class _ConvBnAct(torch.autograd.Function):
             def launch(v, ad, ld):
                 check(lib.hn_conv2d_dgrad_planes(_ptr(dyp), npix * cout, _ptr(dy_slot), _ptr(ctx.wth), _ptr(dx), _ptr(ad), ld,
                                                  ctypes.byref(d), v, s), "hn_conv2d_dgrad_planes")
-            var = _pick("dgrad.planes", d, _plane_variants(cin, cout, kh * kw), lambda v: launch(v, None, 0))
-            with _ConvTimer("dgrad", d, lambda: _plan_name(1, d, 3, _variant(var, 0, 0, 4))):
+            var = _pick("dgrad" + tag, d, _plane_variants(cin, cout, kh * kw), lambda v: launch(v, None, 0))
+            with _ConvTimer("dgrad", d, lambda: _plan_name(1, d, 3, _variant(var & 3, var >> 2, 0, mcode))):
                 launch(var, add, ldadd)
         elif dskip is not None:
             dx = dskip
@@ -1367,14 +1401,14 @@ class _ConvBnAct(torch.autograd.Function):
             if DETERMINISTIC:
                 splits = max(1, min(32, npix // 4096))
                 wsp = _det_workspace(dev, splits * dw.numel())
-                with _ConvTimer("wgrad", d, lambda: _wgrad_plan_name(d, 2, 0)):
+                with _ConvTimer("wgrad", d, lambda: _wgrad_plan_name(d, 2, _variant(0, 0, 0, mcode))):
                     check(lib.hn_conv2d_wgrad_det_planes(_ptr(xp), xplane, _ptr(ctx.x_slot), _ptr(dyp), npix * cout, _ptr(dy_slot),
                                                          _ptr(dw), ctypes.byref(d), splits, 0, flags & 2, _ptr(wsp), s),
                           "hn_conv2d_wgrad_det_planes")
             else:
-                split, var = _pick("wgrad.planes", d, _wgrad_plane_candidates(cout, cin),
+                split, var = _pick("wgrad" + tag, d, _wgrad_plane_candidates(cout, cin, bf16),
                                    lambda sv: wgrad(_tune_scratch(dw) if flags else dw, sv[0], sv[1], 0))
-                with _ConvTimer("wgrad", d, lambda: _wgrad_plan_name(d, 2, var)):
+                with _ConvTimer("wgrad", d, lambda: _wgrad_plan_name(d, 2, var + 64 * mcode)):
                     wgrad(dw, split, var, flags)
         if lbias is not None and ctx.needs_input_grad[2]:
             # the output is normalised with batch statistics: the bias cancels, its gradient is exactly zero
@@ -1406,7 +1440,8 @@ def conv_bn_act_fused(x, w, b, gamma, beta, running_mean, running_var, residual,
     if out_mode == "planes":
         z._hn_planes = slot
     else:
-        z._hn_scale = (z._version, slot)  # (a bound of max |z|: valid wherever a scale is taken)
+        if not isinstance(slot, str):
+            z._hn_scale = (z._version, slot)  # (a bound of max |z|: valid wherever a scale is taken)
         if twin is not None:
             z._hn_twin = (z._version, twin)
     if passthrough:
@@ -1608,6 +1643,10 @@ class _BilinearUp2Planes(torch.autograd.Function):
 def bilinear_up2_planes(x):
     """Exact x2 bilinear upsampling as a plane tensor (for conv_bn_act only)."""
     x = as_f32(x)
+    if CONV_MATH == "bf16":
+        y = _BilinearUp2Planes.apply(x, None)
+        y._hn_planes = BF16_PLANE
+        return y
     xn, ldx = as_nhwc(x)
     slot = tensor_scale(xn, ldx, owner=x)
     y = _BilinearUp2Planes.apply(x, slot)
@@ -1723,6 +1762,52 @@ class _Concat(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         return tuple(dy[:, c0:c0 + c] for c0, c in ctx.splits)
+
+
+class _SplitColumns(torch.autograd.Function):
+    """w[:, a_i:b_i] for consecutive input-channel ranges of a 1x1 weight (the pyramid bottleneck applied per pyramid level,
+    pspnet.PSPModule) as ONE autograd node: the backward places every slice's gradient into its columns of one full-size
+    gradient -- the parameter's arena slot when it has one -- with strided copies.  Plain slicing costs, per slice, a
+    full-size zero fill, a copy and a full-size accumulation add in ATen."""
+
+    @staticmethod
+    def forward(ctx, w, *sizes):
+        ctx.sizes = sizes
+        ctx.leaf = _leaf(w)
+        ctx.shape, ctx.strides = tuple(w.shape), tuple(w.stride())
+        outs, a = [], 0
+        for f in sizes:
+            outs.append(w[:, a:a + f])
+            a += f
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.load()
+        cout, ctot = ctx.shape[0], ctx.shape[1]
+        slot = grad_slot(ctx.leaf, accumulate_ok=False) if ctx.leaf is not None else None
+        dev = next(g.device for g in grads if g is not None)
+        if slot is not None and slot[1] and slot[0].stride() == ctx.strides:
+            full = slot[0]
+        else:
+            full = torch.empty_strided(ctx.shape, ctx.strides, device=dev, dtype=torch.float32)
+        dense = full.stride(1) == 1 and full.stride(0) == ctot  # [Cout][Ctot] rows (OIHW 1x1 in channels-last memory)
+        a = 0
+        for f, g in zip(ctx.sizes, grads):
+            dst = full[:, a:a + f]
+            if g is None:
+                dst.zero_()
+            elif dense and g.stride(1) == 1 and g.is_cuda:
+                check(lib.hn_copy(_ptr(g), g.stride(0), ctypes.c_void_p(full.data_ptr() + 4 * a), ctot, cout, f, _stream()), "hn_copy")
+            else:
+                dst.copy_(g)
+            a += f
+        return (full,) + (None,) * len(ctx.sizes)
+
+
+def split_columns(w, sizes):
+    """Consecutive input-channel slices of a [Cout, sum(sizes), 1, 1] weight with a single fused gradient (see _SplitColumns)."""
+    return _SplitColumns.apply(w, *[int(f) for f in sizes])
 
 
 def concat(xs):

@@ -34,17 +34,21 @@ class PSPModule(nn.Module):
         w = self.bottleneck.weight
         f = feats.size(1)
         k = len(self.stages)
+        if w.is_cuda and w.size(1) == (k + 1) * f:
+            cols = ops.split_columns(w, [f] * (k + 1))  # one autograd node: the slices' gradients land in ONE full-size dW
+        else:
+            cols = [w[:, i * f:(i + 1) * f] for i in range(k + 1)]
         if feats.requires_grad:
             # the pooled branches read the main conv's pass-through alias: their (single, fused) gradient enters the
             # main conv's dgrad kernel as its addend instead of being summed by autograd
-            main, feats = ops.conv2d(feats, w[:, k * f:(k + 1) * f], self.bottleneck.bias, passthrough=True)
+            main, feats = ops.conv2d(feats, cols[k], self.bottleneck.bias, passthrough=True)
         else:
-            main = ops.conv2d(feats, w[:, k * f:(k + 1) * f], self.bottleneck.bias)
+            main = ops.conv2d(feats, cols[k], self.bottleneck.bias)
         pooled = ops.pyramid_pool(feats, [stage[0].output_size for stage in self.stages])
         levels = []
         for i, stage in enumerate(self.stages):
-            q = stage[1](pooled[i])                              # 1x1 conv (C -> C) at s x s
-            levels.append(ops.conv2d(q, w[:, i * f:(i + 1) * f]))  # this level's slice of the bottleneck, still s x s
+            q = stage[1](pooled[i])                  # 1x1 conv (C -> C) at s x s
+            levels.append(ops.conv2d(q, cols[i]))    # this level's slice of the bottleneck, still s x s
         return ops.pyramid_merge(main, levels)
 
 

@@ -161,7 +161,7 @@ def test_conv_planes_refusals(dev):
     xh, xplane = to_planes(lib, x, xs)
     y = torch.empty(n, h, w_, cout, device=dev)
     d = _lib.HnConvDesc(n, h, w_, cin, cin, h, w_, cout, cout, k, k, 1, 1, 1)
-    assert lib.hn_conv2d_fwd_planes(P(xh), xplane, None, P(wh), None, P(y), None, None, ctypes.byref(d), 0, 0.0, 0, s) == -1
+    # (x_scale = NULL is the one-plane bf16 form, test_conv_planes_bf16_bitwise)
     assert lib.hn_conv2d_fwd_planes(None, xplane, P(xs), P(wh), None, P(y), None, None, ctypes.byref(d), 0, 0.0, 0, s) == -1
     d48 = _lib.HnConvDesc(n, h, w_, 48, 48, h, w_, cout, cout, k, k, 1, 1, 1)  # Cin % 32 != 0
     assert lib.hn_conv2d_fwd_planes(P(xh), xplane, P(xs), P(wh), None, P(y), None, None, ctypes.byref(d48), 0, 0.0, 0, s) == -4
@@ -238,12 +238,16 @@ FUSED_CASES = [  # cin, cout, k, stride, dil, act, residual ("f32" | "planes" | 
 ]
 
 
+@pytest.mark.parametrize("math", ["f16x2", "bf16"])
 @pytest.mark.parametrize("case", FUSED_CASES, ids=str)
-def test_fused_conv_bn_act_matches_unfused(dev, case):
+def test_fused_conv_bn_act_matches_unfused(dev, case, math):
     """layers.conv_bn_act through the fused plane-tensor node (conv_igemm4 + range-bounded scales + plane-writing BatchNorm
     passes + conv_wgrad4) against the same call with HEATNET_PLANES off (fp32 tensors, operands split in the kernels): outputs,
     input / residual / parameter gradients and running statistics.  Without a residual the bound equals the maximum, both
-    paths use the same scales and the convolution outputs agree bitwise; with one the scale may differ by a factor of two."""
+    paths use the same scales and the convolution outputs agree bitwise; with one the scale may differ by a factor of two.
+    math = "bf16" (the mixed-precision arithmetic): the fused node keeps ONE bf16 image per operand; the unfused path rounds the
+    same fp32 values to bf16 in the convolution loaders, so everything agrees to fp32 noise except what was STORED in bf16 --
+    a plane output, a plane residual (2^-9 relative)."""
     import torch.nn as nn
     from heatnet_amd import layers, ops
     cin, cout, k, stride, dil, act, res_kind, use_mask, out_mode = case
@@ -278,13 +282,13 @@ def test_fused_conv_bn_act_matches_unfused(dev, case):
                     class _ToPlanes(torch.autograd.Function):
                         @staticmethod
                         def forward(ctx, t):
-                            pt, slot = ops.planes_of(t)
+                            pt, slot = ops.planes_of(t, math == "bf16")
                             return pt.clone()
 
                         @staticmethod
                         def backward(ctx, g_):
                             return g_
-                    pt, slot = ops.planes_of(res)
+                    pt, slot = ops.planes_of(res, math == "bf16")
                     res = _ToPlanes.apply(res)
                     res._hn_planes = slot
             mask = None
@@ -295,7 +299,8 @@ def test_fused_conv_bn_act_matches_unfused(dev, case):
             zf = ops.planes_to_tensor(z) if ops.is_planes(z) else z.detach()
             twin = getattr(z, "_hn_twin", None)
             if twin is not None:
-                assert float((ops.planes_to_tensor(twin[1]) - z.detach()).abs().max()) <= 2.0 ** -21 * float(z.detach().abs().max())
+                assert float((ops.planes_to_tensor(twin[1]) - z.detach()).abs().max()) <= \
+                    (2.0 ** -8 if math == "bf16" else 2.0 ** -21) * float(z.detach().abs().max())
             gz = (torch.randn(n, cout, ho, wo, generator=g) * 1e-3).to(dev).contiguous(memory_format=torch.channels_last)
             z.backward(gz)
             outs = dict(z=zf, dx=x.grad, dw=conv.weight.grad, dgamma=bn.weight.grad, dbeta=bn.bias.grad,
@@ -308,16 +313,21 @@ def test_fused_conv_bn_act_matches_unfused(dev, case):
             return {k_: v.detach().float().cpu() for k_, v in outs.items()}
         finally:
             ops.PLANES = prev
-    prev_math = ops.set_conv_math("f16x2")
+    prev_math = ops.set_conv_math(math)
     try:
         a, b = run(True), run(False)
     finally:
         ops.set_conv_math(prev_math)
+    stored16 = math == "bf16" and (out_mode == "planes" or res_kind == "planes")  # something was kept in bf16
     for key in b:
         ref = b[key]
         tol = 2e-6 if key in ("z", "rm", "rv") else 2e-5
         if key == "dprelu":
             tol = 1e-3  # one scalar: a sum of 10^5 cancelling terms
+        if stored16 and key == "z":
+            tol = 2.0 ** -8
+        elif stored16 and res_kind == "planes" and key not in ("rm", "rv"):
+            tol = 2e-3  # the ReLU mask behind the residual add sees the bf16-rounded residual
         err = float((a[key] - ref).abs().max())
         assert err <= tol * max(float(ref.abs().max()), 1e-30), (key, err, float(ref.abs().max()))
 
@@ -373,3 +383,51 @@ def test_f16x2_range_guard_moves_heavy_tailed_layers_to_bf16x3(dev):
         ops.set_range_census(prev_census)
         ops.set_conv_math(prev_math)
         ops._census.clear()
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("case", PLANE_CONV_CASES[:5] + PLANE_CONV_CASES[6:], ids=str)
+def test_conv_planes_bf16_bitwise(dev, case, tile):
+    """The mixed-precision bf16 arithmetic on ONE bf16 image per operand (x_scale = NULL): forward, data gradient and weight
+    gradient equal, bit for bit, the kernels that round the fp32 operands to bf16 in their loaders (variant math 3)."""
+    from heatnet_amd import _lib, ops
+    lib = _lib.load()
+    s = _stream()
+    n, cin, h, w_, cout, k, stride, pad, dil = case
+    ho, wo = ops.conv_out_size(h, k, stride, pad, dil), ops.conv_out_size(w_, k, stride, pad, dil)
+    x = F.relu(rnd(n, h, w_, cin, seed=41)).to(dev)
+    wt = rnd(cout, k, k, cin, seed=42, scale=1.0 / np.sqrt(cin * k * k)).to(dev)
+    b = rnd(cout, seed=43).to(dev)
+    gy = (rnd(n, ho, wo, cout, seed=44) * 1e-3).to(dev)
+    skip = (rnd(n, h, w_, cin, seed=45) * 1e-3).to(dev)
+    nw, plane_w = wt.numel(), ops.x3_plane(wt.numel())
+    w3, wt3, wtf = (torch.empty(3 * plane_w, device=dev, dtype=torch.int16), torch.empty(3 * plane_w, device=dev, dtype=torch.int16),
+                    torch.empty(nw, device=dev))
+    _lib.check(lib.hn_weight_flip_transpose(P(wt), P(w3), P(wtf), P(wt3), cout, k, k, cin, stride, pad, dil, s), "flip")
+    d = _lib.HnConvDesc(n, h, w_, cin, cin, ho, wo, cout, cout, k, k, stride, pad, dil)
+    vb = ops._variant(0, 0, 0, 3)
+    lib.hn_set_deterministic(1)
+    try:
+        y0 = torch.empty(n, ho, wo, cout, device=dev)
+        _lib.check(lib.hn_conv2d_fwd(P(x), P(wt), P(w3), P(b), P(y0), None, ctypes.byref(d), 0, 0.0, vb, s), "fwd")
+        dx0 = torch.empty_like(x)
+        _lib.check(lib.hn_conv2d_dgrad(P(gy), P(wtf), P(wt3), P(dx0), P(skip), cin, ctypes.byref(d), vb, s), "dgrad")
+    finally:
+        lib.hn_set_deterministic(0)
+    xb = torch.zeros(n * h * w_ * cin, device=dev, dtype=torch.int16)
+    gb = torch.zeros(n * ho * wo * cout, device=dev, dtype=torch.int16)
+    _lib.check(lib.hn_tensor_to_planes(P(x), cin, n * h * w_, cin, None, P(xb), xb.numel(), cin, s), "to bf16")
+    _lib.check(lib.hn_tensor_to_planes(P(gy), cout, n * ho * wo, cout, None, P(gb), gb.numel(), cout, s), "to bf16")
+    assert torch.equal(xb.view(torch.bfloat16).float().view(n, h, w_, cin), x.to(torch.bfloat16).float())
+    y1 = torch.full_like(y0, float("nan"))
+    _lib.check(lib.hn_conv2d_fwd_planes(P(xb), xb.numel(), None, P(w3), P(b), P(y1), None, None, ctypes.byref(d), 0, 0.0, tile, s), "fwd")
+    assert torch.equal(y0, y1)
+    dx1 = torch.full_like(x, float("nan"))
+    _lib.check(lib.hn_conv2d_dgrad_planes(P(gb), gb.numel(), None, P(wt3), P(dx1), P(skip), cin, ctypes.byref(d), tile, s), "dgrad")
+    assert torch.equal(dx0, dx1)
+    if cin % 64 == 0 and cout % 64 == 0 and tile < 2:
+        dw0, dw1 = torch.empty_like(wt), torch.full_like(wt, float("nan"))
+        _lib.check(lib.hn_conv2d_wgrad(P(x), P(gy), P(dw0), ctypes.byref(d), 1, vb, 0, s), "wgrad")
+        _lib.check(lib.hn_conv2d_wgrad_planes(P(xb), xb.numel(), None, P(gb), gb.numel(), None, P(dw1), ctypes.byref(d), 1, 2 * tile, 0, s),
+                   "wgrad_planes")
+        assert torch.equal(dw0, dw1)
