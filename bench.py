@@ -196,7 +196,7 @@ def pmc_traffic(math, workload, batch, height, width):
                 "hn_version": _lib.load().hn_version()}
         if any(meta.get(k) != v for k, v in want.items()):
             return None, None, None
-        conv = {k: v for k, v in data.items() if k.startswith("conv_igemm") or k.startswith("conv_wgrad")}
+        conv = {k: v for k, v in data.items() if k.startswith(("conv_igemm", "conv_wgrad", "stem_", "narrow_"))}
         calls = sum(v["calls"] for v in conv.values())
         mean = sum(v["calls"] * v["hbm_bytes_per_launch"] for v in conv.values()) / calls
         per = {k: round(v["hbm_bytes_per_launch"]) for k, v in conv.items()}

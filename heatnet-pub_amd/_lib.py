@@ -83,6 +83,10 @@ SIGNATURES = {
                                    c_i64, c_int, c_int, P, c_float, P, c_i64, P, P],
     "hn_bilinear_up2_planes": [P, c_int, P, P, c_i64, c_int, c_int, c_int, c_int, c_int, P],
     "hn_range_census": [P, P, c_i64, c_int, P, c_i64, c_int, P, P],
+    "hn_conv_stem_fwd": [P, P, P, P, DP, P],
+    "hn_conv_stem_wgrad": [P, P, P, DP, c_int, P],
+    "hn_conv_narrow_dgrad": [P, P, P, DP, P],
+    "hn_conv_narrow_wgrad": [P, P, P, DP, c_int, P],
     "hn_thermal_augment": [P, P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P, P],
     "hn_thermal_resize": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "hn_set_conv_math": [c_int],

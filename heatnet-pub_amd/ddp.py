@@ -170,6 +170,9 @@ class GradBuckets:
             ev.record(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
+                from . import ops
+                if ops.side_stream_used.get(self.device):  # weight gradients may still be running on the side stream
+                    self.comm_stream.wait_stream(ops._side_stream(self.device))
                 if self.average:
                     b["flat"].mul_(1.0 / self.world)
                 b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)

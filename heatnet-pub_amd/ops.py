@@ -590,6 +590,43 @@ def _side_stream(device):
     return s
 
 
+# ---- weight gradients beside the BatchNorm backward passes ---------------------------------------------------------------
+# In the backward chain  dz_k -> [BatchNorm_k reduce, apply] -> dy_k -> dgrad_k -> dz_(k-1) -> ...  the weight gradient of layer k
+# only needs dy_k and the saved input: it is off the critical path.  The BatchNorm passes are HBM-bound (5+ TB/s, matrix cores
+# idle), the weight gradient is bound by the matrix cores / LDS: launched on a second stream, wgrad_k runs WHILE the main stream
+# does the BatchNorm backward of layer k-1 -- complementary resources, unlike dgrad || wgrad (HEATNET_OVERLAP above: two matrix
+# kernels just contend).  The side stream is joined once, when the backward pass ends (an autograd engine callback), and before
+# any gradient bucket is handed to RCCL (ddp.GradBuckets._launch).  HEATNET_WGRAD_STREAM=0 keeps everything on one stream.
+WGRAD_STREAM = os.environ.get("HEATNET_WGRAD_STREAM", "1") != "0"
+_side_join_task = [None]
+side_stream_used = {}  # device -> True once a weight gradient ran on the side stream (ddp asks)
+
+
+def _wgrad_side_stream(device, main):
+    """The side stream for this backward pass's weight gradients, with the join queued at the end of the pass."""
+    side = _side_stream(device)
+    side_stream_used[device] = True
+    task = _graph_task()
+    if _side_join_task[0] != task:
+        _side_join_task[0] = task
+
+        def join():
+            main.wait_stream(side)
+            cur = torch.cuda.current_stream(device)
+            if cur != main:
+                cur.wait_stream(side)
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+    return side
+
+
+def join_side_stream(device=None):
+    """Make the current stream wait for weight gradients still running on the side stream (explicit form of the join the
+    autograd callback does; ddp calls it on its communication stream)."""
+    for dev, side in _side_streams.items():
+        if device is None or dev == device:
+            torch.cuda.current_stream(dev).wait_stream(side)
+
+
 # ---- gradient slots -------------------------------------------------------------------------------------------------
 # optim.ParamArena gives every parameter a fixed slot in a flat gradient buffer that is cleared once per step and marks
 # the parameter with `_hn_grad_slot`.  The backward that produces the FIRST gradient of such a parameter in a step
@@ -630,6 +667,26 @@ def grad_slot(param, accumulate_ok=True):
 
 def _leaf(t):
     return t if isinstance(t, torch.nn.Parameter) else None
+
+
+# Layers with a tiny channel count on one side -- the 7x7 stride-2 stems (1 / 3 / 4 input channels) and the 13-class head --
+# run on streaming fp32-MFMA kernels of their own (csrc/conv_small.hip); HEATNET_SMALL_KERNELS=0: the generic kernels (A/B).
+SMALL_KERNELS = os.environ.get("HEATNET_SMALL_KERNELS", "1") != "0"
+# The stem kernels gather their 7x7 windows straight from global memory (37 scattered 4-byte loads per 16 pixels) and measured
+# SLOWER than the generic kernels (forward 0.24 vs 0.14 ms, weight gradient 0.36 vs 0.34 ms, profiles/r03_small_kernels.txt);
+# they stay built and tested but are off unless HEATNET_SMALL_STEM=1.  The head kernels are on: weight gradient 0.35 -> 0.15 ms,
+# data gradient 0.21 -> 0.12 ms.
+SMALL_STEM = os.environ.get("HEATNET_SMALL_STEM", "0") == "1"
+
+
+def _stem_geometry(d):
+    return (d.KH == 7 and d.KW == 7 and d.stride == 2 and d.pad == 3 and d.dil == 1 and d.Cout == 64 and d.Cin in (1, 3, 4) and
+            d.ldx == d.Cin and d.ldy % 4 == 0)
+
+
+def _narrow_geometry(d):
+    return (d.KH == 1 and d.KW == 1 and d.stride == 1 and d.pad == 0 and d.dil == 1 and d.Cin == 64 and d.Cout <= 16 and
+            d.ldx % 4 == 0)
 
 
 _conv_prof = None  # bench.py: list receiving (kind, algorithmic flops, start event, end event) per conv launch
@@ -746,7 +803,13 @@ class _Conv2d(torch.autograd.Function):
         wx3, ctx.wt, ctx.wtx3 = _weight_operands(w_in, w, stride, pad, dil, lm, ctx.needs_input_grad[0], s)
         ctx.lm = lm
         ctx.x_scale = None
-        if lm == "f16x2" and _h2_covers(0, d) and x.data_ptr() % 16 == 0:
+        ctx.small = None
+        if SMALL_KERNELS and SMALL_STEM and _stem_geometry(d) and b is None and act == ACT_NONE and want_stats is not True:
+            # 7x7 / stride-2 stem with 1, 3 or 4 input channels: its own fp32-MFMA streaming kernel (csrc/conv_small.hip)
+            ctx.small = "stem"
+            with _ConvTimer("fwd", d, "stem_fwd_kernel<%d>" % cin):
+                check(lib.hn_conv_stem_fwd(_ptr(x), _ptr(w), _ptr(y), _ptr(stats), ctypes.byref(d), s), "hn_conv_stem_fwd")
+        elif lm == "f16x2" and _h2_covers(0, d) and x.data_ptr() % 16 == 0:
             xs = ctx.x_scale = tensor_scale(x, ldx, owner=x_in)
             if RANGE_CENSUS:
                 _census_operand(_leaf(w_in), 0, x, None, ldx, xs, n * h * wd, cin)
@@ -761,9 +824,12 @@ class _Conv2d(torch.autograd.Function):
             def launch(v, st):
                 check(lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), _ptr(st), ctypes.byref(d), act, slope,
                                         v, s), "hn_conv2d_fwd")
-        var = _pick(_kind("fwd", lm), d, _igemm_candidates(cout, "fwd", cin, lm), lambda v: launch(v, None))
-        with _ConvTimer("fwd", d, lambda: _plan_name(0, d, wx3 is not None, var)):
-            launch(var, stats)
+        if ctx.small is None:
+            if SMALL_KERNELS and _narrow_geometry(d):
+                ctx.small = "narrow"  # (13-class head: forward on the generic kernel -- already at its HBM time --, backward below)
+            var = _pick(_kind("fwd", lm), d, _igemm_candidates(cout, "fwd", cin, lm), lambda v: launch(v, None))
+            with _ConvTimer("fwd", d, lambda: _plan_name(0, d, wx3 is not None, var)):
+                launch(var, stats)
         ctx.geom = (stride, pad, dil, act, slope)
         ctx.has_bias = b is not None
         ctx.w_leaf, ctx.b_leaf = _leaf(w_in), _leaf(b)
@@ -813,7 +879,13 @@ class _Conv2d(torch.autograd.Function):
                     ctx.x_scale = tensor_scale(x, ldx)
             fork = torch.cuda.Event()
             fork.record()  # dy (and the activation backward that produced it) and the scales are complete up to here
-        if ctx.needs_input_grad[0]:
+        small = ctx.small if not DETERMINISTIC else None  # (the streaming kernels reduce with float atomics)
+        if ctx.needs_input_grad[0] and small == "narrow" and dskip is None:
+            dx = new_nhwc(n, cin, h, wd, x.device)
+            dn = _desc(n, h, wd, cin, cin, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
+            with _ConvTimer("dgrad", dn, "narrow_dgrad_kernel"):
+                check(lib.hn_conv_narrow_dgrad(_ptr(dy), _ptr(w), _ptr(dx), ctypes.byref(dn), s), "hn_conv_narrow_dgrad")
+        elif ctx.needs_input_grad[0]:
             nw = cin * kh * kw * cout
             wt, wtx3 = ctx.wt, ctx.wtx3  # prepared by the forward (plane arithmetics), else made here
             dm = lm if lm != "f16x2" else _layer_math("dgrad", cin, cout, kh, kw, ctx.w_leaf)
@@ -856,6 +928,12 @@ class _Conv2d(torch.autograd.Function):
                 dw_out = dw if slot[1] else None  # a later use adds in place and reports no gradient of its own
             else:
                 dw_out = dw = torch.empty((cout, kh, kw, cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
+            if (small == "stem" and dy.data_ptr() % 16 == 0 and lddy % 4 == 0) or (small == "narrow" and x.data_ptr() % 16 == 0):
+                fn = lib.hn_conv_stem_wgrad if small == "stem" else lib.hn_conv_narrow_wgrad
+                name = ("stem_wgrad_kernel<%d>" % cin) if small == "stem" else "narrow_wgrad_kernel"
+                with _ConvTimer("wgrad", d, name):
+                    check(fn(_ptr(x), _ptr(dy), _ptr(dw), ctypes.byref(d), flags, s), "hn_conv_small_wgrad")
+                return _Conv2d._finish_backward(ctx, lib, dx, dw_out, dy, lddy, npix, cout, x, s)
             # f16x2 layer: the weight gradient too where its kernel covers the geometry (whole 64-channel blocks both ways),
             # with the input's scale from the forward and dY's from the data gradient above; elsewhere as under bf16x3
             wm = lm if not h2_layer else _layer_math("wgrad", cin, cout, kh, kw, ctx.w_leaf)
@@ -905,6 +983,12 @@ class _Conv2d(torch.autograd.Function):
             else:
                 with _ConvTimer("wgrad", d, lambda: _wgrad_plan_name(d, 1 if h2_w else 0, var)):
                     wgrad(dw, split, var, flags)
+        return _Conv2d._finish_backward(ctx, lib, dx, dw_out, dy, lddy, npix, cout, x, s)
+
+    @staticmethod
+    def _finish_backward(ctx, lib, dx, dw_out, dy, lddy, npix, cout, x, s):
+        """Bias gradient and the return tuple of backward()."""
+        db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             slot = grad_slot(ctx.b_leaf, accumulate_ok=False) if ctx.b_leaf is not None else None
             db = slot[0] if slot is not None else None
@@ -1366,6 +1450,15 @@ class _ConvBnAct(torch.autograd.Function):
                                                  _ptr(dy_slot), _ptr(dres), cout, npix, cout, act, _ptr(prelu_w), leaky,
                                                  _ptr(ctx.drop_mask), ho * wo, _ptr(rbits), s), "hn_bn_act_bwd_apply_planes")
         d = _desc(n, h, wd, cin, cin, ho, wo, cout, cout, kh, kw, stride, pad, dil)
+        side = None
+        # Only when the gradient goes into the parameter's arena slot: then nothing on the main stream touches it before the
+        # end-of-backward join (a second use of the layer adds in place on the same side stream).  A free-standing dW is
+        # handed to autograd, which may add to it on the main stream at once (a layer applied to the day and the night batch).
+        if WGRAD_STREAM and need_w and _conv_prof is None and not DETERMINISTIC and getattr(lw, "_hn_grad_slot", None) is not None:
+            main = torch.cuda.current_stream(dev)
+            ready = torch.cuda.Event()
+            ready.record(main)  # dy (and, far earlier, the cleared gradient arena) is complete up to here; dgrad comes after
+            side = _wgrad_side_stream(dev, main)
         if RANGE_CENSUS and (need_x or need_w) and not bf16:
             _census_operand(lw, 1, None, dyp, cout, dy_slot, npix, cout)
         tag = ".bf16p" if bf16 else ".planes"
@@ -1395,9 +1488,9 @@ class _ConvBnAct(torch.autograd.Function):
                 dw_out = dw = torch.empty((cout, kh, kw, cin), device=dev, dtype=torch.float32).permute(0, 3, 1, 2)
             xplane = n * h * wd * cin
 
-            def wgrad(dst, sp_, v, fl):
+            def wgrad(dst, sp_, v, fl, st=s):
                 check(lib.hn_conv2d_wgrad_planes(_ptr(xp), xplane, _ptr(ctx.x_slot), _ptr(dyp), npix * cout, _ptr(dy_slot), _ptr(dst),
-                                                 ctypes.byref(d), sp_, v, fl, s), "hn_conv2d_wgrad_planes")
+                                                 ctypes.byref(d), sp_, v, fl, st), "hn_conv2d_wgrad_planes")
             if DETERMINISTIC:
                 splits = max(1, min(32, npix // 4096))
                 wsp = _det_workspace(dev, splits * dw.numel())
@@ -1408,8 +1501,17 @@ class _ConvBnAct(torch.autograd.Function):
             else:
                 split, var = _pick("wgrad" + tag, d, _wgrad_plane_candidates(cout, cin, bf16),
                                    lambda sv: wgrad(_tune_scratch(dw) if flags else dw, sv[0], sv[1], 0))
-                with _ConvTimer("wgrad", d, lambda: _wgrad_plan_name(d, 2, var + 64 * mcode)):
-                    wgrad(dw, split, var, flags)
+                if side is not None and slot is not None and dw is slot[0]:
+                    # beside the main stream's next BatchNorm backward passes (see WGRAD_STREAM); the operands stay reserved
+                    # for the side stream until it is done with them
+                    side.wait_event(ready)
+                    wgrad(dw, split, var, flags, ctypes.c_void_p(side.cuda_stream))
+                    for t in (xp, dyp, dw, ctx.x_slot, dy_slot):
+                        if t is not None:
+                            t.record_stream(side)
+                else:
+                    with _ConvTimer("wgrad", d, lambda: _wgrad_plan_name(d, 2, var + 64 * mcode)):
+                        wgrad(dw, split, var, flags)
         if lbias is not None and ctx.needs_input_grad[2]:
             # the output is normalised with batch statistics: the bias cancels, its gradient is exactly zero
             bslot = grad_slot(lbias, accumulate_ok=False)

@@ -309,6 +309,16 @@ int hn_conv2d_wgrad_plan(const HnConvDesc* d, int mode, int variant, char* name,
 int hn_conv2d_wgrad_det(const float* x, const float* dy, float* dw, const HnConvDesc* d, int split_k, int variant, int flags,
                         float* workspace, void* stream);
 
+/* Layers with a tiny channel count on one side (csrc/conv_small.hip): HBM-bound streams on v_mfma_f32_16x16x4_f32 (exact
+ * fp32), every global access a full 256-byte pixel row.  Stems: KH = KW = 7, stride 2, pad 3, Cin in {1, 3, 4} (ldx == Cin),
+ * Cout = 64, no bias (cm/models/extractors.py:108-126); `stats` as for hn_conv2d_fwd.  Head: 1 x 1, Cin = 64, Cout <= 16
+ * (cm/models/pspnet.py:56-58); `w` is the forward weight [Cout][64] (no flip needed), dx is overwritten.  The weight
+ * gradients accumulate with float atomics (flags as for hn_conv2d_wgrad); HN_ESHAPE for any other geometry. */
+int hn_conv_stem_fwd(const float* x, const float* w, float* y, double* stats, const HnConvDesc* d, void* stream);
+int hn_conv_stem_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int flags, void* stream);
+int hn_conv_narrow_dgrad(const float* dy, const float* w, float* dx, const HnConvDesc* d, void* stream);
+int hn_conv_narrow_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int flags, void* stream);
+
 /* out[c] = sum over npix pixels of x[p*ld + c]  (bias gradient).  `out` is overwritten. */
 int hn_channel_sum(const float* x, int ld, int64_t npix, int C, float* out, void* stream);
 
