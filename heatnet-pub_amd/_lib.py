@@ -87,6 +87,9 @@ SIGNATURES = {
     "hn_conv_stem_wgrad": [P, P, P, DP, c_int, P],
     "hn_conv_narrow_dgrad": [P, P, P, DP, P],
     "hn_conv_narrow_wgrad": [P, P, P, DP, c_int, P],
+    "hn_grouped_conv3x3_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "hn_grouped_conv3x3_dgrad": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "hn_grouped_conv3x3_wgrad": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "hn_thermal_augment": [P, P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, P, P],
     "hn_thermal_resize": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     "hn_set_conv_math": [c_int],

@@ -37,19 +37,26 @@ class conv_segnet(nn.Module):
     def __init__(self, pretrained=True, disc_arch="resnet", num_critics=6, feedback_seg=False, no_conf=False,
                  modalities="ir_rgb", input_adapter=False, cert_branch=False, arch="custom", late_fusion=False):
         super().__init__()
-        if arch != "pspnet":
-            raise NotImplementedError("arch=%r: only the PSPNet path is built for MI355X" % arch)
+        if arch not in ("pspnet", "custom"):
+            raise NotImplementedError("arch=%r: the reference itself only knows 'pspnet' and 'custom'" % arch)
         if input_adapter:
             # cm/models/conf_segnet.py:108-112 hands the [rgb, ir] LIST to the UNet adapter: with arch='pspnet' the
             # reference raises TypeError in its first conv (verified by running it); there is nothing to be compatible with
             raise NotImplementedError("input_adapter: the reference's adapter takes a single tensor (arch='custom'); with the "
                                       "PSPNet path's [rgb, ir] inputs its own forward raises TypeError")
         if cert_branch:
-            raise NotImplementedError("cert_branch belongs to the ResNeXt 'custom' arch (PSPNet returns cert = None)")
+            raise NotImplementedError("cert_branch (the certainty head of the ResNeXt 'custom' arch) is not built; PSPNet "
+                                      "returns cert = None")
         num_input_channels = (3 if "rgb" in modalities else 0) + (1 if "ir" in modalities else 0)
-        self.trgb_segnet = build_net.build_network(None, "resnet50", in_channels=num_input_channels,
-                                                   late_fusion=late_fusion)
-        critic_num = [13, 2048, 1024, 512 * 2, 256 * 2, 64 * 2] if late_fusion else [13, 2048, 1024, 512, 256, 64]
+        if arch == "custom":  # :38-43 -- ResNeXt-50 (64 groups) + ASPP, the reference's default architecture
+            from .trgb_segnet import ResNeXt
+            self.trgb_segnet = ResNeXt(structure=[3, 4, 6, 3], input_channels=num_input_channels, cert_branch=cert_branch,
+                                       late_fusion=late_fusion)
+            critic_num = [13, 768, 1024, 512, 256 * 2, 64 * 2] if late_fusion else [13, 512, 1024, 512, 256, 64]
+        else:
+            self.trgb_segnet = build_net.build_network(None, "resnet50", in_channels=num_input_channels,
+                                                       late_fusion=late_fusion)
+            critic_num = [13, 2048, 1024, 512 * 2, 256 * 2, 64 * 2] if late_fusion else [13, 2048, 1024, 512, 256, 64]
         self.trgb_segnet.apply(weights_init_normal)
         self.feedback_seg = feedback_seg
         self.input_adapter = False

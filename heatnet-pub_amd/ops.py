@@ -583,11 +583,47 @@ OVERLAP = os.environ.get("HEATNET_OVERLAP", "0") == "1"
 _side_streams = {}
 
 
+SIDE_PRIORITY = int(os.environ.get("HEATNET_SIDE_PRIORITY", "0"))  # experiment knob: priority of the side stream
+
+
 def _side_stream(device):
     s = _side_streams.get(device)
     if s is None:
-        s = _side_streams[device] = torch.cuda.Stream(device=device)
+        s = _side_streams[device] = torch.cuda.Stream(device=device, priority=SIDE_PRIORITY)
     return s
+
+
+_main_streams = {}
+
+
+class main_stream:
+    """`with ops.main_stream(device): ...` -- experiment knob HEATNET_MAIN_HIGH=1: run the enclosed work on a HIGH-priority
+    stream, so that the critical path (BatchNorm passes, data gradients) is dispatched ahead of the weight gradients that
+    share the GPU from the side stream.  A no-op without the knob."""
+    ON = os.environ.get("HEATNET_MAIN_HIGH", "0") == "1"
+
+    def __init__(self, device):
+        self.device = device
+        self.ctx = None
+
+    def __enter__(self):
+        if not self.ON or self.device.type != "cuda":
+            return self
+        hp = _main_streams.get(self.device)
+        if hp is None:
+            hp = _main_streams[self.device] = torch.cuda.Stream(device=self.device, priority=-1)
+        self.outer = torch.cuda.current_stream(self.device)
+        hp.wait_stream(self.outer)
+        self.hp = hp
+        self.ctx = torch.cuda.stream(hp)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.outer.wait_stream(self.hp)
+        return False
 
 
 # ---- weight gradients beside the BatchNorm backward passes ---------------------------------------------------------------
@@ -1923,6 +1959,143 @@ def concat(xs):
             m = torch.maximum(m, h[1])
         out._hn_scale = (out._version, m)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# operators of the ResNeXt / ASPP "custom" architecture (cm/models/trgb_segnet.py)
+# ------------------------------------------------------------------------------------------------------
+
+class _GroupedConv3x3(torch.autograd.Function):
+    """nn.Conv2d(C, C, 3, padding=dil, dilation=dil, groups=G, bias=False) with 2..16 channels per group
+    (cm/models/trgb_segnet.py:106-107), direct fp32 kernels (csrc/grouped_conv.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, groups, dil):
+        lib = _lib.load()
+        x, ldx = as_nhwc(x)
+        w_in, w = w, weight_ohwi(w)
+        n, c, h, wd = x.shape
+        y = new_nhwc(n, c, h, wd, x.device)
+        check(lib.hn_grouped_conv3x3_fwd(_ptr(x), _ptr(w), _ptr(y), n, h, wd, c, groups, ldx, c, dil, _stream()),
+              "hn_grouped_conv3x3_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (groups, dil)
+        ctx.w_leaf = _leaf(w_in)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        groups, dil = ctx.cfg
+        x, ldx = as_nhwc(x)
+        dy, lddy = as_nhwc(dy)
+        n, c, h, wd = x.shape
+        s = _stream()
+        dx = dw_out = None
+        if ctx.needs_input_grad[0]:
+            dx = new_nhwc(n, c, h, wd, x.device)
+            check(lib.hn_grouped_conv3x3_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, h, wd, c, groups, lddy, c, dil, s),
+                  "hn_grouped_conv3x3_dgrad")
+        if ctx.needs_input_grad[1]:
+            slot = grad_slot(ctx.w_leaf) if ctx.w_leaf is not None else None
+            flags = 0
+            if slot is not None and weight_ohwi(slot[0]) is slot[0]:
+                dw = slot[0]
+                flags = 1 if slot[1] else 2
+                dw_out = dw if slot[1] else None
+            else:
+                dw_out = dw = torch.empty((c, 3, 3, c // groups), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
+            check(lib.hn_grouped_conv3x3_wgrad(_ptr(x), _ptr(dy), _ptr(dw), n, h, wd, c, groups, ldx, lddy, dil, flags, s),
+                  "hn_grouped_conv3x3_wgrad")
+        return dx, dw_out, None, None
+
+
+def grouped_conv3x3(x, w, groups, dil=1):
+    return _GroupedConv3x3.apply(x, w, int(groups), int(dil))
+
+
+class _ConvTranspose2d(torch.autograd.Function):
+    """nn.ConvTranspose2d(Cin, Cout, K, stride, pad, bias=False) (cm/models/trgb_segnet.py:208,338: the decoder's learned
+    upsamplings, 13 channels): y = the DATA GRADIENT of the convolution whose OIHW weight is the transposed convolution's
+    (Cin, Cout, K, K) tensor, so the forward runs hn_conv2d_dgrad, the input gradient hn_conv2d_fwd and the weight gradient
+    hn_conv2d_wgrad with the roles of the two tensors swapped -- all on the generic fp32 kernels (13 channels)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        lib = _lib.load()
+        x, ldx = as_nhwc(x)
+        w_in, w = w, weight_ohwi(w)
+        n, cin, h, wd = x.shape
+        cin_w, cout, kh, kw = w.shape  # as a convolution: Cout_conv = cin, Cin_conv = cout
+        ho, wo = (h - 1) * stride - 2 * pad + kh, (wd - 1) * stride - 2 * pad + kw
+        y = new_nhwc(n, cout, ho, wo, x.device)
+        s = _stream()
+        wt = torch.empty(w.numel(), device=x.device, dtype=torch.float32)
+        check(lib.hn_weight_flip_transpose(_ptr(w), None, _ptr(wt), None, cin, kh, kw, cout, stride, pad, 1, s),
+              "hn_weight_flip_transpose")
+        d = _desc(n, ho, wo, cout, cout, h, wd, cin, ldx, kh, kw, stride, pad, 1)  # the convolution y -> x
+        check(lib.hn_conv2d_dgrad(_ptr(x), _ptr(wt), None, _ptr(y), None, 0, ctypes.byref(d), _variant(0, 0, 0, 1), s),
+              "hn_conv2d_dgrad")
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, ho, wo)
+        ctx.w_leaf = _leaf(w_in)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        stride, pad, ho, wo = ctx.cfg
+        x, ldx = as_nhwc(x)
+        gy, ldg = as_nhwc(gy)
+        n, cin, h, wd = x.shape
+        _, cout, kh, kw = w.shape
+        s = _stream()
+        f32 = _variant(0, 0, 0, 1)
+        dx = dw_out = None
+        if ctx.needs_input_grad[0]:  # dx = conv(gy, w) with the forward stride
+            dx = new_nhwc(n, cin, h, wd, x.device)
+            d = _desc(n, ho, wo, cout, ldg, h, wd, cin, cin, kh, kw, stride, pad, 1)
+            check(lib.hn_conv2d_fwd(_ptr(gy), _ptr(w), None, None, _ptr(dx), None, ctypes.byref(d), ACT_NONE, 0.0, f32, s),
+                  "hn_conv2d_fwd")
+        if ctx.needs_input_grad[1]:  # dw[cin][k][k][cout] = wgrad(input = gy, output gradient = x)
+            slot = grad_slot(ctx.w_leaf) if ctx.w_leaf is not None else None
+            flags = 0
+            if slot is not None and weight_ohwi(slot[0]) is slot[0]:
+                dw = slot[0]
+                flags = 1 if slot[1] else 2
+                dw_out = dw if slot[1] else None
+            else:
+                dw_out = dw = torch.empty((cin, kh, kw, cout), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
+            d = _desc(n, ho, wo, cout, ldg, h, wd, cin, ldx, kh, kw, stride, pad, 1)
+            check(lib.hn_conv2d_wgrad(_ptr(gy), _ptr(x), _ptr(dw), ctypes.byref(d), 0, f32, flags, s), "hn_conv2d_wgrad")
+        return dx, dw_out, None, None
+
+
+def conv_transpose2d(x, w, stride, pad):
+    return _ConvTranspose2d.apply(x, w, int(stride), int(pad))
+
+
+class _Add(torch.autograd.Function):
+    """a + b (the residual sum of the pre-activation blocks, cm/models/trgb_segnet.py:127): hn_add; the gradient passes to both."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, lda = as_nhwc(a)
+        b, ldb = as_nhwc(b)
+        n, c, h, w = a.shape
+        y = new_nhwc(n, c, h, w, a.device)
+        check(_lib.load().hn_add(_ptr(a), lda, _ptr(b), ldb, _ptr(y), c, n * h * w, c, _stream()), "hn_add")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(as_f32(a), as_f32(b))
 
 
 # ------------------------------------------------------------------------------------------------------

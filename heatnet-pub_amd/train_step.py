@@ -138,6 +138,11 @@ def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_w
 
 def segmentation_step(model, optimizer, rgb, ir, labels, ignore_index=-100, grad_sync=None):
     """BASELINE config 2: dual-stream PSPNet forward/backward + CE + optimizer step (no critics)."""
+    with ops.main_stream(rgb.device):
+        return _segmentation_step(model, optimizer, rgb, ir, labels, ignore_index, grad_sync)
+
+
+def _segmentation_step(model, optimizer, rgb, ir, labels, ignore_index, grad_sync):
     optimizer.zero_grad(set_to_none=grad_sync is None)
     if grad_sync is not None:
         grad_sync.begin_step()

@@ -319,6 +319,16 @@ int hn_conv_stem_wgrad(const float* x, const float* dy, float* dw, const HnConvD
 int hn_conv_narrow_dgrad(const float* dy, const float* w, float* dx, const HnConvDesc* d, void* stream);
 int hn_conv_narrow_wgrad(const float* x, const float* dy, float* dw, const HnConvDesc* d, int flags, void* stream);
 
+/* Grouped 3x3 convolution, stride 1, pad = dil, C / groups in {2, 4, 8, 16} channels per group, C % 16 == 0 (the ResNeXt
+ * bottleneck of the reference's "custom" architecture, cm/models/trgb_segnet.py:106-107): direct fp32 kernels
+ * (csrc/grouped_conv.hip).  w is [C][3][3][C / groups]; the data gradient takes the FORWARD weights. */
+int hn_grouped_conv3x3_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int groups, int ldx, int ldy,
+                           int dil, void* stream);
+int hn_grouped_conv3x3_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int groups, int lddy, int lddx,
+                             int dil, void* stream);
+int hn_grouped_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int groups, int ldx, int lddy,
+                             int dil, int flags, void* stream);
+
 /* out[c] = sum over npix pixels of x[p*ld + c]  (bias gradient).  `out` is overwritten. */
 int hn_channel_sum(const float* x, int ld, int64_t npix, int C, float* out, void* stream);
 

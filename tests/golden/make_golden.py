@@ -304,7 +304,50 @@ def part_miou():
     _save("miou_cases", **out)
 
 
-PARTS = {"segnet": part_segnet, "confstep": part_confstep, "confgrads": part_confgrads, "feedback": part_feedback,
+RESNEXT_GRAD_KEYS = ["mod1.conv1_2.weight", "mod1_2.conv3.weight", "mod2_1.block1.convs.conv2.weight", "mod2_1.block1.proj_conv.weight",
+                     "mod2_2.block3.convs.conv1.weight", "mod3_1.block1.convs.conv1.weight", "mod3_1.block2.convs.conv2.weight",
+                     "mod4_1.block3.convs.conv2.weight", "mod4_1.block6.convs.conv3.weight", "mod5_1.block1.proj_conv.weight",
+                     "mod5_1.block2.convs.conv2.weight", "mod5_1.block3.bn1.bn.weight", "bn_out_1.bn.bias",
+                     "aspp.conv1.conv1.weight", "aspp.conv3.conv1.weight", "aspp.conv4.bn1.bn.weight", "aspp.conv5.conv1.weight",
+                     "aspp.fuse_conv.conv1.weight", "aspp.final_conv.conv1.weight", "up_seg_2.weight", "fuse_seg.conv1.weight",
+                     "fuse_seg.bn2.bn.weight", "fuse_seg.conv3.weight", "fuse_seg.up.weight"]
+
+
+def part_resnext():
+    """The ResNeXt-50 (groups = 64) + ASPP "custom" architecture (conf-max models/trgb_segnet.py:242-402), late fusion, as
+    conf_segnet builds it (models/conf_segnet.py:38-43): train-mode forward, cross-entropy, backward."""
+    sys.path.insert(0, CM)
+    from models import trgb_segnet
+    for tag, late in (("late", True), ("early", False)):
+        net = trgb_segnet.ResNeXt(structure=[3, 4, 6, 3], input_channels=4, cert_branch=False, late_fusion=late)
+        net.load_state_dict(seeded_state(net, seed=21))
+        rgb, ir, lab = seeded_inputs(2, 128, 192, seed=23)
+        net.train()
+        seg, feats, cert = net(rgb, ir)
+        assert cert is None
+        loss = torch.nn.functional.cross_entropy(seg, lab)
+        loss.backward()
+        d, _ = tensor_digest(seg, 1)
+        out = {"logits_sub": seg.detach()[..., ::2, ::2].numpy().copy(), "logits_digest": d, "loss": np.array(float(loss.detach())),
+               "keys": np.array(list(net.state_dict().keys())),
+               "shapes": np.array([list(v.shape) + [0] * (4 - v.dim()) for v in net.state_dict().values()])}
+        _digests("feat", feats[1:], 31, out)
+        params = dict(net.named_parameters())
+        out["grad_keys"] = np.array([k for k, p_ in params.items() if p_.grad is not None])
+        out["grad_norms"] = np.array([float(p_.grad.double().norm()) for p_ in params.values() if p_.grad is not None])
+        for k in RESNEXT_GRAD_KEYS:
+            if late or "_2." not in k.split(".")[0] + ".":
+                if k in params and params[k].grad is not None:
+                    g = params[k].grad
+                    out["grad|" + k] = g.reshape(-1)[:: max(1, g.numel() // 4096)].numpy().copy()
+        sd = net.state_dict()
+        for k in ("mod1.bn1_2.bn.running_mean", "mod5_1.block3.convs.bn3.bn.running_var", "aspp.conv5.bn1.bn.running_var",
+                  "fuse_seg.bn1.bn.running_mean"):
+            out["after_" + k] = sd[k].numpy()
+        _save("resnext_%s_2x128x192" % tag, **out)
+
+
+PARTS = {"resnext": part_resnext, "segnet": part_segnet, "confstep": part_confstep, "confgrads": part_confgrads, "feedback": part_feedback,
          "rgb18": part_rgb18,
          "miou": part_miou}
 

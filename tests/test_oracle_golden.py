@@ -193,3 +193,37 @@ def test_gradient_tensors_match_reference_elementwise(golden_dir, adv, state):
             continue
         rel = float((got - ref).norm() / ref.norm())
         assert rel < 5e-3, (key, rel)
+
+
+@pytest.mark.parametrize("tag,late", [("late", True), ("early", False)])
+def test_resnext_oracle_matches_reference_fixture(golden_dir, tag, late):
+    """oracle/resnext_ref.py (the ResNeXt-50 + ASPP "custom" architecture, cm/models/trgb_segnet.py:242-402) against the
+    outputs of the reference's own module (make_golden.py --part resnext): state_dict keys and shapes, logits, loss, the five
+    feature maps, the gradient norm of every parameter, BatchNorm running statistics."""
+    from oracle import resnext_ref as R
+    g = np.load(os.path.join(golden_dir, "resnext_%s_2x128x192.npz" % tag))
+    net = R.RefResNeXt(late_fusion=late)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(g["keys"])
+    assert all(tuple(v.shape) == tuple(int(x) for x in sh[:v.dim()]) for v, sh in zip(sd.values(), g["shapes"]))
+    net.load_state_dict(seeded_state(net, seed=21))
+    rgb, ir, lab = seeded_inputs(2, 128, 192, seed=23)
+    net.train()
+    seg, feats, cert = net(rgb, ir)
+    assert cert is None
+    loss = torch.nn.functional.cross_entropy(seg, lab)
+    loss.backward()
+    assert float((seg.detach()[..., ::2, ::2] - torch.from_numpy(g["logits_sub"])).abs().max()) < 3e-4
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
+    for i, t in enumerate(feats[1:]):
+        assert tuple(t.shape) == tuple(g["feat%d_shape" % i])
+        _, s = tensor_digest(t, 31)
+        np.testing.assert_allclose(s, g["feat%d_sample" % i], rtol=0, atol=3e-4)
+    norms = {k: float(p.grad.double().norm()) for k, p in net.named_parameters() if p.grad is not None}
+    assert list(norms.keys()) == list(g["grad_keys"])
+    floor = 1e-6 * float(g["grad_norms"].max())
+    for k, ref in zip(g["grad_keys"], g["grad_norms"]):
+        assert abs(norms[k] - ref) <= 5e-3 * max(ref, floor), k
+    for k in ("mod1.bn1_2.bn.running_mean", "mod5_1.block3.convs.bn3.bn.running_var", "aspp.conv5.bn1.bn.running_var",
+              "fuse_seg.bn1.bn.running_mean"):
+        np.testing.assert_allclose(net.state_dict()[k].numpy(), g["after_" + k], rtol=1e-4, atol=1e-6)
