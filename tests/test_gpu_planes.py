@@ -326,8 +326,10 @@ def test_fused_conv_bn_act_matches_unfused(dev, case, math):
             tol = 1e-3  # one scalar: a sum of 10^5 cancelling terms
         if stored16 and key == "z":
             tol = 2.0 ** -8
-        elif stored16 and res_kind == "planes" and key not in ("rm", "rv"):
-            tol = 2e-3  # the ReLU mask behind the residual add sees the bf16-rounded residual
+        elif math == "bf16" and key not in ("z", "rm", "rv"):
+            # gradients under bf16: the unfused path runs a few geometries (strided data gradients) on the fp32 kernels, i.e.
+            # WITHOUT rounding dY to bf16, and the ReLU mask behind a plane residual sees the bf16-rounded residual
+            tol = 4e-3
         err = float((a[key] - ref).abs().max())
         assert err <= tol * max(float(ref.abs().max()), 1e-30), (key, err, float(ref.abs().max()))
 
