@@ -330,6 +330,11 @@ def test_fused_conv_bn_act_matches_unfused(dev, case, math):
             # gradients under bf16: the unfused path runs a few geometries (strided data gradients) on the fp32 kernels, i.e.
             # WITHOUT rounding dY to bf16, and the ReLU mask behind a plane residual sees the bf16-rounded residual
             tol = 4e-3
+        if math == "bf16" and res_kind == "planes" and key not in ("z", "rm", "rv"):
+            # the ReLU behind the residual add sees the bf16-rounded residual: a few masks flip, and with them whole
+            # gradient elements -- compared in the norm
+            assert float((a[key] - ref).norm() / ref.norm()) < 3e-2, key
+            continue
         err = float((a[key] - ref).abs().max())
         assert err <= tol * max(float(ref.abs().max()), 1e-30), (key, err, float(ref.abs().max()))
 

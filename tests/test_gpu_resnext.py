@@ -110,6 +110,9 @@ def test_resnext_matches_reference_fixture(dev, golden_dir, tag, late):
             gr = params[name].grad.detach().cpu().reshape(-1)
             gr = gr[:: max(1, gr.numel() // 4096)].double().numpy()
             ref = g[k].astype(np.float64)
+            if np.linalg.norm(ref) == 0.0:  # (e.g. the corner taps of a 3x3 with dilation 24 on a 16 x 24 map: never in range)
+                assert np.linalg.norm(gr) == 0.0, name
+                continue
             cos = float((gr * ref).sum() / (np.linalg.norm(gr) * np.linalg.norm(ref) + 1e-300))
             assert cos > 0.999, (name, cos)
     sd = net.state_dict()
