@@ -116,85 +116,92 @@ __device__ __forceinline__ void stem_k(int k, int W, int& off, int& kh, int& kw)
     off = (kh * W + kw) * CIN + c;
 }
 
+// Output tile of a block: TH x TW pixels; the (2 TH + 5) x (2 TW + 5) x CIN input window is staged in LDS once (coalesced row
+// segments, zero outside the image) and all 49 taps gather from there -- the first version gathered from global memory (37
+// scattered 4-byte loads per 16 pixels) and was slower than the generic kernels.
+constexpr int STEM_TH = 4, STEM_TW = 64, STEM_PH = 2 * STEM_TH + 5, STEM_PW = 2 * STEM_TW + 5;
+
+template <int CIN>
+__device__ __forceinline__ void stem_load_patch(const SmallArgs& p, float* patch, int img, int ho0, int wo0) {
+    const int hb = 2 * ho0 - 3, wb = 2 * wo0 - 3;
+    for (int e = threadIdx.x; e < STEM_PH * STEM_PW * CIN; e += 256) {
+        const int row = e / (STEM_PW * CIN), rem = e - row * (STEM_PW * CIN);
+        const int col = rem / CIN;
+        const int h = hb + row, w = wb + col;
+        float v = 0.f;
+        if ((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)
+            v = p.x[((long long)(img * p.H + h) * p.W + wb) * CIN + rem];  // (row segment: contiguous in rem)
+        patch[e] = v;
+    }
+}
+
 template <int CIN>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const SmallArgs p) {
     using S = Stem<CIN>;
-    __shared__ float wl[S::KS * 4][64];  // w transposed: [k][co], zero rows past K
-    __shared__ int ktab[S::KS * 4];      // k -> element offset in the window (24 bits) | kh << 24 | kw << 28; past K: -1
+    __shared__ float wl[S::KS * 4][64];                 // w transposed: [k][co], zero rows past K
+    __shared__ float patch[STEM_PH * STEM_PW * CIN];
+    __shared__ int ktab[S::KS * 4];                     // k -> offset inside the patch of tap k for output pixel (0, 0); past K: 0
     for (int i = threadIdx.x; i < S::KS * 4 * 64; i += 256) {
         const int k = i >> 6, co = i & 63;
         wl[k][co] = k < S::K ? p.w[co * S::K + k] : 0.f;
     }
     for (int k = threadIdx.x; k < S::KS * 4; k += 256) {
         int off, kh, kw;
-        stem_k<CIN>(k, p.W, off, kh, kw);
-        ktab[k] = k < S::K ? (off | (kh << 24) | (kw << 28)) : -1;
+        stem_k<CIN>(k, STEM_PW, off, kh, kw);
+        ktab[k] = k < S::K ? off : 0;  // (past K the weight row is zero: any in-range patch element will do)
     }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, n = lane & 15, kk = lane >> 4;
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
-    const long long groups = (p.M + 15) / 16;
-    const int hw = p.Ho * p.Wo;
-    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};  // channels 4 n + j (lanes < 16 after the reduction)
-    for (long long g = wave; g < groups; g += nwaves) {
-        const long long pa = g * 16 + n;
-        const bool pok = pa < p.M;
-        const int img = pok ? (int)(pa / hw) : 0, rem = pok ? (int)(pa - (long long)img * hw) : 0;
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        const int hb = 2 * ho - 3, wb = 2 * wo - 3;
-        const long long base = ((long long)(img * p.H + hb) * p.W + wb) * CIN;
-        f32x4 d[4];
+    const int lane = threadIdx.x & 63, n = lane & 15, kk = lane >> 4, wv = threadIdx.x >> 6;
+    const int tiles_w = (p.Wo + STEM_TW - 1) / STEM_TW, tiles_h = (p.Ho + STEM_TH - 1) / STEM_TH;
+    const int ntiles = p.N * tiles_h * tiles_w;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h, img = tile / (tiles_w * tiles_h);
+        const int ho0 = th * STEM_TH, wo0 = tw * STEM_TW;
+        __syncthreads();  // (previous tile's readers are done with the patch; first pass: the tables are written)
+        stem_load_patch<CIN>(p, patch, img, ho0, wo0);
+        __syncthreads();
+        // wave wv: output row ho0 + wv, four groups of 16 consecutive columns
+        const int ho = ho0 + wv;
+        for (int grp = 0; grp < STEM_TW / 16; ++grp) {
+            const int wo_a = wo0 + 16 * grp + n;                       // this lane's A row (pixel)
+            const int pbase = (2 * wv * STEM_PW + 2 * (16 * grp + n)) * CIN;
+            f32x4 d[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) d[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // K steps in chunks of CH: the chunk's CH gathers are issued together (CH loads in flight per wave), then its MFMAs run
-        constexpr int CH = 8;
-#pragma unroll 1
-        for (int s0 = 0; s0 < S::KS; s0 += CH) {
-            float a[CH];
+            for (int j = 0; j < 4; ++j) d[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int s = 0; s < S::KS; ++s) {
+                const int k = 4 * s + kk;
+                const float a = patch[pbase + ktab[k]];
+                const f32x4 b = *reinterpret_cast<const f32x4*>(&wl[k][4 * n]);
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int k = 4 * (s0 + u) + kk;  // (ktab / wl have KS * 4 rows; chunks past KS are guarded below)
-                // volatile LDS reads: the tables are loop-invariant across pixel groups and hipcc would otherwise keep all of
-                // them -- 150+ registers -- live, leaving one wave per SIMD to hide the gather latency
-                const int e = s0 + u < S::KS ? *reinterpret_cast<volatile const int*>(&ktab[k]) : -1;
-                const int off = e & 0xFFFFFF, kh = (e >> 24) & 15, kw = (e >> 28) & 7;
-                // (e < 0: a reduction index past K -- no tap: never load; its weight row is zero anyway)
-                const bool ok = pok && e >= 0 && (unsigned)(hb + kh) < (unsigned)p.H && (unsigned)(wb + kw) < (unsigned)p.W;
-                a[u] = ok ? p.x[base + off] : 0.f;
+                for (int j = 0; j < 4; ++j) d[j] = mfma4(a, b[j], d[j]);
             }
+            (void)wo_a;
+            float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                if (s0 + u < S::KS) {
-                    const volatile float* wr = &wl[4 * (s0 + u) + kk][4 * n];
-                    const float b[4] = {wr[0], wr[1], wr[2], wr[3]};
+            for (int r = 0; r < 4; ++r) {
+                const int wo = wo0 + 16 * grp + 4 * kk + r;
+                if (ho < p.Ho && wo < p.Wo) {
+                    const long long po = ((long long)img * p.Ho + ho) * p.Wo + wo;
+                    *reinterpret_cast<f32x4*>(p.out + po * p.ldy + 4 * n) = f32x4{d[0][r], d[1][r], d[2][r], d[3][r]};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) d[j] = mfma4(a[u], b[j], d[j]);
+                    for (int j = 0; j < 4; ++j) {
+                        t1[j] += d[j][r];
+                        t2[j] += d[j][r] * d[j][r];
+                    }
                 }
             }
-        }
-        float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long long po = g * 16 + 4 * kk + r;
-            if (po < p.M) {
-                *reinterpret_cast<f32x4*>(p.out + po * p.ldy + 4 * n) = f32x4{d[0][r], d[1][r], d[2][r], d[3][r]};
+            if (p.stats != nullptr) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    t1[j] += d[j][r];
-                    t2[j] += d[j][r] * d[j][r];
+                    float a1 = t1[j], a2 = t2[j];
+                    a1 += __shfl_xor(a1, 16);
+                    a2 += __shfl_xor(a2, 16);
+                    a1 += __shfl_xor(a1, 32);
+                    a2 += __shfl_xor(a2, 32);
+                    s1[j] += (double)a1;  // (16 pixels summed in fp32, everything beyond in double, as the implicit-GEMM epilogue)
+                    s2[j] += (double)a2;
                 }
-            }
-        }
-        if (p.stats != nullptr) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float a1 = t1[j], a2 = t2[j];
-                a1 += __shfl_xor(a1, 16);
-                a2 += __shfl_xor(a2, 16);
-                a1 += __shfl_xor(a1, 32);
-                a2 += __shfl_xor(a2, 32);
-                s1[j] += (double)a1;  // (16 pixels summed in fp32, everything beyond in double, as the implicit-GEMM epilogue)
-                s2[j] += (double)a2;
             }
         }
     }
@@ -208,56 +215,65 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const SmallArgs p) {
     }
 }
 
-// dw[co][k] += sum_p dy[p][co] * patch[p][k]
+// dw[co][k] += sum_p dy[p][co] * patch[p][k]; a block walks output tiles (accumulators persist), one reduction at the end
 template <int CIN>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const SmallArgs p) {
     using S = Stem<CIN>;
-    extern __shared__ float red_dyn[];  // [64][KB * 16]
     constexpr int KP = S::KB * 16;
-    for (int i = threadIdx.x; i < 64 * KP; i += 256) red_dyn[i] = 0.f;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, n = lane & 15, kk = lane >> 4;
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
-    const long long groups = (p.M + 3) / 4;
-    const int hw = p.Ho * p.Wo;
-    int koff[S::KB], kkh[S::KB], kkw[S::KB];  // this lane's reduction index m = 16 b + n of every K block
+    extern __shared__ float dyn[];  // patch [PH * PW * CIN] | red [64][KP]
+    float* patch = dyn;
+    float* red = dyn + STEM_PH * STEM_PW * CIN;
+    for (int i = threadIdx.x; i < 64 * KP; i += 256) red[i] = 0.f;
+    const int lane = threadIdx.x & 63, n = lane & 15, kk = lane >> 4, wv = threadIdx.x >> 6;
+    int koff[S::KB];  // this lane's reduction index m = 16 b + n of every K block: offset inside the patch (past K: 0, masked below)
+    bool kval[S::KB];
 #pragma unroll
     for (int b = 0; b < S::KB; ++b) {
-        stem_k<CIN>(16 * b + n, p.W, koff[b], kkh[b], kkw[b]);
-        if (16 * b + n >= S::K) kkh[b] = 1 << 20;  // past the end: never valid
+        int kh, kw;
+        stem_k<CIN>(16 * b + n, STEM_PW, koff[b], kh, kw);
+        kval[b] = 16 * b + n < S::K;
+        if (!kval[b]) koff[b] = 0;
     }
     f32x4 d[S::KB][4];
 #pragma unroll
     for (int b = 0; b < S::KB; ++b)
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (long long g = wave; g < groups; g += nwaves) {
-        const long long pix = g * 4 + kk;
-        const bool pok = pix < p.M;
-        const int img = pok ? (int)(pix / hw) : 0, rem = pok ? (int)(pix - (long long)img * hw) : 0;
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        const int hb = 2 * ho - 3, wb = 2 * wo - 3;
-        const long long base = ((long long)(img * p.H + hb) * p.W + wb) * CIN;
-        const f32x4 gv = pok ? *reinterpret_cast<const f32x4*>(p.dy + pix * p.ldy + 4 * n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tiles_w = (p.Wo + STEM_TW - 1) / STEM_TW, tiles_h = (p.Ho + STEM_TH - 1) / STEM_TH;
+    const int ntiles = p.N * tiles_h * tiles_w;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h, img = tile / (tiles_w * tiles_h);
+        const int ho0 = th * STEM_TH, wo0 = tw * STEM_TW;
+        __syncthreads();
+        stem_load_patch<CIN>(p, patch, img, ho0, wo0);
+        __syncthreads();
+        const int ho = ho0 + wv;  // wave wv: output row ho0 + wv, 16 groups of 4 consecutive columns
+        for (int grp = 0; grp < STEM_TW / 4; ++grp) {
+            const int wo = wo0 + 4 * grp + kk;
+            const bool pok = ho < p.Ho && wo < p.Wo;
+            const long long pix = ((long long)img * p.Ho + ho) * p.Wo + wo;
+            const f32x4 gv = pok ? *reinterpret_cast<const f32x4*>(p.dy + pix * p.ldy + 4 * n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int pbase = (2 * wv * STEM_PW + 2 * (4 * grp + kk)) * CIN;
 #pragma unroll
-        for (int b = 0; b < S::KB; ++b) {
-            const bool ok = pok && (unsigned)(hb + kkh[b]) < (unsigned)p.H && (unsigned)(wb + kkw[b]) < (unsigned)p.W;
-            const float a = ok ? p.x[base + koff[b]] : 0.f;
+            for (int b = 0; b < S::KB; ++b) {
+                const float a = kval[b] ? patch[pbase + koff[b]] : 0.f;  // (dy is zero for pixels outside the image)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[b][j] = mfma4(a, gv[j], d[b][j]);  // D_{b,j}[m][n] += patch[p][16 b + m] * dy[p][4 n + j]
+                for (int j = 0; j < 4; ++j) d[b][j] = mfma4(a, gv[j], d[b][j]);  // D_{b,j}[m][n] += patch[p][16 b + m] * dy[p][4 n + j]
+            }
         }
     }
     // D_{b,j}[row = 4 kk + r][col = n] = dw[co = 4 n + j][k = 16 b + 4 kk + r]: the block's four waves meet in LDS
+    __syncthreads();
 #pragma unroll
     for (int b = 0; b < S::KB; ++b)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&red_dyn[(4 * n + j) * KP + 16 * b + 4 * kk + r], d[b][j][r]);
+            for (int r = 0; r < 4; ++r) atomicAdd(&red[(4 * n + j) * KP + 16 * b + 4 * kk + r], d[b][j][r]);
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * S::K; i += 256) {
         const int co = i / S::K, k = i - co * S::K;
-        atomicAdd(p.out + i, red_dyn[co * KP + k]);
+        atomicAdd(p.out + i, red[co * KP + k]);
     }
 }
 
@@ -270,7 +286,7 @@ int grid_for(long long groups, int per_wave) {
 
 bool stem_geometry(const HnConvDesc* d) {
     return d->KH == 7 && d->KW == 7 && d->stride == 2 && d->pad == 3 && d->dil == 1 && d->Cout == 64 &&
-           (d->Cin == 1 || d->Cin == 3 || d->Cin == 4) && d->ldx == d->Cin && d->ldy % 4 == 0 &&
+           (d->Cin == 1 || d->Cin == 3) && d->ldx == d->Cin && d->ldy % 4 == 0 &&
            d->Hout == (d->Hin - 1) / 2 + 1 && d->Wout == (d->Win - 1) / 2 + 1 &&
            (long long)d->N * d->Hin * d->Win * d->Cin < (1LL << 31) && (6 * d->Win + 6) * d->Cin + d->Cin < (1 << 24);
 }
@@ -298,10 +314,10 @@ extern "C" int hn_conv_stem_fwd(const float* x, const float* w, float* y, double
     if (!hn_aligned16(y)) return HN_EALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const SmallArgs a = small_args(x, w, y, y, stats, d);
-    const dim3 grid(grid_for((a.M + 15) / 16, 8));
+    const int ntiles = d->N * ((d->Hout + STEM_TH - 1) / STEM_TH) * ((d->Wout + STEM_TW - 1) / STEM_TW);
+    const dim3 grid(ntiles < 2048 ? ntiles : 2048);
     if (d->Cin == 1) HN_LAUNCH(stem_fwd_kernel<1>, grid, dim3(256), 0, s, a);
-    else if (d->Cin == 3) HN_LAUNCH(stem_fwd_kernel<3>, grid, dim3(256), 0, s, a);
-    else HN_LAUNCH(stem_fwd_kernel<4>, grid, dim3(256), 0, s, a);
+    else HN_LAUNCH(stem_fwd_kernel<3>, grid, dim3(256), 0, s, a);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -316,12 +332,12 @@ extern "C" int hn_conv_stem_wgrad(const float* x, const float* dy, float* dw, co
         hipMemsetAsync(dw, 0, (size_t)64 * K * sizeof(float), s) != hipSuccess)
         return HN_ELAUNCH;
     const SmallArgs a = small_args(x, nullptr, dy, dw, nullptr, d);
-    const dim3 grid(grid_for((a.M + 3) / 4, 64));
+    const int ntiles = d->N * ((d->Hout + STEM_TH - 1) / STEM_TH) * ((d->Wout + STEM_TW - 1) / STEM_TW);
+    const dim3 grid(ntiles < 512 ? ntiles : 512);  // two blocks per CU; every block ends with 64 * K global atomics
     const int kp = ((K + 15) / 16) * 16;
-    const int lds = 64 * kp * (int)sizeof(float);
+    const int lds = (64 * kp + STEM_PH * STEM_PW * d->Cin) * (int)sizeof(float);
     if (d->Cin == 1) HN_LAUNCH(stem_wgrad_kernel<1>, grid, dim3(256), lds, s, a);
-    else if (d->Cin == 3) HN_LAUNCH(stem_wgrad_kernel<3>, grid, dim3(256), lds, s, a);
-    else HN_LAUNCH(stem_wgrad_kernel<4>, grid, dim3(256), lds, s, a);
+    else HN_LAUNCH(stem_wgrad_kernel<3>, grid, dim3(256), lds, s, a);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

@@ -687,6 +687,47 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const float* __restrict__ 
     }
 }
 
+// dx = dy * act'(out) AND dbias[c] += sum over pixels of dx (the bias gradient of a convolution with a fused activation: the
+// critics' conv + LeakyReLU layers, cm/discriminator_model.py:40-58) in one pass over dy -- a separate column-sum pass cost as
+// much as this one again (and 46 us of latency on the critics' small tensors).
+template <int V>
+__global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ out,
+                                                          int ldo, float* __restrict__ dx, int lddx, int64_t npix, int C, int act,
+                                                          float slope, float* __restrict__ dbias) {
+    __shared__ float red[256 * 4];
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const bool live = c < C;
+    float s[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) s[i] = 0.f;
+    if (live) {
+        for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
+            float g[V], o[V], r[V];
+            ldv<V>(dy + pix * lddy + c, g);
+            ldv<V>(out + pix * ldo + c, o);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float k = o[i] > 0.f ? 1.f : (act == HN_ACT_RELU ? 0.f : (act == HN_ACT_NONE ? 1.f : slope));
+                r[i] = g[i] * k;
+                s[i] += r[i];
+            }
+            stv<V>(dx + pix * lddx + c, r);
+        }
+    }
+    const int bx = blockDim.x, by = blockDim.y, tx = threadIdx.x, ty = threadIdx.y;
+#pragma unroll
+    for (int i = 0; i < V; ++i) red[(ty * bx + tx) * V + i] = s[i];
+    __syncthreads();
+    if (ty == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float a = 0.f;
+            for (int k = 0; k < by; ++k) a += red[(k * bx + tx) * V + i];
+            atomicAdd(dbias + c + i, a);
+        }
+    }
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void scale_nc_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mask,
                                                       float* __restrict__ y, int ldy, int64_t npix, int64_t hw, int C) {
@@ -1058,6 +1099,17 @@ extern "C" int hn_act_bwd(const float* dy, int lddy, const float* out, int ldo, 
     const RowLaunch pl = plan_rows(npix, C, {dy, out, dx}, {lddy, ldo, lddx});
     if (pl.V == 4) HN_LAUNCH((rowwise_kernel<4, 0>), pl.grid, pl.block, 0, s, dy, lddy, out, ldo, dx, lddx, npix, C, act, leaky_slope);
     else HN_LAUNCH((rowwise_kernel<1, 0>), pl.grid, pl.block, 0, s, dy, lddy, out, ldo, dx, lddx, npix, C, act, leaky_slope);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_act_bwd_bias(const float* dy, int lddy, const float* out, int ldo, float* dx, int lddx, int64_t npix, int C,
+                               int act, float leaky_slope, float* dbias, void* stream) {
+    if (!dy || !out || !dx || !dbias || act < 0 || act > 3 || bad_rows(npix, C, {lddy, ldo, lddx})) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(dbias, 0, (size_t)C * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
+    const RowLaunch pl = plan_rows(npix, C, {dy, out, dx}, {lddy, ldo, lddx}, 512);
+    HN_LAUNCH_V(pl, act_bwd_bias_kernel, dy, lddy, out, ldo, dx, lddx, npix, C, act, leaky_slope, dbias);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

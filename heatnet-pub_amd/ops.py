@@ -716,7 +716,7 @@ SMALL_STEM = os.environ.get("HEATNET_SMALL_STEM", "0") == "1"
 
 
 def _stem_geometry(d):
-    return (d.KH == 7 and d.KW == 7 and d.stride == 2 and d.pad == 3 and d.dil == 1 and d.Cout == 64 and d.Cin in (1, 3, 4) and
+    return (d.KH == 7 and d.KW == 7 and d.stride == 2 and d.pad == 3 and d.dil == 1 and d.Cout == 64 and d.Cin in (1, 3) and
             d.ldx == d.Cin and d.ldy % 4 == 0)
 
 
@@ -894,10 +894,19 @@ class _Conv2d(torch.autograd.Function):
         _, _, ho, wo = dy.shape
         npix = n * ho * wo
         s = _stream()
+        ctx.db_done = None
         if act != ACT_NONE:
             dpre = new_nhwc(n, cout, ho, wo, x.device)
-            check(lib.hn_act_bwd(_ptr(dy), lddy, _ptr(y), cout, _ptr(dpre), cout, npix, cout, act, slope, s),
-                  "hn_act_bwd")
+            if ctx.has_bias and ctx.needs_input_grad[2] and not ctx.zero_bias_grad:
+                # the bias gradient is the column sum of the tensor this pass writes: taken along (one pass over dy, not two)
+                slot = grad_slot(ctx.b_leaf, accumulate_ok=False) if ctx.b_leaf is not None else None
+                db = slot[0] if slot is not None else torch.empty(cout, device=x.device, dtype=torch.float32)
+                check(lib.hn_act_bwd_bias(_ptr(dy), lddy, _ptr(y), cout, _ptr(dpre), cout, npix, cout, act, slope, _ptr(db), s),
+                      "hn_act_bwd_bias")
+                ctx.db_done = db
+            else:
+                check(lib.hn_act_bwd(_ptr(dy), lddy, _ptr(y), cout, _ptr(dpre), cout, npix, cout, act, slope, s),
+                      "hn_act_bwd")
             dy, lddy = dpre, cout
         d = _desc(n, h, wd, cin, ldx, ho, wo, cout, lddy, kh, kw, stride, pad, dil)
         dx = dw = db = None
@@ -1025,6 +1034,8 @@ class _Conv2d(torch.autograd.Function):
     def _finish_backward(ctx, lib, dx, dw_out, dy, lddy, npix, cout, x, s):
         """Bias gradient and the return tuple of backward()."""
         db = None
+        if getattr(ctx, "db_done", None) is not None:
+            return dx, dw_out, ctx.db_done, None, None, None, None, None, None, None, None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             slot = grad_slot(ctx.b_leaf, accumulate_ok=False) if ctx.b_leaf is not None else None
             db = slot[0] if slot is not None else None

@@ -310,7 +310,7 @@ int hn_conv2d_wgrad_det(const float* x, const float* dy, float* dw, const HnConv
                         float* workspace, void* stream);
 
 /* Layers with a tiny channel count on one side (csrc/conv_small.hip): HBM-bound streams on v_mfma_f32_16x16x4_f32 (exact
- * fp32), every global access a full 256-byte pixel row.  Stems: KH = KW = 7, stride 2, pad 3, Cin in {1, 3, 4} (ldx == Cin),
+ * fp32), every global access a full 256-byte pixel row.  Stems: KH = KW = 7, stride 2, pad 3, Cin in {1, 3} (ldx == Cin),
  * Cout = 64, no bias (cm/models/extractors.py:108-126); `stats` as for hn_conv2d_fwd.  Head: 1 x 1, Cin = 64, Cout <= 16
  * (cm/models/pspnet.py:56-58); `w` is the forward weight [Cout][64] (no flip needed), dx is overwritten.  The weight
  * gradients accumulate with float atomics (flags as for hn_conv2d_wgrad); HN_ESHAPE for any other geometry. */
@@ -394,6 +394,11 @@ int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, cons
  * output equals the sign of the pre-activation).  In place allowed (dx == dy). */
 int hn_act_bwd(const float* dy, int lddy, const float* out, int ldo, float* dx, int lddx,
                int64_t npix, int C, int act, float leaky_slope, void* stream);
+
+/* hn_act_bwd that also returns the bias gradient dbias[c] = sum over pixels of dx (overwritten): one pass instead of
+ * hn_act_bwd + hn_channel_sum for the critics' conv + LeakyReLU layers (cm/discriminator_model.py:40-58). */
+int hn_act_bwd_bias(const float* dy, int lddy, const float* out, int ldo, float* dx, int lddx, int64_t npix, int C, int act,
+                    float leaky_slope, float* dbias, void* stream);
 
 /* y[n,:,:,c] = x[n,:,:,c] * mask[n*C + c]: nn.Dropout2d forward and backward given a host-drawn
  * keep/(1-p) mask, cm/models/pspnet.py:49,55,63-72. */

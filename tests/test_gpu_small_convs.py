@@ -35,7 +35,7 @@ def rel(a, ref):
     return float((a.double().cpu() - ref).abs().max() / ref.abs().max())
 
 
-@pytest.mark.parametrize("cin", [3, 1, 4])
+@pytest.mark.parametrize("cin", [3, 1])
 @pytest.mark.parametrize("hw", [(64, 96), (37, 53), (320, 704)])
 def test_stem_forward_and_weight_gradient(dev, cin, hw):
     from heatnet_amd import _lib, ops
