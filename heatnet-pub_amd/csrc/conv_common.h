@@ -56,6 +56,9 @@ struct ConvArgs {
     // optional [HN_STAT_REPLICAS][2][K] words next to `stats`: order-preserving keys of the per-channel maximum of y and of
     // -y over the launch (zero = nothing seen), from which hn_bn_finalize bounds the normalised tensor's magnitude
     unsigned* minmax = nullptr;
+    // one-plane bf16 arithmetic, forward with BatchNorm statistics: y holds bf16 elements (ldy counts elements) -- the
+    // statistics still come from the fp32 accumulators.  Honoured by the conv_igemm4 one-plane kernels only.
+    int y_bf16 = 0;
 };
 
 // bf16x3 LDS image: [split][row][32 k] bf16 with 80-byte rows (64 B of data + 16 B pad: 16 consecutive rows start in
@@ -165,7 +168,7 @@ __device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[T
 // in front of every store.
 // `oscale`, `oscale2` (f16x2: the inverse operand scales, powers of two, applied one after the other -- see conv_init_acc)
 // take the accumulators back to the tensor's own scale first.
-template <int TM, int TN, bool S16, int BM = 64 * TM, int BN = 64 * TN, bool SCALED = false>
+template <int TM, int TN, bool S16, int BM = 64 * TM, int BN = 64 * TN, bool SCALED = false, bool YB = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], const AccMap<TM, TN, S16>& am,
                                               const int* rowinfo, int m0, int tile_m, int split, float oscale = 1.f,
                                               float oscale2 = 1.f) {
@@ -238,7 +241,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                                 s2 += v * v;
                                 vmax = fmaxf(vmax, v);
                                 vmin = fminf(vmin, v);
-                                p.y[(size_t)row * p.ldy + col] = v > 0.f ? v : v * neg_slope;
+                                const float o = v > 0.f ? v : v * neg_slope;
+                                if constexpr (YB) {
+                                    if (p.y_bf16) reinterpret_cast<__bf16*>(p.y)[(size_t)row * p.ldy + col] = (__bf16)o;
+                                    else p.y[(size_t)row * p.ldy + col] = o;
+                                } else {
+                                    p.y[(size_t)row * p.ldy + col] = o;
+                                }
                             }
                         }
                     }

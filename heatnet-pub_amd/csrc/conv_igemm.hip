@@ -1025,6 +1025,9 @@ int conv2d_fwd_impl(const float* x, const float* x_scale, const float* w, const 
                     double* stats, const HnConvDesc* d, int act, float slope, int variant, void* stream,
                     const void* xh = nullptr, long long xh_plane = 0, unsigned* minmax = nullptr) {
     if ((x == nullptr && xh == nullptr) || (w == nullptr && xh == nullptr) || y == nullptr) return HN_EINVAL;
+    const bool y_bf16 = (act & HN_Y_BF16) != 0;  // (one bf16 plane in, bf16 y out: hn_conv2d_fwd_planes only)
+    act &= ~HN_Y_BF16;
+    if (y_bf16 && (xh == nullptr || x_scale != nullptr || act != HN_ACT_NONE || d == nullptr || d->ldy % 2 != 0)) return HN_EINVAL;
     if (act < HN_ACT_NONE || act > HN_ACT_LEAKY) return HN_EINVAL;
     const int rc = check_desc(d);
     if (rc != HN_OK) return rc;
@@ -1043,6 +1046,7 @@ int conv2d_fwd_impl(const float* x, const float* x_scale, const float* w, const 
     if (xh != nullptr) {  // plane tensor: the all-DMA kernels only (no split-K on that path)
         if (xh_plane <= 0 || w_x3 == nullptr) return HN_EINVAL;
         if (x_scale == nullptr) variant = (variant & 63) | (3 << 6);  // one bf16 plane: the mixed-precision bf16 arithmetic
+        a.y_bf16 = y_bf16 ? 1 : 0;
         a.xh = static_cast<const unsigned short*>(xh);
         a.xh_plane = xh_plane;
         a.x_bytes = (((long long)d->N * d->Hin * d->Win - 1) * d->ldx + d->Cin) * 2;

@@ -91,6 +91,13 @@ __device__ __forceinline__ void ld_bf16(const unsigned short* __restrict__ p, fl
     }
 }
 
+// y of a BatchNorm pass: fp32, or (YB: one-plane bf16 arithmetic, HN_Y_BF16) bf16 elements behind the same pointer
+template <int V, bool YB>
+__device__ __forceinline__ void ld_y(const float* __restrict__ y, int64_t off, float (&v)[V]) {
+    if constexpr (YB) ld_bf16<V>(reinterpret_cast<const unsigned short*>(y) + off, v);
+    else ldv<V>(y + off, v);
+}
+
 struct RowLaunch {
     dim3 grid, block;
     int V;
@@ -155,7 +162,7 @@ struct PlaneIn {
 
 // ZP: z is (also) written as a plane tensor with the scale of zp.slot (a bound known before the pass, hn_bn_finalize_range);
 // the fp32 z is then optional.  RP: the residual is a plane tensor.
-template <int V, bool ZP = false, bool RP = false>
+template <int V, bool ZP = false, bool RP = false, bool YB = false>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, int ldy,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ res, int ldr, float* __restrict__ z,
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
         const float slope = act == HN_ACT_PRELU ? *slope_p : leaky;
         for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
             float v[V], r[V], o[V], m[V];
-            ldv<V>(y + pix * ldy + c, v);
+            ld_y<V, YB>(y, pix * ldy + c, v);
             if constexpr (RP) {
                 if (rp.slot != nullptr) ld_planes<V>(rp.hi + pix * rp.ld + c, rp.plane, r, ri);
                 else ld_bf16<V>(rp.hi + pix * rp.ld + c, r);
@@ -231,7 +238,7 @@ __device__ __forceinline__ float slot_max(const float* slot) {
 // sums[0:C] += sum du ; sums[C:2C] += sum du*xhat ; sums[2C] += dslope   (double accumulation throughout)
 // ZMASK / MASK are compile-time so that the pixel loop is straight-line code the compiler can unroll and pipeline
 // (loads of the next pixels issued before the arithmetic of the current ones)
-template <int V, bool ZMASK, bool MASK>
+template <int V, bool ZMASK, bool MASK, bool YB = false>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ dz, int lddz,
                                                                const float* __restrict__ z, int ldz,
                                                                const float* __restrict__ y, int ldy,
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
     if (live) {
         const int64_t first = (int64_t)blockIdx.y * blockDim.y + threadIdx.y, step = (int64_t)gridDim.y * blockDim.y;
         const float* pg = dz + first * lddz + c;
-        const float* py = y + first * ldy + c;
+        int64_t oy = first * ldy + c;
         const float* pz = (ZMASK && z != nullptr) ? z + first * ldz + c : nullptr;
         const int64_t sg = step * lddz, sy = step * ldy, sz = step * ldz;
 #pragma unroll 4
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
             float g[V], zz[V], yy[V], du[V];
             float ds = 0.f;
             ldv<V>(pg, g);
-            ldv<V>(py, yy);
+            ld_y<V, YB>(y, oy, yy);
             if constexpr (ZMASK) {
                 if (V == 4 && rbits != nullptr) {  // the ReLU mask as one byte per 16-B piece instead of z itself
                     const unsigned b = rbits[pix * (C / 4) + c / 4];
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
                 for (int i = 0; i < V; ++i) zz[i] = 0.f;
             }
             pg += sg;
-            py += sy;
+            oy += sy;
             if constexpr (MASK) {
                 float m[V];
                 ldv<V>(mask + (pix / hw) * C + c, m);
@@ -418,7 +425,7 @@ __global__ void f64_to_f32_reset_kernel(double* __restrict__ in, float* __restri
     }
 }
 
-template <int V, bool DP = false>
+template <int V, bool DP = false, bool YB = false>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __restrict__ dz, int lddz,
                                                               const float* __restrict__ z, int ldz,
                                                               const float* __restrict__ y, int ldy,
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
     for (int64_t pix = (int64_t)blockIdx.y * blockDim.y + threadIdx.y; pix < npix; pix += (int64_t)gridDim.y * blockDim.y) {
         float g[V], zz[V], yy[V], du[V], o[V];
         ldv<V>(dz + pix * lddz + c, g);
-        ldv<V>(y + pix * ldy + c, yy);
+        ld_y<V, YB>(y, pix * ldy + c, yy);
         if (mask != nullptr) {
             float m[V];
             ldv<V>(mask + (pix / hw) * C + c, m);
@@ -904,7 +911,10 @@ extern "C" int hn_bn_act_fwd_planes(const float* y, int ldy, const float* scale,
                                     int ldz, void* z_planes, int64_t z_plane_elems, int ldzp, const float* z_slot, int64_t npix,
                                     int C, int act, const float* slope, float leaky_slope, const float* mask, int64_t hw,
                                     unsigned char* relu_bits, void* stream) {
+    const bool yb = (act & HN_Y_BF16) != 0;  // y holds bf16 elements (one-plane bf16 arithmetic)
+    act &= ~HN_Y_BF16;
     if (!y || !scale || !shift || !z_planes || act < 0 || act > 3 || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;  // (z_slot NULL: bf16)
+    if (yb && z_slot != nullptr) return HN_EINVAL;
     if (residual && res_planes) return HN_EINVAL;
     if (res_planes && (res_plane_elems < (npix - 1) * ldrp + C || ldrp < C)) return HN_EINVAL;
     if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
@@ -914,9 +924,19 @@ extern "C" int hn_bn_act_fwd_planes(const float* y, int ldy, const float* scale,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool v4 = planes_v4(z_planes, z_plane_elems, ldzp) && planes_v4(res_planes, res_plane_elems, ldrp);
     const RowLaunch pl = plan_rows(npix, C, {y, z, residual, scale, shift, mask, v4 ? nullptr : kUnaligned}, {ldy, z ? ldz : 4, residual ? ldr : 4});
-    if (relu_bits != nullptr && pl.V != 4) return HN_EALIGN;
+    if ((relu_bits != nullptr || yb) && pl.V != 4) return HN_EALIGN;
     const PlaneOut zp{static_cast<unsigned short*>(z_planes), (long long)z_plane_elems, ldzp, z_slot};
     const PlaneIn rp{static_cast<const unsigned short*>(res_planes), (long long)res_plane_elems, ldrp, res_slot};
+    if (yb) {
+        if (res_planes)
+            HN_LAUNCH((bn_act_fwd_kernel<4, true, true, true>), pl.grid, pl.block, 0, s, y, ldy, scale, shift, residual, ldr, z, ldz,
+                      npix, C, act, slope, leaky_slope, mask, hw, (float*)nullptr, relu_bits, zp, rp);
+        else
+            HN_LAUNCH((bn_act_fwd_kernel<4, true, false, true>), pl.grid, pl.block, 0, s, y, ldy, scale, shift, residual, ldr, z, ldz,
+                      npix, C, act, slope, leaky_slope, mask, hw, (float*)nullptr, relu_bits, zp, rp);
+        HN_CHECK_LAUNCH();
+        return HN_OK;
+    }
 #define HN_LAUNCH_FWDP(RPF)                                                                                                    \
     do {                                                                                                                        \
         if (pl.V == 4)                                                                                                          \
@@ -941,16 +961,19 @@ int bn_bwd_reduce_impl(const float* dz, int lddz, const float* z, int ldz, const
                                     int out_accumulate, const float* mask, int64_t hw, const unsigned char* relu_bits,
                                     void* stream, unsigned* gmax = nullptr, const float* gamma = nullptr,
                                     const float* xhat_max = nullptr, float inv_count = 0.f, float* dy_slot = nullptr) {
+    const bool yb = (act & HN_Y_BF16) != 0;
+    act &= ~HN_Y_BF16;
     if (!dz || !y || !mean || !invstd || !scale || !shift || !sums || !dparams || act < 0 || act > 3) return HN_EINVAL;
     if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
     if (act == HN_ACT_PRELU && !slope) return HN_EINVAL;
+    if (yb && gmax != nullptr) return HN_EINVAL;
     if (bad_rows(npix, C, {lddz, ldy}) || (z && ldz < C)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool zmask = act == HN_ACT_RELU && (z != nullptr || relu_bits != nullptr);
     const bool zread = zmask && relu_bits == nullptr;  // z itself is read only when there is no byte mask
     RowLaunch pl = plan_rows(npix, C, {dz, y, zread ? z : nullptr, mean, invstd, scale, shift},
                              {lddz, ldy, zread ? ldz : 4}, 2048);
-    if (relu_bits != nullptr && pl.V != 4) return HN_EALIGN;
+    if ((relu_bits != nullptr || yb) && pl.V != 4) return HN_EALIGN;
     {
         // every block ends with 2C double atomics: give each thread at least MINPIX pixels so that small tensors are not
         // dominated by them (a [8x40x88, 256] tensor went from 2048 blocks / 1 M atomics to 440 / 225 k)
@@ -963,7 +986,10 @@ int bn_bwd_reduce_impl(const float* dz, int lddz, const float* z, int ldz, const
     }
 #define HN_LAUNCH_REDUCE(ZM, MK)                                                                                       \
     do {                                                                                                                \
-        if (pl.V == 4)                                                                                                  \
+        if (yb)                                                                                                         \
+            HN_LAUNCH((bn_act_bwd_reduce_kernel<4, ZM, MK, true>), pl.grid, pl.block, 0, s, dz, lddz, z, ldz, y, ldy, mean,  \
+                      invstd, scale, shift, npix, C, act, slope, leaky_slope, sums, mask, hw, relu_bits, gmax);         \
+        else if (pl.V == 4)                                                                                             \
             HN_LAUNCH((bn_act_bwd_reduce_kernel<4, ZM, MK>), pl.grid, pl.block, 0, s, dz, lddz, z, ldz, y, ldy, mean, invstd, \
                       scale, shift, npix, C, act, slope, leaky_slope, sums, mask, hw, relu_bits, gmax);                 \
         else                                                                                                            \
@@ -1020,7 +1046,10 @@ int bn_bwd_apply_impl(const float* dz, int lddz, const float* z, int ldz, const 
                                    int lddy, float* dres, int lddr, int64_t npix, int C, int act, const float* slope,
                                    float leaky_slope, const float* mask, int64_t hw, float* dy_scale,
                                    const unsigned char* relu_bits, void* stream, PlaneOut dp = PlaneOut{nullptr, 0, 0, nullptr}) {
+    const bool yb = (act & HN_Y_BF16) != 0;
+    act &= ~HN_Y_BF16;
     if (!dz || !y || !mean || !invstd || !gamma || !scale || !shift || (!dy && !dp.hi) || act < 0 || act > 3) return HN_EINVAL;
+    if (yb && (dp.hi == nullptr || dp.slot != nullptr)) return HN_EINVAL;
     if (dp.hi != nullptr) { dy = nullptr; lddy = C; }
     if (mask != nullptr && (hw <= 0 || npix % hw != 0)) return HN_EINVAL;
     if ((training && (!dparams || count <= 0)) || (act == HN_ACT_PRELU && !slope)) return HN_EINVAL;
@@ -1031,10 +1060,14 @@ int bn_bwd_apply_impl(const float* dz, int lddz, const float* z, int ldz, const 
         plan_rows(npix, C, {dz, y, dy, dres, zmask ? z : nullptr, mean, invstd, gamma, scale, shift,
                             planes_v4(dp.hi, dp.plane, dp.ld) ? nullptr : kUnaligned},
                   {lddz, ldy, lddy, dres ? lddr : 4, zmask ? ldz : 4});
-    if (relu_bits != nullptr && pl.V != 4) return HN_EALIGN;
+    if ((relu_bits != nullptr || yb) && pl.V != 4) return HN_EALIGN;
     const float inv_count = training ? (float)(1.0 / (double)count) : 0.f;
     if (dp.hi != nullptr) {
-        if (pl.V == 4)
+        if (yb)
+            HN_LAUNCH((bn_act_bwd_apply_kernel<4, true, true>), pl.grid, pl.block, 0, s, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma,
+                      scale, shift, dparams, inv_count, training, dy, lddy, dres, lddr, npix, C, act, slope, leaky_slope, mask, hw,
+                      (float*)nullptr, relu_bits, dp);
+        else if (pl.V == 4)
             HN_LAUNCH((bn_act_bwd_apply_kernel<4, true>), pl.grid, pl.block, 0, s, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale,
                       shift, dparams, inv_count, training, dy, lddy, dres, lddr, npix, C, act, slope, leaky_slope, mask, hw,
                       (float*)nullptr, relu_bits, dp);

@@ -1267,6 +1267,8 @@ def as_f32(t):
     return t
 
 
+HN_Y_BF16 = 256  # include/heatnet_hip.h: OR-ed into `act`, the pre-normalisation tensor y holds bf16 elements
+BF16_Y = os.environ.get("HEATNET_BF16_Y", "1") != "0"  # A/B knob of the bf16 arithmetic: 0 = y stays fp32 between conv and BatchNorm
 BF16_PLANE = "bf16"  # `_hn_planes` marker of a ONE-plane bf16 tensor (the mixed-precision bf16 arithmetic): bf16(t), no scale
 
 
@@ -1371,7 +1373,13 @@ class _ConvBnAct(torch.autograd.Function):
         npix = n * ho * wo
         dev = xp.device
         wh, ctx.wt, ctx.wth = _weight_operands(w_in, w, stride, pad, dil, CONV_MATH, ctx.needs_input_grad[0], s)
-        y = new_nhwc(n, cout, ho, wo, dev)
+        # one-plane bf16 arithmetic: the pre-normalisation tensor never leaves this node -- kept as bf16 (what the reference's
+        # mixed-precision mode stores between its convolution and BatchNorm kernels, in fp16), statistics from the fp32 accumulators
+        ybf = HN_Y_BF16 if (bf16 and BF16_Y and cout % 4 == 0) else 0
+        if ybf:
+            y = torch.empty((n, ho, wo, cout), device=dev, dtype=torch.bfloat16).permute(0, 3, 1, 2)
+        else:
+            y = new_nhwc(n, cout, ho, wo, dev)
         d = _desc(n, h, wd, cin, cin, ho, wo, cout, cout, kh, kw, stride, pad, dil)
         ws.open_stats()
         xplane = n * h * wd * cin
@@ -1382,7 +1390,7 @@ class _ConvBnAct(torch.autograd.Function):
 
         def launch(v, st, keys):
             check(lib.hn_conv2d_fwd_planes(_ptr(xp), xplane, _ptr(x_slot), _ptr(wh), _ptr(b), _ptr(y), _ptr(st), _ptr(keys),
-                                           ctypes.byref(d), ACT_NONE, 0.0, v, s), "hn_conv2d_fwd_planes")
+                                           ctypes.byref(d), ACT_NONE | ybf, 0.0, v, s), "hn_conv2d_fwd_planes")
         var = _pick("fwd" + tag, d, _plane_variants(cout, cin, kh * kw), lambda v: launch(v, None, None))
         with _ConvTimer("fwd", d, lambda: _plan_name(0, d, 3, _variant(var & 3, var >> 2, 0, mcode))):
             launch(var, ws.stats, None if bf16 else ws.keys)
@@ -1421,16 +1429,18 @@ class _ConvBnAct(torch.autograd.Function):
         if zp is not None:
             check(lib.hn_bn_act_fwd_planes(_ptr(y), cout, _ptr(scale), _ptr(shift), _ptr(res_f), ldr, _ptr(res_p), npix * cout, cout,
                                            _ptr(res_slot) if res_p is not None else None, _ptr(zf), cout, _ptr(zp), npix * cout,
-                                           cout, _ptr(z_slot), npix, cout, act, _ptr(prelu_w), leaky, _ptr(drop_mask), ho * wo,
+                                           cout, _ptr(z_slot), npix, cout, act | ybf, _ptr(prelu_w), leaky, _ptr(drop_mask), ho * wo,
                                            _ptr(rbits), s), "hn_bn_act_fwd_planes")
             zp._hn_planes = BF16_PLANE if bf16 else z_slot
         else:
             if res_p is not None:
                 raise RuntimeError("conv_bn_act: a plane-tensor residual needs a plane (or dual) output")
+            if ybf:
+                raise RuntimeError("conv_bn_act: the bf16 arithmetic writes plane (or dual) outputs")
             check(lib.hn_bn_act_fwd(_ptr(y), cout, _ptr(scale), _ptr(shift), _ptr(res_f), ldr, _ptr(zf), cout, npix, cout, act,
                                     _ptr(prelu_w), leaky, _ptr(drop_mask), ho * wo, None, _ptr(rbits), s), "hn_bn_act_fwd")
         ctx.cfg = (stride, pad, dil, act, leaky, passthrough, residual is not None, out_mode)
-        ctx.ws, ctx.drop_mask, ctx.x_slot, ctx.bf16 = ws, drop_mask, x_slot, bf16
+        ctx.ws, ctx.drop_mask, ctx.x_slot, ctx.bf16, ctx.ybf = ws, drop_mask, x_slot, bf16, ybf
         ctx.leaves = (_leaf(w_in), _leaf(b), _leaf(gamma), _leaf(beta), _leaf(prelu_w))
         # z itself is needed by the backward only for a ReLU behind a residual add without the byte mask
         keep_z = zf if (act == ACT_RELU and residual is not None and rbits is None and zf is not None) else None
@@ -1475,7 +1485,7 @@ class _ConvBnAct(torch.autograd.Function):
         if bf16:
             dy_slot = None
             check(lib.hn_bn_act_bwd_reduce(_ptr(dz), lddz, _ptr(z), cout, _ptr(y), cout, _ptr(mean), _ptr(invstd), _ptr(scale),
-                                           _ptr(shift), npix, cout, act, _ptr(prelu_w), leaky, _ptr(ws.bwd), _ptr(dpar),
+                                           _ptr(shift), npix, cout, act | ctx.ybf, _ptr(prelu_w), leaky, _ptr(ws.bwd), _ptr(dpar),
                                            _ptr(sg[0]) if sg else None, _ptr(sb[0]) if sb else None,
                                            _ptr(sp[0]) if sp else None, int(accumulate), _ptr(ctx.drop_mask), ho * wo,
                                            _ptr(rbits), s), "hn_bn_act_bwd_reduce")
@@ -1494,7 +1504,7 @@ class _ConvBnAct(torch.autograd.Function):
             dyp = new_nhwc(n, cout, ho, wo, dev)
             check(lib.hn_bn_act_bwd_apply_planes(_ptr(dz), lddz, _ptr(z), cout, _ptr(y), cout, _ptr(mean), _ptr(invstd), _ptr(gamma),
                                                  _ptr(scale), _ptr(shift), _ptr(dpar), npix, 1, _ptr(dyp), npix * cout, cout,
-                                                 _ptr(dy_slot), _ptr(dres), cout, npix, cout, act, _ptr(prelu_w), leaky,
+                                                 _ptr(dy_slot), _ptr(dres), cout, npix, cout, act | ctx.ybf, _ptr(prelu_w), leaky,
                                                  _ptr(ctx.drop_mask), ho * wo, _ptr(rbits), s), "hn_bn_act_bwd_apply_planes")
         d = _desc(n, h, wd, cin, cin, ho, wo, cout, cout, kh, kw, stride, pad, dil)
         side = None

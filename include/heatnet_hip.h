@@ -42,6 +42,11 @@ extern "C" {
 #define HN_ACT_RELU 1
 #define HN_ACT_PRELU 2   /* one shared slope read from device memory (nn.PReLU())  */
 #define HN_ACT_LEAKY 3   /* constant slope (nn.LeakyReLU(0.2))                     */
+/* OR-ed into `act` of hn_conv2d_fwd_planes / hn_bn_act_fwd_planes / hn_bn_act_bwd_reduce / hn_bn_act_bwd_apply_planes in the
+ * one-plane bf16 arithmetic (scale slots NULL): the pre-normalisation tensor y is stored as bf16 elements (ldy counts
+ * elements, C % 4 == 0) -- the convolution still takes the batch statistics from its fp32 accumulators.  Halves the bytes
+ * of the tensor every BatchNorm pass reads; not available to the fp32-result arithmetics (HN_EINVAL). */
+#define HN_Y_BF16 256
 
 /* Per-channel double accumulators (batch statistics, BatchNorm backward sums) are kept in HN_STAT_REPLICAS
  * interleaved copies so that concurrent workgroups do not serialise on one address; the kernels that consume an

@@ -238,7 +238,7 @@ FUSED_CASES = [  # cin, cout, k, stride, dil, act, residual ("f32" | "planes" | 
 ]
 
 
-@pytest.mark.parametrize("math", ["f16x2", "bf16"])
+@pytest.mark.parametrize("math", ["f16x2", "bf16", "bf16y"])
 @pytest.mark.parametrize("case", FUSED_CASES, ids=str)
 def test_fused_conv_bn_act_matches_unfused(dev, case, math):
     """layers.conv_bn_act through the fused plane-tensor node (conv_igemm4 + range-bounded scales + plane-writing BatchNorm
@@ -247,9 +247,14 @@ def test_fused_conv_bn_act_matches_unfused(dev, case, math):
     paths use the same scales and the convolution outputs agree bitwise; with one the scale may differ by a factor of two.
     math = "bf16" (the mixed-precision arithmetic): the fused node keeps ONE bf16 image per operand; the unfused path rounds the
     same fp32 values to bf16 in the convolution loaders, so everything agrees to fp32 noise except what was STORED in bf16 --
-    a plane output, a plane residual (2^-9 relative)."""
+    a plane output, a plane residual (2^-9 relative).  "bf16y": the node's default under bf16 -- it also keeps the
+    pre-normalisation tensor y in bf16 (HN_Y_BF16; "bf16" above runs with HEATNET_BF16_Y off): z moves by 2^-9 |y| / sigma,
+    the gradients are compared in the norm."""
     import torch.nn as nn
     from heatnet_amd import layers, ops
+    y16 = math == "bf16y"
+    math = "bf16" if y16 else math
+    prev_y16, ops.BF16_Y = ops.BF16_Y, y16
     cin, cout, k, stride, dil, act, res_kind, use_mask, out_mode = case
     n, h, w_ = 2, 72, 80
     pad = dil * (k - 1) // 2
@@ -318,6 +323,7 @@ def test_fused_conv_bn_act_matches_unfused(dev, case, math):
         a, b = run(True), run(False)
     finally:
         ops.set_conv_math(prev_math)
+        ops.BF16_Y = prev_y16
     stored16 = math == "bf16" and (out_mode == "planes" or res_kind == "planes")  # something was kept in bf16
     for key in b:
         ref = b[key]
@@ -330,7 +336,9 @@ def test_fused_conv_bn_act_matches_unfused(dev, case, math):
             # gradients under bf16: the unfused path runs a few geometries (strided data gradients) on the fp32 kernels, i.e.
             # WITHOUT rounding dY to bf16, and the ReLU mask behind a plane residual sees the bf16-rounded residual
             tol = 4e-3
-        if math == "bf16" and res_kind == "planes" and key not in ("z", "rm", "rv"):
+        if y16 and key == "z":
+            tol = 2.0 ** -6  # y / sigma reaches ~5, max |z| is of that order too: a few bf16 steps of y
+        if (y16 or (math == "bf16" and res_kind == "planes")) and key not in ("z", "rm", "rv"):
             # the ReLU behind the residual add sees the bf16-rounded residual: a few masks flip, and with them whole
             # gradient elements -- compared in the norm
             assert float((a[key] - ref).norm() / ref.norm()) < 3e-2, key
@@ -429,6 +437,17 @@ def test_conv_planes_bf16_bitwise(dev, case, tile):
     y1 = torch.full_like(y0, float("nan"))
     _lib.check(lib.hn_conv2d_fwd_planes(P(xb), xb.numel(), None, P(w3), P(b), P(y1), None, None, ctypes.byref(d), 0, 0.0, tile, s), "fwd")
     assert torch.equal(y0, y1)
+    # HN_Y_BF16: the same output rounded (to nearest even) to bf16 elements, the batch statistics still from the fp32 values
+    y2 = torch.zeros(n, ho, wo, cout, device=dev, dtype=torch.bfloat16)
+    st1, st2 = (torch.zeros(ops.STAT_REPLICAS * 2 * cout, device=dev, dtype=torch.float64) for _ in range(2))
+    _lib.check(lib.hn_conv2d_fwd_planes(P(xb), xb.numel(), None, P(w3), P(b), P(y1), P(st1), None, ctypes.byref(d), 0, 0.0, tile, s), "fwd")
+    _lib.check(lib.hn_conv2d_fwd_planes(P(xb), xb.numel(), None, P(w3), P(b), P(y2), P(st2), None, ctypes.byref(d), ops.HN_Y_BF16, 0.0,
+                                        tile, s), "fwd bf16 y")
+    assert torch.equal(y2, y1.to(torch.bfloat16))
+    assert torch.allclose(st1.view(16, -1).sum(0), st2.view(16, -1).sum(0), rtol=1e-11, atol=0)
+    xs = torch.ones(64 * 16, device=dev)  # (a scale slot: the fp32-result arithmetic refuses the flag)
+    assert lib.hn_conv2d_fwd_planes(P(xb), xb.numel(), P(xs), P(w3), P(b), P(y2), None, None, ctypes.byref(d), ops.HN_Y_BF16, 0.0,
+                                    tile, s) == -1
     dx1 = torch.full_like(x, float("nan"))
     _lib.check(lib.hn_conv2d_dgrad_planes(P(gb), gb.numel(), None, P(wt3), P(dx1), P(skip), cin, ctypes.byref(d), tile, s), "dgrad")
     assert torch.equal(dx0, dx1)
