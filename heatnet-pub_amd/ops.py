@@ -1375,7 +1375,7 @@ class _ConvBnAct(torch.autograd.Function):
         wh, ctx.wt, ctx.wth = _weight_operands(w_in, w, stride, pad, dil, CONV_MATH, ctx.needs_input_grad[0], s)
         # one-plane bf16 arithmetic: the pre-normalisation tensor never leaves this node -- kept as bf16 (what the reference's
         # mixed-precision mode stores between its convolution and BatchNorm kernels, in fp16), statistics from the fp32 accumulators
-        ybf = HN_Y_BF16 if (bf16 and BF16_Y and cout % 4 == 0) else 0
+        ybf = HN_Y_BF16 if (bf16 and BF16_Y and cout % 4 == 0 and out_mode != "f32") else 0  # (the plane-writing passes read it)
         if ybf:
             y = torch.empty((n, ho, wo, cout), device=dev, dtype=torch.bfloat16).permute(0, 3, 1, 2)
         else:
@@ -1435,8 +1435,6 @@ class _ConvBnAct(torch.autograd.Function):
         else:
             if res_p is not None:
                 raise RuntimeError("conv_bn_act: a plane-tensor residual needs a plane (or dual) output")
-            if ybf:
-                raise RuntimeError("conv_bn_act: the bf16 arithmetic writes plane (or dual) outputs")
             check(lib.hn_bn_act_fwd(_ptr(y), cout, _ptr(scale), _ptr(shift), _ptr(res_f), ldr, _ptr(zf), cout, npix, cout, act,
                                     _ptr(prelu_w), leaky, _ptr(drop_mask), ho * wo, None, _ptr(rbits), s), "hn_bn_act_fwd")
         ctx.cfg = (stride, pad, dil, act, leaky, passthrough, residual is not None, out_mode)

@@ -341,7 +341,9 @@ def test_fused_conv_bn_act_matches_unfused(dev, case, math):
         if (y16 or (math == "bf16" and res_kind == "planes")) and key not in ("z", "rm", "rv"):
             # the ReLU behind the residual add sees the bf16-rounded residual: a few masks flip, and with them whole
             # gradient elements -- compared in the norm
-            assert float((a[key] - ref).norm() / ref.norm()) < 3e-2, key
+            # (bf16 y: u = y * scale + shift of ~0.3 % of the elements changes sign with the rounding of y; against this test's
+            # white-noise dz every flipped mask is a whole element of error -- sqrt(0.003) ~ 5 % in the norm)
+            assert float((a[key] - ref).norm()) <= (8e-2 if y16 else 3e-2) * float(ref.norm()), key  # (db: both exactly zero)
             continue
         err = float((a[key] - ref).abs().max())
         assert err <= tol * max(float(ref.abs().max()), 1e-30), (key, err, float(ref.abs().max()))
