@@ -207,3 +207,11 @@ class ResNeXt(nn.Module):
 
 def net_resnext50(**kw):
     return ResNeXt(structure=[3, 4, 6, 3], **kw)
+
+
+def net_resnext101(**kw):  # (`_NETS`, :419-429)
+    return ResNeXt(structure=[3, 4, 23, 3], **kw)
+
+
+def net_resnext152(**kw):
+    return ResNeXt(structure=[3, 8, 36, 3], **kw)

@@ -93,7 +93,14 @@ def test_phase_switch_and_drop_in_module_paths():
     assert all(p.requires_grad for p in m.trgb_segnet.parameters())
     assert not any(p.requires_grad for p in m.critics.parameters())
     with pytest.raises(NotImplementedError):
-        conv_segnet(pretrained=False, arch="custom")
+        conv_segnet(pretrained=False, arch="custom")  # (the default disc_arch 'resnet': critics the reference cannot train)
+    # the reference's default arch: ResNeXt-50 + ASPP, same state_dict keys as the oracle pinned to the reference's module
+    from models.confusion_maximization.models import trgb_segnet
+    from oracle import resnext_ref
+    assert callable(trgb_segnet.net_resnext50) and callable(trgb_segnet.net_resnext101) and callable(trgb_segnet.net_resnext152)
+    c = conv_segnet(pretrained=False, disc_arch="cyclegan", num_critics=6, arch="custom", late_fusion=True)
+    ref_keys = set(resnext_ref.RefResNeXt(late_fusion=True).state_dict())
+    assert set(c.trgb_segnet.state_dict()) == ref_keys
     r = np.random.RandomState(0)
     pred, tgt = r.randint(0, 13, (2, 30, 40)), r.randint(0, 14, (2, 30, 40))
     np.testing.assert_array_equal(calculate_ious(torch.from_numpy(pred), torch.from_numpy(tgt)),
