@@ -84,6 +84,10 @@ def build(workload, dev):
     if workload in ("seg", "seg_bf16"):
         model = PSPNet(backend="resnet50", pretrained=False, late_fusion=True, in_channels=4)
         model.apply(weights_init_normal)
+    elif workload == "seg_resnext":
+        from heatnet_amd.trgb_segnet import net_resnext50
+        model = net_resnext50(classes=13, input_channels=4, late_fusion=True)
+        model.apply(weights_init_normal)
     else:
         model = conf_segnet.conv_segnet(pretrained=False, disc_arch="cyclegan", num_critics=6, arch="pspnet",
                                         late_fusion=True)
@@ -93,7 +97,7 @@ def build(workload, dev):
 
 def make_step(workload, model, opt, batch, buckets):
     from heatnet_amd import train_step
-    if workload in ("seg", "seg_bf16"):
+    if workload in ("seg", "seg_bf16", "seg_resnext"):
         return lambda: train_step.segmentation_step(model, opt, batch["rgb_day"], batch["ir_day"], batch["label_day"],
                                                     grad_sync=buckets)
     state = "train_seg" if workload == "confmax_seg" else "train_critic"
@@ -145,7 +149,7 @@ def measure_conv_roofline(step_fn, steps, workload, scale=1.0, geom=(BS, H, W)):
                   "ms_per_step": v[2] / steps, "avg_launch_us": 1e3 * v[2] / v[0], "tflops": v[1] / v[2] / 1e9}
               for k, v in per_kind.items()}
     achieved = flops / ms / 1e9 if ms > 0 else 0.0
-    ref_tflop = REFERENCE_CONV_TFLOP.get(workload) * scale if abs(scale - round(scale)) < 1e-9 else None
+    ref_tflop = REFERENCE_CONV_TFLOP[workload] * scale if (workload in REFERENCE_CONV_TFLOP and abs(scale - round(scale)) < 1e-9) else None
     math = ops.CONV_MATH
     peak = round(PEAK_TFLOPS[math], 1)
     traffic_all, traffic_per_kernel, traffic_source = pmc_traffic(math, workload, *geom)
@@ -290,7 +294,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="seg", choices=["seg", "seg_bf16", "confmax_seg", "confmax_critic"])
+    ap.add_argument("--workload", default="seg", choices=["seg", "seg_bf16", "confmax_seg", "confmax_critic", "seg_resnext"])
     ap.add_argument("--height", type=int, default=H, help="input height (default: the BASELINE metric's 320)")
     ap.add_argument("--width", type=int, default=W, help="input width (default 704)")
     ap.add_argument("--batch", type=int, default=BS, help="images per GPU (default 8)")
@@ -467,7 +471,7 @@ def main():
             del s2, o2, a2, m2
             torch.cuda.empty_cache()
     base = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "seg_resnext":
         base = cpu_baseline(args.workload)
 
     if rank == 0:
@@ -475,7 +479,9 @@ def main():
                         "backward + RMSprop",
                  "seg_bf16": "configs[4] (one GPU's share): the configs[1] step with the mixed-precision bf16 conv MFMA path",
                  "confmax_seg": "configs[2]: confusion-maximisation train_seg iteration (day+night passes, 6 critics)",
-                 "confmax_critic": "configs[2]: confusion-maximisation train_critic iteration (day+night passes, 6 critics)"}
+                 "confmax_critic": "configs[2]: confusion-maximisation train_critic iteration (day+night passes, 6 critics)",
+                 "seg_resnext": "optional branch (SURVEY 8f N4): the configs[1] step on the reference's arch='custom' network "
+                                "(ResNeXt-50, 64 groups, + ASPP, late fusion); no CPU baseline"}
         out = {"metric": "training images/s at %dx%d RGB+IR, bs=%d/GPU" % (args.height, args.width, args.batch), "value": round(world * args.batch * args.steps / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",

@@ -1,9 +1,9 @@
 """Segmentation network + domain critics wrapper (the object the HeatNet trainer drives).
 
-models/confusion_maximization/models/conf_segnet.py:22-140 for arch='pspnet', disc_arch='cyclegan', with the
-`feedback_seg` branch (DownNets appended to the critic inputs, :61-70,121-125).  The remaining optional branches of the
-reference (ResNeXt 'custom' arch, ResNet critics, input adapter, cert branch) are outside the hot path (SURVEY.md
-section 2) and raise NotImplementedError.
+models/confusion_maximization/models/conf_segnet.py:22-140 for arch='pspnet' and arch='custom' (ResNeXt-50 + ASPP,
+trgb_segnet.py), disc_arch='cyclegan', with the `feedback_seg` branch (DownNets appended to the critic inputs,
+:61-70,121-125).  The remaining optional branches of the reference (ResNet critics, input adapter, cert branch) are not
+working configurations of its training loop and raise NotImplementedError.
 """
 import torch
 import torch.nn as nn

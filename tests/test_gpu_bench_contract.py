@@ -49,7 +49,7 @@ def test_bench_self_launches_its_workers():
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(HN_BENCH_SHARE_GPU="1", HN_BENCH_BACKEND="gloo")
+    env.update(HN_BENCH_SHARE_GPU="1", HN_BENCH_BACKEND="gloo", HEATNET_AUTOTUNE="0")  # (no per-shape candidate timing: launch logic is the subject)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                           "--batch", "1", "--height", "256", "--width", "256", "--workload", "confmax_seg"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)

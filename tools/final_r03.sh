@@ -23,8 +23,10 @@ if [ "$part" = "a" ]; then
   HN_CONV_TABLE="$out/conv_table_f16x2.txt" python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt --no-other-workloads > /dev/null 2>> "$out/warm.err"
   step "kernel stats seg"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_seg" -- python3 bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-alt --no-other-workloads > "$out/stats_seg.json" 2> "$out/stats_seg.err"
-  step "kernel stats confmax"
-  for wl in confmax_seg confmax_critic; do
+  step "resnext"
+  python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt --no-other-workloads --workload seg_resnext > "$out/bench_seg_resnext.json" 2>> "$out/warm.err"
+  step "kernel stats confmax / bf16 / resnext"
+  for wl in confmax_seg confmax_critic seg_bf16 seg_resnext; do
     rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_$wl" -- python3 bench.py --steps 6 --warmup 2 --workload $wl --no-cpu-baseline --no-alt --no-other-workloads --no-roofline > "$out/stats_$wl.json" 2> "$out/stats_$wl.err"
   done
   step "smoke"
