@@ -644,10 +644,12 @@ void plan_name(const ConvPlan& pl, char* buf, int n) {
 // Split-K plan: K steps (of 32) per split, or 0.  Used when the output has so few tiles that the chip would idle
 // (pyramid levels, critic tails: a few hundred pixels) while the reduction is long.
 int plan_split_k(int M, int K, int Kdim) {
-    if (M > 2048) return 0;
     const int total = (Kdim + 31) / 32;
     if (total < 8) return 0;
     const int tiles = ((M + 63) / 64) * ((K + (K > 64 ? 127 : 63)) / (K > 64 ? 128 : 64));
+    // more rows only when the tiles still leave most of the chip idle under a very long reduction: the critics' first
+    // convolutions (4x4 stride 2 over 1024 / 2048-channel features: 110 tiles, 512 / 1024 K steps ran at 43 TFLOP/s unsplit)
+    if (M > 2048 && !(tiles <= 192 && total >= 128)) return 0;
     int splits = 512 / tiles;
     if (splits > total / 4) splits = total / 4;
     if (splits < 2) return 0;
