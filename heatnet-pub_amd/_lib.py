@@ -23,6 +23,16 @@ class HnConvDesc(ctypes.Structure):
 DP = ctypes.POINTER(HnConvDesc)
 
 
+HN_ESHAPE = -4  # include/heatnet_hip.h
+
+
+class HnBnReduceArgs(ctypes.Structure):
+    """include/heatnet_hip.h: the BatchNorm-backward reduction that rides in a data-gradient epilogue."""
+    _fields_ = [("y", ctypes.c_void_p), ("ldy", ctypes.c_int32), ("y_bf16", ctypes.c_int32), ("act", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("mean", ctypes.c_void_p),
+                ("invstd", ctypes.c_void_p), ("relu_bits", ctypes.c_void_p), ("sums", ctypes.c_void_p), ("du_max", ctypes.c_void_p)]
+
+
 class HnWeightPrepItem(ctypes.Structure):
     _fields_ = [("w", ctypes.c_void_p), ("w_x3", ctypes.c_void_p), ("wt", ctypes.c_void_p), ("wt_x3", ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ("Cout", "KH", "KW", "Cin", "stride", "pad", "dil", "format")]
@@ -73,6 +83,8 @@ SIGNATURES = {
     "hn_conv2d_fwd_planes": [P, c_i64, P, P, P, P, P, P, DP, c_int, c_float, c_int, P],
     "hn_conv2d_fwd_scaled_range": [P, P, P, P, P, P, P, P, DP, c_int, P],
     "hn_conv2d_dgrad_planes": [P, c_i64, P, P, P, P, c_int, DP, c_int, P],
+    "hn_conv2d_dgrad_planes_bnreduce": [P, c_i64, P, P, P, P, c_int, DP, c_int, ctypes.POINTER(HnBnReduceArgs), P],
+    "hn_bn_act_bwd_finish": [P, P, c_int, P, P, P, c_int, P, P, P, P, c_i64, c_int, P, P],
     "hn_conv2d_wgrad_planes": [P, c_i64, P, P, c_i64, P, P, DP, c_int, c_int, c_int, P],
     "hn_conv2d_wgrad_det_planes": [P, c_i64, P, P, c_i64, P, P, DP, c_int, c_int, c_int, P, P],
     "hn_bn_finalize_range": [P, P, c_i64, P, P, P, P, c_float, c_float, P, P, P, P, P, c_int, c_int, P, c_float, P, c_float, P, P],

@@ -59,6 +59,19 @@ struct ConvArgs {
     // one-plane bf16 arithmetic, forward with BatchNorm statistics: y holds bf16 elements (ldy counts elements) -- the
     // statistics still come from the fp32 accumulators.  Honoured by the conv_igemm4 one-plane kernels only.
     int y_bf16 = 0;
+    // data gradient of the convolution BEHIND a BatchNorm + ReLU (conv_igemm4 kernels, dense stride-1 launches): this launch's
+    // output IS that layer's dz, so its epilogue also takes the first pass of the BatchNorm backward over the tile it holds
+    // -- du = dz * (u > 0), sums[0:K] += sum du, sums[K:2K] += sum du * xhat, du_max = max |du| per channel -- reading the
+    // layer's pre-normalisation tensor y instead of a stand-alone pass reading dz and y (hn_bn_act_bwd_reduce).  NULL: off.
+    const void* br_y = nullptr;          // [pixels][br_ldy] fp32, or bf16 elements when br_ybf
+    int br_ldy = 0, br_ybf = 0, br_relu = 0;
+    const float* br_scale = nullptr;     // u = y * scale + shift (ReLU mask when there are no byte masks)
+    const float* br_shift = nullptr;
+    const float* br_mean = nullptr;      // xhat = (y - mean) * invstd
+    const float* br_invstd = nullptr;
+    const unsigned char* br_bits = nullptr;  // the forward's byte ReLU masks (a residual was added in front of the ReLU)
+    double* br_sums = nullptr;           // [HN_STAT_REPLICAS][2K + 1]
+    unsigned* br_gmax = nullptr;         // [HN_STAT_REPLICAS][K] or NULL
 };
 
 // bf16x3 LDS image: [split][row][32 k] bf16 with 80-byte rows (64 B of data + 16 B pad: 16 consecutive rows start in
@@ -168,7 +181,7 @@ __device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[T
 // in front of every store.
 // `oscale`, `oscale2` (f16x2: the inverse operand scales, powers of two, applied one after the other -- see conv_init_acc)
 // take the accumulators back to the tensor's own scale first.
-template <int TM, int TN, bool S16, int BM = 64 * TM, int BN = 64 * TN, bool SCALED = false, bool YB = false>
+template <int TM, int TN, bool S16, int BM = 64 * TM, int BN = 64 * TN, bool SCALED = false, bool YB = false, bool BR = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], const AccMap<TM, TN, S16>& am,
                                               const int* rowinfo, int m0, int tile_m, int split, float oscale = 1.f,
                                               float oscale2 = 1.f) {
@@ -212,6 +225,86 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] += bias_v[j][am.c2_of(r)];
 
+    if constexpr (BR) {
+        if (p.br_y != nullptr) {  // (ConvArgs::br_y) before the stores: its loads would otherwise queue behind them
+            // Loads are UNCONDITIONAL (clamped indices) and issued as a batch per column, the arithmetic follows: a load under a
+            // condition makes hipcc drain the memory queue in front of every one of them (see the store loop below).
+            auto reduce = [&](auto ybf_tag, auto bits_tag) {
+                constexpr bool YBF = decltype(ybf_tag)::value, BITS = decltype(bits_tag)::value;
+                constexpr int NR = 16 / NC;  // rows of one column a lane holds per 32 x 32 block
+                const int kq = p.K >> 2;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int c2 = 0; c2 < NC; ++c2) {
+                        const int col = am.col(j, c2);
+                        const bool cok = col < p.K;
+                        const int cc = cok ? col : p.K - 1;
+                        const float sc = p.br_scale[cc], sh = p.br_shift[cc], mu = p.br_mean[cc], is = p.br_invstd[cc];
+                        float yv[TM][NR];
+                        unsigned bb[TM][NR];
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            int q = 0;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                if (am.c2_of(r) != c2) continue;
+                                const int row = min(m0 + am.row(i, r), p.M - 1);
+                                const size_t at = (size_t)row * p.br_ldy + cc;
+                                if constexpr (YBF) yv[i][q] = (float)reinterpret_cast<const __bf16*>(p.br_y)[at];
+                                else yv[i][q] = reinterpret_cast<const float*>(p.br_y)[at];
+                                if constexpr (BITS) bb[i][q] = p.br_bits[(size_t)row * kq + (cc >> 2)];
+                                else bb[i][q] = 0u;
+                                ++q;
+                            }
+                        }
+                        float b1 = 0.f, b2 = 0.f;
+                        unsigned bm = 0u;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            int q = 0;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                if (am.c2_of(r) != c2) continue;
+                                const bool in = (m0 + am.row(i, r) < p.M) && cok;
+                                bool on;
+                                if constexpr (BITS) on = (bb[i][q] >> (cc & 3)) & 1u;
+                                else on = !p.br_relu || yv[i][q] * sc + sh > 0.f;
+                                const float du = (in && on) ? acc[i][j][r] : 0.f;
+                                b1 += du;
+                                b2 += du * ((yv[i][q] - mu) * is);
+                                bm = max(bm, __float_as_uint(du) & 0x7fffffffu);
+                                ++q;
+                            }
+                        }
+                        double d1 = (double)b1, d2 = (double)b2;
+                        d1 += __shfl_xor(d1, 32);
+                        d2 += __shfl_xor(d2, 32);
+                        bm = max(bm, (unsigned)__shfl_xor((int)bm, 32));
+                        if constexpr (S16) {
+                            d1 += __shfl_xor(d1, 16);
+                            d2 += __shfl_xor(d2, 16);
+                            bm = max(bm, (unsigned)__shfl_xor((int)bm, 16));
+                        }
+                        if ((S16 ? (lane >> 4) : (lane >> 5)) == 0 && cok) {
+                            const int rep_i = tile_m % HN_STAT_REPLICAS;
+                            double* rep = p.br_sums + (size_t)rep_i * (2 * p.K + 1);
+                            unsafeAtomicAdd(rep + col, d1);
+                            unsafeAtomicAdd(rep + p.K + col, d2);
+                            if (p.br_gmax != nullptr && bm != 0u) atomicMax(p.br_gmax + (size_t)rep_i * p.K + col, bm);
+                        }
+                    }
+                }
+            };
+            if (p.br_ybf) {
+                if (p.br_bits != nullptr) reduce(std::true_type{}, std::true_type{});
+                else reduce(std::true_type{}, std::false_type{});
+            } else {
+                if (p.br_bits != nullptr) reduce(std::false_type{}, std::true_type{});
+                else reduce(std::false_type{}, std::false_type{});
+            }
+        }
+    }
     // branch-free activation: out = v > 0 ? v : v * neg_slope  (none: 1, relu: 0, leaky/prelu: slope)
     const float neg_slope = p.act == HN_ACT_NONE ? 1.f : (p.act == HN_ACT_RELU ? 0.f : p.slope);
     auto finish = [&](auto full_tag, auto map_tag) {

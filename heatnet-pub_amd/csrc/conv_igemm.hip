@@ -1116,8 +1116,15 @@ int init_output(float* dx, int ldx, const float* addend, int ldadd, int64_t npix
 namespace {
 int conv2d_dgrad_impl(const float* dy, const float* dy_scale, const float* wt, const void* wt_x3, float* dx, const float* addend,
                       int ldadd, const HnConvDesc* d, int variant, void* stream, const void* dyh = nullptr,
-                      long long dyh_plane = 0) {
+                      long long dyh_plane = 0, const HnBnReduceArgs* br = nullptr) {
     if ((dy == nullptr && dyh == nullptr) || (wt == nullptr && dyh == nullptr) || dx == nullptr) return HN_EINVAL;
+    if (br != nullptr) {
+        // the BatchNorm-backward reduction rides in the epilogue of the dense stride-1 plane-tensor launch only
+        if (dyh == nullptr || d == nullptr || d->stride != 1 || d->ldx != d->Cin) return HN_ESHAPE;
+        if (!br->y || !br->scale || !br->shift || !br->mean || !br->invstd || !br->sums || br->ldy < d->Cin) return HN_EINVAL;
+        if (br->act != HN_ACT_NONE && br->act != HN_ACT_RELU) return HN_EINVAL;
+        if (br->relu_bits != nullptr && (d->Cin % 4 != 0 || br->act != HN_ACT_RELU)) return HN_EINVAL;
+    }
     if (dyh != nullptr && (wt_x3 == nullptr || dyh_plane <= 0)) return HN_EINVAL;
     if (dyh != nullptr && dy_scale == nullptr) variant = (variant & 63) | (3 << 6);  // one bf16 plane
     if (dy_scale != nullptr) {
@@ -1163,6 +1170,11 @@ int conv2d_dgrad_impl(const float* dy, const float* dy_scale, const float* wt, c
         a.Kdim = d->KH * d->KW * d->Cout;
         a.omap = 0; a.oH = a.oW = a.oph = a.opw = 0; a.ostep = 1;
         a.cps = (d->ldx == d->Cin && d->stride == 1 && !g_deterministic && !planes_in) ? plan_split_k(a.M, a.K, a.Kdim) : 0;
+        if (br != nullptr) {
+            a.br_y = br->y; a.br_ldy = br->ldy; a.br_ybf = br->y_bf16 ? 1 : 0; a.br_relu = br->act == HN_ACT_RELU ? 1 : 0;
+            a.br_scale = br->scale; a.br_shift = br->shift; a.br_mean = br->mean; a.br_invstd = br->invstd;
+            a.br_bits = br->relu_bits; a.br_sums = br->sums; a.br_gmax = br->du_max;
+        }
         if (a.cps > 0) {  // split-K partials add into dX, which therefore starts as the addend (or zero)
             const int rci = init_output(dx, d->ldx, addend, ldadd, (int64_t)a.M, d->Cin, stream);
             if (rci != HN_OK) return rci;
@@ -1237,6 +1249,13 @@ extern "C" int hn_conv2d_dgrad_planes(const void* dy_planes, int64_t plane_elems
                                       void* stream) {
     if (dy_planes == nullptr || wt_h2 == nullptr) return HN_EINVAL;
     return conv2d_dgrad_impl(nullptr, dy_scale, nullptr, wt_h2, dx, addend, ldadd, d, variant, stream, dy_planes, plane_elems);
+}
+
+extern "C" int hn_conv2d_dgrad_planes_bnreduce(const void* dy_planes, int64_t plane_elems, const float* dy_scale, const void* wt_h2,
+                                               float* dx, const float* addend, int ldadd, const HnConvDesc* d, int variant,
+                                               const HnBnReduceArgs* bn, void* stream) {
+    if (dy_planes == nullptr || wt_h2 == nullptr || bn == nullptr) return HN_EINVAL;
+    return conv2d_dgrad_impl(nullptr, dy_scale, nullptr, wt_h2, dx, addend, ldadd, d, variant, stream, dy_planes, plane_elems, bn);
 }
 
 extern "C" int hn_absmax_scale(const float* x, int ld, int64_t npix, int C, float* scale, void* stream) {

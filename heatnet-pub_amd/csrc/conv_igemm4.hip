@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last, out-of-range DMAs)
 
-    conv_epilogue<TM, TN, true, BM, BN, NPL == 2, NPL == 1>(p, acc, am, rowinfo, m0, tile_m, 0, o_s, o_s2);
+    conv_epilogue<TM, TN, true, BM, BN, NPL == 2, NPL == 1, true>(p, acc, am, rowinfo, m0, tile_m, 0, o_s, o_s2);
 }
 
 template <int WM, int WN, int TM, int TN, int NST, int NPL = 2>

@@ -1039,6 +1039,24 @@ extern "C" int hn_bn_act_bwd_reduce_range(const float* dz, int lddz, const float
                               training ? (float)(1.0 / (double)count) : 0.f, dy_slot);
 }
 
+extern "C" int hn_bn_act_bwd_finish(double* sums, float* dparams, int C, float* dgamma_out, float* dbeta_out, float* dslope_out,
+                                    int out_accumulate, uint32_t* du_max, const float* gamma, const float* invstd,
+                                    const float* xhat_max, int64_t count, int training, float* dy_slot, void* stream) {
+    if (!sums || !dparams || C <= 0) return HN_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (du_max != nullptr) {
+        if (!gamma || !invstd || !xhat_max || !dy_slot || count <= 0) return HN_EINVAL;
+        const float inv_count = training ? (float)(1.0 / (double)count) : 0.f;
+        HN_LAUNCH(bn_bwd_finish_range_kernel, dim3((C + 1 + 15) / 16), dim3(256), 0, s, sums, dparams, 2 * C + 1, C, dgamma_out,
+                  dbeta_out, dslope_out, out_accumulate, du_max, gamma, invstd, xhat_max, inv_count, dy_slot);
+    } else {
+        HN_LAUNCH(f64_to_f32_reset_kernel, dim3((2 * C + 1 + 255) / 256), dim3(256), 0, s, sums, dparams, 2 * C + 1, C, dgamma_out,
+                  dbeta_out, dslope_out, out_accumulate);
+    }
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
 namespace {
 int bn_bwd_apply_impl(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                                    const float* mean, const float* invstd, const float* gamma, const float* scale,

@@ -1201,10 +1201,18 @@ class BnWorkspace:
         # host-side guards: set while an accumulator may hold partial sums (between the kernel that adds into it and the
         # kernel that consumes + re-zeroes it); if an exception interrupts that window, the next user clears it first
         self.stats_open = self.bwd_open = False
+        # the _BnLink whose consumer filled `bwd` / `gmax` from its data-gradient epilogue (between that launch and the layer's
+        # own backward); a forward never sees one unless a backward was interrupted
+        self.fused_owner = None
 
     def open_stats(self):
         if self.stats_open:
             self.stats.zero_()
+        if self.fused_owner is not None:
+            self.fused_owner = None
+            self.bwd.zero_()
+            self.gmax.zero_()
+            self.bwd_open = False
         self.stats_open = True
 
     def open_bwd(self):
@@ -1353,6 +1361,24 @@ def fused_conv_bn_ok(x, conv_w, stride, pad, dil, bn_training, shape=None):
     return n * h * w * cin * 2 < 0xFFFF0000 and n * ho * wo * cout * 2 < 0xFFFF0000 - 64 * cout * 2
 
 
+BN_REDUCE_FUSION = os.environ.get("HEATNET_BN_REDUCE_FUSION", "1") != "0"  # A/B knob, see _BnLink
+bn_reduce_counts = {"fused": 0, "discarded": 0, "standalone": 0}  # per process: how the BatchNorm backward reductions ran
+
+
+class _BnLink:
+    """Rides on the output of a fused conv -> BatchNorm (-> ReLU) node to the fused node that consumes it: the consumer's
+    data-gradient launch produces exactly this layer's dz, so its epilogue takes the first pass of this layer's BatchNorm
+    backward along (hn_conv2d_dgrad_planes_bnreduce) and the stand-alone reduction pass over dz and y is not run.  The
+    producer's backward accepts the sums only if the gradient it receives IS the buffer that launch wrote (autograd hands a
+    sole consumer's gradient through untouched; a sum of several is a new tensor) -- otherwise it clears them and reduces
+    itself."""
+    __slots__ = ("y", "ybf", "par", "rbits", "ws", "act", "cout", "npix", "fused_ptr")
+
+    def __init__(self, y, ybf, par, rbits, ws, act, cout, npix):
+        self.y, self.ybf, self.par, self.rbits, self.ws, self.act, self.cout, self.npix = y, ybf, par, rbits, ws, act, cout, npix
+        self.fused_ptr = None
+
+
 class _ConvBnAct(torch.autograd.Function):
     """z = act(bn(conv(x, w) + b) [+ residual]) [* drop_mask] as ONE autograd node; x (and the residual) may be plane tensors,
     z is written as fp32, as a plane tensor, or both; the gradient dy between the BatchNorm backward and the convolution's
@@ -1369,6 +1395,9 @@ class _ConvBnAct(torch.autograd.Function):
         n, cin, h, wd = xp.shape
         w_in, w = w, weight_ohwi(w)
         cout, _, kh, kw = w.shape
+        in_link = getattr(x, "_hn_bn_link", None)
+        ctx.in_link = in_link if (BN_REDUCE_FUSION and in_link is not None and stride == 1 and ctx.needs_input_grad[0]
+                                  and in_link.cout == cin and in_link.npix == n * h * wd) else None
         ho, wo = conv_out_size(h, kh, stride, pad, dil), conv_out_size(wd, kw, stride, pad, dil)
         npix = n * ho * wo
         dev = xp.device
@@ -1447,6 +1476,12 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.save_for_backward(xp, w, y, par, gamma, prelu_w, rbits, keep_z)
         out = zf if zf is not None else zp
         _last_fused["slot"], _last_fused["twin"] = (BF16_PLANE if bf16 else z_slot), (zp if zf is not None else None)
+        # what a consuming fused node needs to take this layer's backward reduction into its data-gradient epilogue
+        ctx.link = None
+        if (BN_REDUCE_FUSION and act in (ACT_RELU, ACT_NONE) and drop_mask is None and cout % 4 == 0 and any(ctx.needs_input_grad)
+                and (residual is None or rbits is not None) and keep_z is None):
+            ctx.link = _BnLink(y, bool(ybf), par, rbits, ws, act, cout, npix)
+        _last_fused["link"] = ctx.link
         if passthrough:
             return out, x.view_as(x)
         return out
@@ -1466,7 +1501,22 @@ class _ConvBnAct(torch.autograd.Function):
         dz, lddz = as_nhwc(dz)
         mean, invstd, scale, shift, xhat = (par[i * cout:(i + 1) * cout] for i in range(5))
         ws = ctx.ws
-        ws.open_bwd()
+        link = ctx.link
+        fused_reduce = False
+        if link is not None and link.fused_ptr is not None:
+            # the consumer's data-gradient epilogue already summed du / du * xhat of THIS dz (see _BnLink)?
+            fused_reduce = ws.fused_owner is link and link.fused_ptr == dz.data_ptr() and lddz == cout
+            if ws.fused_owner is link:
+                ws.fused_owner = None
+                if not fused_reduce:  # they belong to a partial gradient: start over
+                    ws.bwd.zero_()
+                    ws.gmax.zero_()
+                    ws.bwd_open = False
+                    bn_reduce_counts["discarded"] += 1
+            link.fused_ptr = None
+        bn_reduce_counts["fused" if fused_reduce else "standalone"] += 1
+        if not fused_reduce:
+            ws.open_bwd()
         lw, lbias, lg, lb, lp = ctx.leaves
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         # ---- BatchNorm backward: reductions (+ the bound of |dy|), then dy as a plane tensor ----
@@ -1480,7 +1530,12 @@ class _ConvBnAct(torch.autograd.Function):
             used = []
         accumulate = bool(used) and not used[0][1]
         bf16 = ctx.bf16
-        if bf16:
+        if fused_reduce:
+            dy_slot = None if bf16 else _new_scale_slot(dev)
+            check(lib.hn_bn_act_bwd_finish(_ptr(ws.bwd), _ptr(dpar), cout, _ptr(sg[0]) if sg else None, _ptr(sb[0]) if sb else None,
+                                           None, int(accumulate), None if bf16 else _ptr(ws.gmax), _ptr(gamma), _ptr(invstd),
+                                           _ptr(xhat), npix, 1, _ptr(dy_slot), s), "hn_bn_act_bwd_finish")
+        elif bf16:
             dy_slot = None
             check(lib.hn_bn_act_bwd_reduce(_ptr(dz), lddz, _ptr(z), cout, _ptr(y), cout, _ptr(mean), _ptr(invstd), _ptr(scale),
                                            _ptr(shift), npix, cout, act | ctx.ybf, _ptr(prelu_w), leaky, _ptr(ws.bwd), _ptr(dpar),
@@ -1523,12 +1578,26 @@ class _ConvBnAct(torch.autograd.Function):
             dx = new_nhwc(n, cin, h, wd, dev)
             add, ldadd = (None, 0) if dskip is None else as_nhwc(dskip)
 
-            def launch(v, ad, ld):
+            def launch(v, ad, ld, bn=None):
+                if bn is not None:
+                    rc = lib.hn_conv2d_dgrad_planes_bnreduce(_ptr(dyp), npix * cout, _ptr(dy_slot), _ptr(ctx.wth), _ptr(dx), _ptr(ad),
+                                                             ld, ctypes.byref(d), v, ctypes.byref(bn), s)
+                    if rc != _lib.HN_ESHAPE:
+                        check(rc, "hn_conv2d_dgrad_planes_bnreduce")
+                        return True
                 check(lib.hn_conv2d_dgrad_planes(_ptr(dyp), npix * cout, _ptr(dy_slot), _ptr(ctx.wth), _ptr(dx), _ptr(ad), ld,
                                                  ctypes.byref(d), v, s), "hn_conv2d_dgrad_planes")
+                return False
             var = _pick("dgrad" + tag, d, _plane_variants(cin, cout, kh * kw), lambda v: launch(v, None, 0))
+            # dx is the dz of the BatchNorm layer that produced this node's input: its backward reduction rides along
+            il, bn_args = ctx.in_link, None
+            if il is not None and il.ws.fused_owner is None and not il.ws.bwd_open and il.y.data_ptr() != 0:
+                lmean, linvstd, lscale, lshift = (il.par[i * cin:(i + 1) * cin] for i in range(4))
+                bn_args = _lib.HnBnReduceArgs(_ptr(il.y), cin, int(il.ybf), il.act, 0, _ptr(lscale), _ptr(lshift), _ptr(lmean),
+                                              _ptr(linvstd), _ptr(il.rbits), _ptr(il.ws.bwd), None if bf16 else _ptr(il.ws.gmax))
             with _ConvTimer("dgrad", d, lambda: _plan_name(1, d, 3, _variant(var & 3, var >> 2, 0, mcode))):
-                launch(var, add, ldadd)
+                if launch(var, add, ldadd, bn_args):
+                    il.ws.fused_owner, il.ws.bwd_open, il.fused_ptr = il, True, dx.data_ptr()
         elif dskip is not None:
             dx = dskip
         # ---- weight gradient ----
@@ -1594,6 +1663,9 @@ def conv_bn_act_fused(x, w, b, gamma, beta, running_mean, running_var, residual,
     out = _ConvBnAct.apply(x, w, b, gamma, beta, running_mean, running_var, residual, prelu_w, cfg)
     z, skip = out if passthrough else (out, None)
     slot, twin = _last_fused.pop("slot"), _last_fused.pop("twin")
+    link = _last_fused.pop("link", None)
+    if link is not None:
+        z._hn_bn_link = link  # (NOT handed to the pass-through alias: one consumer takes the reduction)
     if out_mode == "planes":
         z._hn_planes = slot
     else:

@@ -229,6 +229,27 @@ int hn_conv2d_fwd_scaled_range(const float* x, const float* x_scale, const float
 /* d->ldy = pixel stride of the dY planes */
 int hn_conv2d_dgrad_planes(const void* dy_planes, int64_t plane_elems, const float* dy_scale, const void* wt_h2, float* dx,
                            const float* addend, int ldadd, const HnConvDesc* d, int variant, void* stream);
+/* hn_conv2d_dgrad_planes whose output dx IS the gradient dz of a BatchNorm (+ ReLU) layer in front of this convolution: the
+ * epilogue also takes the FIRST pass of that layer's BatchNorm backward over the tile it holds (what hn_bn_act_bwd_reduce /
+ * hn_bn_act_bwd_reduce_range compute from dz and y in a pass of their own), reading the layer's pre-normalisation tensor y;
+ * follow with hn_bn_act_bwd_finish.  Dense stride-1 convolutions on plane tensors only (d->ldx == d->Cin; HN_ESHAPE
+ * otherwise: use the two stand-alone calls).  act: HN_ACT_NONE or HN_ACT_RELU (mask from relu_bits if given -- the
+ * forward's byte masks, Cin % 4 == 0 -- else from y * scale + shift > 0); no Dropout2d mask, no PReLU.
+ * cm/models/extractors.py:84-102 (conv -> bn -> relu chains of the bottlenecks). */
+typedef struct HnBnReduceArgs {
+    const void* y;            /* [pixels of dx][ldy] fp32, or bf16 elements when y_bf16 */
+    int32_t ldy, y_bf16, act, reserved;
+    const float* scale;       /* [Cin] of this convolution = channels of the BatchNorm layer */
+    const float* shift;
+    const float* mean;
+    const float* invstd;
+    const unsigned char* relu_bits;  /* optional */
+    double* sums;             /* [HN_STAT_REPLICAS][2 Cin + 1], zero on entry (as for hn_bn_act_bwd_reduce) */
+    uint32_t* du_max;         /* optional [HN_STAT_REPLICAS][Cin], zero on entry (as for hn_bn_act_bwd_reduce_range) */
+} HnBnReduceArgs;
+int hn_conv2d_dgrad_planes_bnreduce(const void* dy_planes, int64_t plane_elems, const float* dy_scale, const void* wt_h2,
+                                    float* dx, const float* addend, int ldadd, const HnConvDesc* d, int variant,
+                                    const HnBnReduceArgs* bn, void* stream);
 
 /* hn_bn_finalize that also consumes (and re-zeroes) the `range_keys` the producing convolution accumulated, publishes into
  * `z_slot` (zero on entry) the bound of |act(y*scale + shift [+ residual]) * mask| over the tensor -- exact when there is no
@@ -255,6 +276,12 @@ int hn_bn_act_bwd_reduce_range(const float* dz, int lddz, const float* z, int ld
                                float* dbeta_out, float* dslope_out, int out_accumulate, const float* mask, int64_t hw,
                                const unsigned char* relu_bits, uint32_t* du_max, const float* gamma, const float* xhat_max,
                                int64_t count, int training, float* dy_slot, void* stream);
+/* The closing kernel of hn_bn_act_bwd_reduce / _reduce_range on its own: sums (consumed and re-zeroed) -> dparams and the
+ * optional gradient outputs; with du_max != NULL also the bound of |dy| into dy_slot (gamma, xhat_max, count, training as
+ * there).  For accumulators filled by hn_conv2d_dgrad_planes_bnreduce. */
+int hn_bn_act_bwd_finish(double* sums, float* dparams, int C, float* dgamma_out, float* dbeta_out, float* dslope_out,
+                         int out_accumulate, uint32_t* du_max, const float* gamma, const float* invstd, const float* xhat_max,
+                         int64_t count, int training, float* dy_slot, void* stream);
 /* hn_bn_act_bwd_apply writing dy as a plane tensor with the scale of dy_slot */
 int hn_bn_act_bwd_apply_planes(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* mean,
                                const float* invstd, const float* gamma, const float* scale, const float* shift,

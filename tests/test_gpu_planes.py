@@ -459,3 +459,64 @@ def test_conv_planes_bf16_bitwise(dev, case, tile):
         _lib.check(lib.hn_conv2d_wgrad_planes(P(xb), xb.numel(), None, P(gb), gb.numel(), None, P(dw1), ctypes.byref(d), 1, 2 * tile, 0, s),
                    "wgrad_planes")
         assert torch.equal(dw0, dw1)
+
+
+@pytest.mark.parametrize("math", ["f16x2", "bf16"])
+def test_bn_backward_reduction_in_dgrad_epilogue(dev, math):
+    """The first pass of a BatchNorm layer's backward (sum du, sum du * xhat, max |du|) taken by the data-gradient epilogue of
+    the convolution that consumes the layer's output (hn_conv2d_dgrad_planes_bnreduce, ops._BnLink) against the stand-alone
+    reduction pass (HEATNET_BN_REDUCE_FUSION off): a layer of three bottlenecks (conv1 / conv2 without, conv3 with a residual
+    and byte ReLU masks, a downsample branch in the first), every parameter gradient and the input gradient.  The two paths sum
+    the same du in a different order: fp32-noise agreement.  Then a tensor with TWO gradient contributions: the sums the
+    epilogue took of the partial gradient must be discarded."""
+    from heatnet_amd import ops, resnet
+    torch.manual_seed(11)
+
+    def run(fuse, two_consumers=False):
+        prev, ops.BN_REDUCE_FUSION = ops.BN_REDUCE_FUSION, fuse
+        for k_ in ops.bn_reduce_counts:
+            ops.bn_reduce_counts[k_] = 0
+        try:
+            net = resnet.ResNet(resnet.Bottleneck, (3, 1, 1, 1), dual=False)
+            layer = net.layer1.to(dev).train()
+            g = torch.Generator().manual_seed(3)
+            with torch.no_grad():
+                for p_ in layer.parameters():
+                    if p_.dim() == 4:
+                        p_.copy_((torch.randn(p_.shape, generator=g) / np.sqrt(p_[0].numel())).to(dev))
+                    else:
+                        p_.copy_((torch.rand(p_.shape, generator=g) + 0.5).to(dev))
+            x = F.relu(torch.randn(2, 64, 40, 48, generator=g)).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+            z = resnet.run_layer(layer, x * 1.0)
+            gz = (torch.randn(z.shape, generator=g) * 1e-2).to(dev).contiguous(memory_format=torch.channels_last)
+            if two_consumers:
+                # the first block's bn1 output feeds conv2 -- and, here, a second reader: its dz is a SUM autograd builds
+                blk = layer[0]
+                y1, xa = resnet._first_conv(blk, x * 1.0)
+                y2 = resnet.conv_bn_act(y1, blk.conv2, blk.bn2, ops.ACT_RELU, out="planes")
+                g64 = gz[:, :64]
+                ((ops.as_f32(y2) * g64).sum() + (ops.as_f32(y1) * g64).sum() + (ops.as_f32(xa) * 0).sum()).backward()
+            else:
+                z.backward(gz)
+            grads = {n_: p_.grad.detach().float().cpu() for n_, p_ in layer.named_parameters() if p_.grad is not None}
+            grads["x"] = x.grad.detach().float().cpu()
+            return grads, dict(ops.bn_reduce_counts)
+        finally:
+            ops.BN_REDUCE_FUSION = prev
+    prev_math = ops.set_conv_math(math)
+    try:
+        a, ca = run(True)
+        b, cb = run(False)
+        a2, ca2 = run(True, two_consumers=True)
+        b2, cb2 = run(False, two_consumers=True)
+    finally:
+        ops.set_conv_math(prev_math)
+    assert cb["fused"] == 0 and ca["fused"] >= 7, (ca, cb)  # 3 x (bn1, bn2) + bn3 of the first two blocks (+ nothing behind the last)
+    assert ca["discarded"] == 0
+    # (bf16: dy is STORED in bf16 -- a last-bit difference of the channel means moves roundings of dy, 2^-9 each)
+    tol = 1e-2 if math == "bf16" else 2e-5
+    for tag, got, ref in (("", a, b), ("two consumers", a2, b2)):
+        for key in ref:
+            err = float((got[key] - ref[key]).abs().max())
+            assert err <= tol * max(float(ref[key].abs().max()), 1e-30), (tag, key, err, float(ref[key].abs().max()))
+    assert ca2["discarded"] >= 1, ca2
