@@ -360,6 +360,8 @@ def main():
         dist.barrier()
         buckets.reset_exposed()
     torch.cuda.synchronize()
+    for k_ in ops.bn_reduce_counts:
+        ops.bn_reduce_counts[k_] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -368,6 +370,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # how the BatchNorm backward reductions of a step ran: in a data-gradient epilogue / as a pass of their own
+    bn_passes = {k_ + "_per_step": round(v_ / max(args.steps, 1), 2) for k_, v_ in ops.bn_reduce_counts.items()}
     comm = None
     if distributed:
         # per rank: time the compute stream idled waiting for gradient collectives (what backward did not hide)
@@ -486,7 +490,7 @@ def main():
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16" if ops.CONV_MATH == "bf16" else "f32", "arithmetic": ops.CONV_MATH,
-               "data": "synthetic", "distributed": comm,
+               "data": "synthetic", "distributed": comm, "bn_backward_reductions": bn_passes,
                "config": {"workload": names[args.workload], "global_batch": world * args.batch, "height": args.height,
                           "width": args.width,
                           "parallelism": "dp%d" % world, "optimizer": "RMSprop lr=1e-4 (fused, flat arena)", "weights": "random init",

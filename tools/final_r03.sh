@@ -31,6 +31,7 @@ if [ "$part" = "a" ]; then
   done
   step "smoke"
   python3 -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.txt" 2>&1; tail -2 "$out/smoke.txt"
+  python3 -c "import sys; sys.path.insert(0, \".\"); import bench" > /dev/null 2>&1
 else
   for ctr in FETCH_SIZE WRITE_SIZE; do
     step "pmc $ctr seg (f16x2)"
