@@ -1049,6 +1049,26 @@ class _Conv2d(torch.autograd.Function):
         return dx, dw_out, db, None, None, None, None, None, None, None, None
 
 
+PAD_CIN = os.environ.get("HEATNET_PAD_CIN", "1") != "0"  # A/B knob, see conv2d
+
+
+class _PadCin(torch.autograd.Function):
+    """w [Cout][KH][KW][Cin] -> [Cout][KH][KW][cin_p] with zero input channels appended (the slice comes back as gradient)."""
+
+    @staticmethod
+    def forward(ctx, w, cin_p):
+        w = weight_ohwi(w)
+        cout, cin, kh, kw = w.shape
+        wp = torch.zeros((cout, kh, kw, cin_p), device=w.device, dtype=torch.float32).permute(0, 3, 1, 2)
+        wp[:, :cin].copy_(w)
+        ctx.cin = cin
+        return wp
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.cin].contiguous(memory_format=torch.channels_last), None
+
+
 def conv2d(x, w, b=None, stride=1, pad=0, dil=1, act=ACT_NONE, slope=0.0, want_stats=False, passthrough=False,
            zero_bias_grad=False):
     """`want_stats`: False, True (fresh accumulator) or a zeroed float64 [STAT_REPLICAS*2*Cout] accumulator.
@@ -1058,6 +1078,16 @@ def conv2d(x, w, b=None, stride=1, pad=0, dil=1, act=ACT_NONE, slope=0.0, want_s
     instead of the rounding noise a full reduction pass over dy would produce."""
     if passthrough and want_stats is True:
         raise ValueError("conv2d: passthrough cannot be combined with want_stats=True")
+    cin = w.shape[1]
+    if PAD_CIN and x.is_cuda and cin >= 128 and cin % 32 != 0 and not passthrough and x.dim() == 4 and x.shape[1] == cin:
+        # A wide layer whose channel count is not a multiple of 32 (the 525-channel decoder of the ResNeXt branch,
+        # cm/models/trgb_segnet.py:201-209) would run on the scalar-gather fp32 kernels at a sixth of the rate: zero channels
+        # are appended to the input and to the weights (one copy of each), the result is the same sum.
+        cin_p = (cin + 31) // 32 * 32
+        n_, _, h_, w_ = x.shape
+        zeros = torch.zeros((n_, h_, w_, cin_p - cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
+        x = concat([x, zeros])
+        w = _PadCin.apply(w, cin_p)
     out = _Conv2d.apply(x, w, b, int(stride), int(pad), int(dil), int(act), float(slope), want_stats, bool(passthrough),
                         bool(zero_bias_grad))
     if passthrough:
@@ -1204,6 +1234,7 @@ class BnWorkspace:
         # the _BnLink whose consumer filled `bwd` / `gmax` from its data-gradient epilogue (between that launch and the layer's
         # own backward); a forward never sees one unless a backward was interrupted
         self.fused_owner = None
+        self.fuse_refused = False  # set once a fused reduction had to be discarded (the gradient was a sum of several)
 
     def open_stats(self):
         if self.stats_open:
@@ -1512,6 +1543,7 @@ class _ConvBnAct(torch.autograd.Function):
                     ws.bwd.zero_()
                     ws.gmax.zero_()
                     ws.bwd_open = False
+                    ws.fuse_refused = True  # this layer's output has several readers: do not try again
                     bn_reduce_counts["discarded"] += 1
             link.fused_ptr = None
         bn_reduce_counts["fused" if fused_reduce else "standalone"] += 1
@@ -1591,7 +1623,7 @@ class _ConvBnAct(torch.autograd.Function):
             var = _pick("dgrad" + tag, d, _plane_variants(cin, cout, kh * kw), lambda v: launch(v, None, 0))
             # dx is the dz of the BatchNorm layer that produced this node's input: its backward reduction rides along
             il, bn_args = ctx.in_link, None
-            if il is not None and il.ws.fused_owner is None and not il.ws.bwd_open and il.y.data_ptr() != 0:
+            if il is not None and il.ws.fused_owner is None and not il.ws.bwd_open and not il.ws.fuse_refused:
                 lmean, linvstd, lscale, lshift = (il.par[i * cin:(i + 1) * cin] for i in range(4))
                 bn_args = _lib.HnBnReduceArgs(_ptr(il.y), cin, int(il.ybf), il.act, 0, _ptr(lscale), _ptr(lshift), _ptr(lmean),
                                               _ptr(linvstd), _ptr(il.rbits), _ptr(il.ws.bwd), None if bf16 else _ptr(il.ws.gmax))

@@ -1,4 +1,5 @@
-"""Diagnostic (GPU box): host time to ENQUEUE one training step vs GPU time to run it."""
+"""How long the host takes to ENQUEUE one training step, against the step's wall time: python tools/host_time.py [workload]
+(the GPU runs behind the host; if the two numbers meet, the step is launch-bound and kernel work no longer decides it)."""
 import os
 import sys
 import time
@@ -11,32 +12,29 @@ import bench  # noqa: E402
 
 
 def main():
+    workload = sys.argv[1] if len(sys.argv) > 1 else "seg"
+    from heatnet_amd import ops, optim
+    if workload == "seg_bf16":
+        ops.set_conv_math("bf16")
     dev = torch.device("cuda:0")
-    from heatnet_amd import optim
-    model = bench.build("seg", dev)
+    model = bench.build(workload, dev)
     arenas = optim.arenas_for(model)
     opt = optim.FlatRMSprop(arenas, lr=1e-4)
     batch = bench.synthetic_batch(0, dev)
-    step = bench.make_step("seg", model, opt, batch, None)
+    step = bench.make_step(workload, model, opt, batch, None)
     for _ in range(4):
         step()
     torch.cuda.synchronize()
-    n = 8
-    t0 = time.perf_counter()
+    n, host = 20, 0.0
+    t_all = time.perf_counter()
     for _ in range(n):
-        step()
-    t_host = (time.perf_counter() - t0) / n
-    torch.cuda.synchronize()
-    t_all = (time.perf_counter() - t0) / n
-    print("host enqueue %.1f ms/step, wall %.1f ms/step (GPU-bound if host << wall)" % (1e3 * t_host, 1e3 * t_all))
-    # host-only cost: same loop while the GPU queue is empty at start of each step
-    ts = []
-    for _ in range(4):
-        torch.cuda.synchronize()
         t0 = time.perf_counter()
         step()
-        ts.append(time.perf_counter() - t0)
-    print("host enqueue from an idle queue: %.1f ms/step" % (1e3 * min(ts)))
+        host += time.perf_counter() - t0
+    t_enq = time.perf_counter() - t_all
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t_all
+    print("%s: host enqueue %.2f ms per step (loop %.2f), wall %.2f ms per step" % (workload, 1e3 * host / n, 1e3 * t_enq / n, 1e3 * wall / n))
 
 
 if __name__ == "__main__":
