@@ -33,8 +33,14 @@ import subprocess
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# The N > 1 path keeps four HIP streams busy per process (compute, weight gradients, gradient exchange, RCCL's own).  With
+# the runtime's default of four hardware queues the weight-gradient stream stopped overlapping the compute stream as soon as
+# the process group existed: 42.6 ms per step through the N > 1 path on one rank against 40.2 with eight queues (39.9 / 39.8
+# without a process group; profiles/r03_hw_queues.txt).  Read when the HIP runtime initialises: set before torch loads it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
