@@ -1052,21 +1052,53 @@ class _Conv2d(torch.autograd.Function):
 PAD_CIN = os.environ.get("HEATNET_PAD_CIN", "1") != "0"  # A/B knob, see conv2d
 
 
-class _PadCin(torch.autograd.Function):
-    """w [Cout][KH][KW][Cin] -> [Cout][KH][KW][cin_p] with zero input channels appended (the slice comes back as gradient)."""
+class _PadW(torch.autograd.Function):
+    """w [Cout][KH][KW][Cin] -> [cout_p][KH][KW][cin_p] with zero output / input channels appended (the corner block comes back
+    as gradient)."""
 
     @staticmethod
-    def forward(ctx, w, cin_p):
+    def forward(ctx, w, cout_p, cin_p):
         w = weight_ohwi(w)
         cout, cin, kh, kw = w.shape
-        wp = torch.zeros((cout, kh, kw, cin_p), device=w.device, dtype=torch.float32).permute(0, 3, 1, 2)
-        wp[:, :cin].copy_(w)
-        ctx.cin = cin
+        wp = torch.zeros((cout_p, kh, kw, cin_p), device=w.device, dtype=torch.float32).permute(0, 3, 1, 2)
+        wp[:cout, :cin].copy_(w)
+        ctx.shape = (cout, cin)
         return wp
 
     @staticmethod
     def backward(ctx, g):
-        return g[:, :ctx.cin].contiguous(memory_format=torch.channels_last), None
+        cout, cin = ctx.shape
+        return g[:cout, :cin].contiguous(memory_format=torch.channels_last), None, None
+
+
+class _PadVec(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, b, n_p):
+        out = torch.zeros(n_p, device=b.device, dtype=torch.float32)
+        out[:b.numel()].copy_(b)
+        ctx.n = b.numel()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:ctx.n].contiguous(), None
+
+
+class _NarrowChannels(torch.autograd.Function):
+    """y_p[:, :c] of an NHWC tensor (no copy); the gradient comes back zero-padded to the full width (one strided copy)."""
+
+    @staticmethod
+    def forward(ctx, y_p, c):
+        ctx.cp = y_p.shape[1]
+        return y_p.detach()[:, :c]
+
+    @staticmethod
+    def backward(ctx, g):
+        g, ldg = as_nhwc(g)
+        n, c, h, w = g.shape
+        gp = torch.zeros((n, h, w, ctx.cp), device=g.device, dtype=torch.float32).permute(0, 3, 1, 2)
+        check(_lib.load().hn_copy(_ptr(g), ldg, _ptr(gp), ctx.cp, n * h * w, c, _stream()), "hn_copy")
+        return gp, None
 
 
 def conv2d(x, w, b=None, stride=1, pad=0, dil=1, act=ACT_NONE, slope=0.0, want_stats=False, passthrough=False,
@@ -1078,16 +1110,35 @@ def conv2d(x, w, b=None, stride=1, pad=0, dil=1, act=ACT_NONE, slope=0.0, want_s
     instead of the rounding noise a full reduction pass over dy would produce."""
     if passthrough and want_stats is True:
         raise ValueError("conv2d: passthrough cannot be combined with want_stats=True")
-    cin = w.shape[1]
-    if PAD_CIN and x.is_cuda and cin >= 128 and cin % 32 != 0 and not passthrough and x.dim() == 4 and x.shape[1] == cin:
+    cout, cin = w.shape[0], w.shape[1]
+    pad_in = cin >= 128 and cin % 32 != 0
+    pad_out = cout >= 128 and cout % 32 != 0  # (the gathered operand of the data / weight gradient is dY)
+    if PAD_CIN and x.is_cuda and (pad_in or pad_out) and not passthrough and x.dim() == 4 and x.shape[1] == cin:
         # A wide layer whose channel count is not a multiple of 32 (the 525-channel decoder of the ResNeXt branch,
         # cm/models/trgb_segnet.py:201-209) would run on the scalar-gather fp32 kernels at a sixth of the rate: zero channels
-        # are appended to the input and to the weights (one copy of each), the result is the same sum.
-        cin_p = (cin + 31) // 32 * 32
-        n_, _, h_, w_ = x.shape
-        zeros = torch.zeros((n_, h_, w_, cin_p - cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
-        x = concat([x, zeros])
-        w = _PadCin.apply(w, cin_p)
+        # are appended to the input, to the weights (both ways) and to the bias -- one copy of each -- the convolution runs at
+        # the padded widths and the output is the narrow view of its result; the same sums.
+        # (to whole 64-channel blocks: the weight-gradient kernels' vector paths want them on both sides)
+        cin_p, cout_p = (cin + 63) // 64 * 64 if pad_in else cin, (cout + 63) // 64 * 64 if pad_out else cout
+        if cin_p != cin:
+            n_, _, h_, w_ = x.shape
+            zeros = torch.zeros((n_, h_, w_, cin_p - cin), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
+            x = concat([x, zeros])
+        w = _PadW.apply(w, cout_p, cin_p)
+        if cout_p == cout:
+            return conv2d(x, w, b, stride, pad, dil, act, slope, want_stats, False, zero_bias_grad)
+        bp = _PadVec.apply(b, cout_p) if b is not None else None
+        res = _Conv2d.apply(x, w, bp, int(stride), int(pad), int(dil), int(act), float(slope), bool(want_stats is not False), False,
+                            bool(zero_bias_grad))
+        y_p, st_p = res if want_stats is not False else (res, None)
+        y = _NarrowChannels.apply(y_p, cout)
+        if want_stats is False:
+            return y
+        st = st_p.view(STAT_REPLICAS, 2, cout_p)[:, :, :cout]
+        if want_stats is True:
+            return y, st.contiguous().view(-1)
+        want_stats.view(STAT_REPLICAS, 2, cout).add_(st)  # the caller's accumulator (zero on entry)
+        return y
     out = _Conv2d.apply(x, w, b, int(stride), int(pad), int(dil), int(act), float(slope), want_stats, bool(passthrough),
                         bool(zero_bias_grad))
     if passthrough:

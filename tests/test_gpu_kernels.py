@@ -53,7 +53,8 @@ CONV_CASES = [
     (2, 13, 32, 32, 64, 4, 2, 1, 1, True),       # critic conv1 on logits
     (2, 64, 16, 16, 128, 4, 2, 1, 1, True),      # critic conv2
     (2, 512, 4, 6, 1, 4, 2, 1, 1, True),         # critic classifier (Cout = 1)
-    (2, 136, 12, 16, 72, 3, 1, 1, 1, True),      # wide ragged Cin (ResNeXt decoder: 525): zero-padded to 160 channels
+    (2, 136, 12, 16, 72, 3, 1, 1, 1, True),      # wide ragged Cin (ResNeXt decoder: 525): zero-padded to 192 channels
+    (2, 136, 12, 16, 136, 3, 1, 1, 1, True),     # ... and ragged Cout: run at 192 x 192, the output is the narrow view
     (2, 512, 64, 88, 64, 4, 2, 1, 1, True),      # critic conv1 on deep features: 2816 rows, 256 K steps -> split-K above 2048 rows
     (2, 64, 12, 16, 13, 1, 1, 0, 1, True),       # final 1x1 (Cout = 13)
     (1, 2048, 6, 6, 2048, 1, 1, 0, 1, False),    # PSP stage conv on a 6x6 map
