@@ -62,7 +62,7 @@ enum : int { MATH_F32 = 0, MATH_X3 = 1, MATH_H2 = 2, MATH3_BF16 = 3 };  // (MATH
 // per CU whose eight waves run the split/store and MFMA phases in lockstep: the A operand is split once per 256 output
 // columns (half the split arithmetic per MFMA) and every SIMD's MFMA phase is two waves long against one staging phase.
 template <int TM, int TN, int MODE, int BK, int MATH = MATH_F32, int WN = 2>
-__global__ __launch_bounds__(128 * WN, 2) void conv_igemm_kernel(const ConvArgs p) {
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& p, int block_id, int nblocks) {
     constexpr int NT = 128 * WN;  // threads
     constexpr int LDK = KStep<BK>::LDK, PR = KStep<BK>::PR, VROWS = NT / PR, SROWS = NT / BK;
     constexpr bool VEC = MODE >= MODE_VEC;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_kernel(const ConvArgs 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int logical = hn_xcd_remap(blockIdx.x, gridDim.x);
+    const int logical = hn_xcd_remap(block_id, nblocks);
     const int ntiles = p.ntm * p.ntn;
     const int split = logical / ntiles, tile = logical - split * ntiles;
     int tile_m, tile_n;
@@ -465,18 +465,31 @@ __global__ __launch_bounds__(128 * WN, 2) void conv_igemm_kernel(const ConvArgs 
 }
 
 template <int TM, int TN, int MODE, int BK, int MATH = MATH_F32, int WN = 2>
-int launch_conv(const ConvArgs& a, hipStream_t stream) {
+__global__ __launch_bounds__(128 * WN, 2) void conv_igemm_kernel(const ConvArgs p) {
+    conv_igemm_body<TM, TN, MODE, BK, MATH, WN>(p, blockIdx.x, gridDim.x);
+}
+
+// The four parity classes of a stride-2 data gradient (conv2d_dgrad_impl) as ONE launch: the classes are independent
+// convolutions of the same dY into interleaved pixels of dX, each a few workgroups on the critics' small maps -- four
+// launches of 6-8 us each were most of such a layer's time.  Workgroups [first[c], first[c + 1]) run class c.
+struct ConvArgs4 {
+    ConvArgs a[4];
+    int first[5];
+};
+
+template <int TM, int TN, int MODE, int BK, int MATH = MATH_F32, int WN = 2>
+__global__ __launch_bounds__(128 * WN, 2) void conv_igemm_classes_kernel(const ConvArgs4 q) {
+    int c = 0;
+    while (c < 3 && (int)blockIdx.x >= q.first[c + 1]) ++c;
+    conv_igemm_body<TM, TN, MODE, BK, MATH, WN>(q.a[c], (int)blockIdx.x - q.first[c], q.first[c + 1] - q.first[c]);
+}
+
+template <int TM, int TN, int MODE, int BK, int MATH = MATH_F32, int WN = 2>
+int finish_launch_args(const ConvArgs& a, ConvArgs& p) {  // tile counts, tile order, split count: the launch's workgroups
     constexpr int BM = 64 * TM, BN = 32 * WN * TN;
-    constexpr int lds = MATH != MATH_F32 ? (MATH == MATH_H2 ? 2 : 3) * (BM + BN) * X3_ROW + BM * 16
-                                        : (2 * (BM + BN) * KStep<BK>::LDK + BM * 4) * (int)sizeof(float);
-    static std::atomic<unsigned long long> configured{0};
-    if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_kernel<TM, TN, MODE, BK, MATH, WN>), lds, configured) != HN_OK)
-        return HN_ELAUNCH;
-    ConvArgs p = a;
+    p = a;
     p.ntm = (a.M + BM - 1) / BM;
     p.ntn = (a.K + BN - 1) / BN;
-    // measured (profiles/r01_tile_order.txt): 8-row groups gain 4-6 % once there are >= 8 column tiles (the B panels
-    // of one group then outgrow an XCD's L2 in row-major order), and lose 1-2 % below that
     static const int gm_env = getenv("HN_GROUP_M") ? atoi(getenv("HN_GROUP_M")) : 0;  // experiment knob
     p.gm = gm_env > 0 ? gm_env : (p.ntn >= 8 ? 8 : 1);
     if (p.gm > p.ntm) p.gm = p.ntm;
@@ -486,7 +499,42 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
         p.cps = a.cps * 32 / BK;
         splits = (total + p.cps - 1) / p.cps;
     }
-    HN_LAUNCH((conv_igemm_kernel<TM, TN, MODE, BK, MATH, WN>), dim3(p.ntm * p.ntn * splits), dim3(128 * WN), lds, stream, p);
+    return p.ntm * p.ntn * splits;
+}
+
+// f16x2, buffer loaders, 64-row tiles: the instantiations the stride-2 classes of the critics run on
+template <int TN>
+int launch_conv_classes(const ConvArgs* cls, int n, hipStream_t stream) {
+    constexpr int TM = 1, BM = 64 * TM, BN = 64 * TN;
+    constexpr int lds = 2 * (BM + BN) * X3_ROW + BM * 16;
+    static std::atomic<unsigned long long> configured{0};
+    if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_classes_kernel<TM, TN, MODE_VEC_BUF, 32, MATH_H2, 2>), lds,
+                              configured) != HN_OK)
+        return HN_ELAUNCH;
+    ConvArgs4 q;
+    q.first[0] = 0;
+    for (int c = 0; c < 4; ++c) {
+        if (c < n) q.first[c + 1] = q.first[c] + finish_launch_args<TM, TN, MODE_VEC_BUF, 32, MATH_H2, 2>(cls[c], q.a[c]);
+        else { q.a[c] = q.a[0]; q.first[c + 1] = q.first[c]; }
+    }
+    HN_LAUNCH((conv_igemm_classes_kernel<TM, TN, MODE_VEC_BUF, 32, MATH_H2, 2>), dim3(q.first[4]), dim3(256), lds, stream, q);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+template <int TM, int TN, int MODE, int BK, int MATH = MATH_F32, int WN = 2>
+int launch_conv(const ConvArgs& a, hipStream_t stream) {
+    constexpr int BM = 64 * TM, BN = 32 * WN * TN;
+    constexpr int lds = MATH != MATH_F32 ? (MATH == MATH_H2 ? 2 : 3) * (BM + BN) * X3_ROW + BM * 16
+                                        : (2 * (BM + BN) * KStep<BK>::LDK + BM * 4) * (int)sizeof(float);
+    static std::atomic<unsigned long long> configured{0};
+    if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm_kernel<TM, TN, MODE, BK, MATH, WN>), lds, configured) != HN_OK)
+        return HN_ELAUNCH;
+    // (tile order, measured in profiles/r01_tile_order.txt: 8-row groups gain 4-6 % once there are >= 8 column tiles -- the B
+    // panels of one group then outgrow an XCD's L2 in row-major order -- and lose 1-2 % below that)
+    ConvArgs p;
+    const int nblocks = finish_launch_args<TM, TN, MODE, BK, MATH, WN>(a, p);
+    HN_LAUNCH((conv_igemm_kernel<TM, TN, MODE, BK, MATH, WN>), dim3(nblocks), dim3(128 * WN), lds, stream, p);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -502,6 +550,8 @@ int dispatch_tile(const ConvArgs& a, bool tall, bool wide, hipStream_t stream, i
 
 constexpr int VARIANT_F16X2 = 4 << 6;  // math_sel of the f16x2 arithmetic (variant codes, plan_conv)
 bool g_deterministic = false;  // hn_set_deterministic: no split-K float atomics in these kernels
+// experiment knob HN_CLASSES_ONE_LAUNCH=0: the parity classes of a stride-2 data gradient as four launches again
+const bool g_classes_one_launch = !(getenv("HN_CLASSES_ONE_LAUNCH") && atoi(getenv("HN_CLASSES_ONE_LAUNCH")) == 0);
 int g_conv_math = 0;  // HN_MATH_* default for variant codes that leave the math field 0 (hn_set_conv_math)
 
 // What a launch will run: the kernel family, its tile and arithmetic.
@@ -1203,6 +1253,8 @@ int conv2d_dgrad_impl(const float* dy, const float* dy_scale, const float* wt, c
         variant &= ~3;
     }
     long long wofs = 0;
+    ConvArgs cls[4];
+    int ncls = 0;
     for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
             const int Th = gh[ph].T, Tw = gw[pw].T;
@@ -1224,11 +1276,26 @@ int conv2d_dgrad_impl(const float* dy, const float* dy_scale, const float* wt, c
                     c.cps = plan_split_k(c.M, c.K, c.Kdim);
                     if (c.cps == 0) c.cps = (c.Kdim + 31) / 32;  // one split, but through the accumulating epilogue
                 }
-                const int rcc = dispatch_conv(c, variant, s);
-                if (rcc != HN_OK) return rcc;
+                cls[ncls++] = c;
             }
             wofs += wsize;
         }
+    // one launch for all classes where they run the same instantiation of the f16x2 64-row kernel (conv_igemm_classes_kernel)
+    if (ncls > 1 && g_classes_one_launch) {
+        ConvPlan p0;
+        bool same = plan_conv(cls[0], variant, p0) == HN_OK && p0.family == FAM_V1 && p0.math == MATH_H2 && !p0.tall &&
+                    p0.mode == MODE_VEC_BUF && p0.bk == 32;
+        for (int i = 1; i < ncls && same; ++i) {
+            ConvPlan pi;
+            same = plan_conv(cls[i], variant, pi) == HN_OK && pi.family == p0.family && pi.math == p0.math && pi.tall == p0.tall &&
+                   pi.wide == p0.wide && pi.mode == p0.mode && pi.bk == p0.bk;
+        }
+        if (same) return p0.wide ? launch_conv_classes<2>(cls, ncls, s) : launch_conv_classes<1>(cls, ncls, s);
+    }
+    for (int i = 0; i < ncls; ++i) {
+        const int rcc = dispatch_conv(cls[i], variant, s);
+        if (rcc != HN_OK) return rcc;
+    }
     return HN_OK;
 }
 }  // namespace
