@@ -55,7 +55,7 @@ SIGNATURES = {
     "hn_bn_act_bwd_apply": [P, c_int, P, c_int, P, c_int, P, P, P, P, P, P, c_i64, c_int, P, c_int, P, c_int,
                             c_i64, c_int, c_int, P, c_float, P, c_i64, P, P, P],
     "hn_act_bwd": [P, c_int, P, c_int, P, c_int, c_i64, c_int, c_int, c_float, P],
-    "hn_act_bwd_bias": [P, c_int, P, c_int, P, c_int, c_i64, c_int, c_int, c_float, P, P],
+    "hn_act_bwd_bias": [P, c_int, P, c_int, P, c_int, c_i64, c_int, c_int, c_float, P, P, P],
     "hn_scale_nc": [P, c_int, P, P, c_int, c_int, c_i64, c_int, P],
     "hn_add": [P, c_int, P, c_int, P, c_int, c_i64, c_int, P],
     "hn_dropout_mask": [P, c_int, c_float, ctypes.c_uint64, P],

@@ -700,8 +700,9 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const float* __restrict__ 
 template <int V>
 __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ out,
                                                           int ldo, float* __restrict__ dx, int lddx, int64_t npix, int C, int act,
-                                                          float slope, float* __restrict__ dbias) {
+                                                          float slope, float* __restrict__ dbias, float* __restrict__ dx_scale) {
     __shared__ float red[256 * 4];
+    unsigned amax = 0u;  // largest |dx| written by this thread (f16x2 scale of the tensor the conv backward kernels read)
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     const bool live = c < C;
     float s[V];
@@ -717,6 +718,7 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float* __restri
                 const float k = o[i] > 0.f ? 1.f : (act == HN_ACT_RELU ? 0.f : (act == HN_ACT_NONE ? 1.f : slope));
                 r[i] = g[i] * k;
                 s[i] += r[i];
+                amax = max(amax, __float_as_uint(r[i]) & 0x7fffffffu);
             }
             stv<V>(dx + pix * lddx + c, r);
         }
@@ -733,6 +735,7 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const float* __restri
             atomicAdd(dbias + c + i, a);
         }
     }
+    if (dx_scale != nullptr) hn_absmax_publish(amax, dx_scale);
 }
 
 template <int V>
@@ -1155,12 +1158,12 @@ extern "C" int hn_act_bwd(const float* dy, int lddy, const float* out, int ldo, 
 }
 
 extern "C" int hn_act_bwd_bias(const float* dy, int lddy, const float* out, int ldo, float* dx, int lddx, int64_t npix, int C,
-                               int act, float leaky_slope, float* dbias, void* stream) {
+                               int act, float leaky_slope, float* dbias, float* dx_scale, void* stream) {
     if (!dy || !out || !dx || !dbias || act < 0 || act > 3 || bad_rows(npix, C, {lddy, ldo, lddx})) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(dbias, 0, (size_t)C * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
     const RowLaunch pl = plan_rows(npix, C, {dy, out, dx}, {lddy, ldo, lddx}, 512);
-    HN_LAUNCH_V(pl, act_bwd_bias_kernel, dy, lddy, out, ldo, dx, lddx, npix, C, act, leaky_slope, dbias);
+    HN_LAUNCH_V(pl, act_bwd_bias_kernel, dy, lddy, out, ldo, dx, lddx, npix, C, act, leaky_slope, dbias, dx_scale);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

@@ -901,8 +901,11 @@ class _Conv2d(torch.autograd.Function):
                 # the bias gradient is the column sum of the tensor this pass writes: taken along (one pass over dy, not two)
                 slot = grad_slot(ctx.b_leaf, accumulate_ok=False) if ctx.b_leaf is not None else None
                 db = slot[0] if slot is not None else torch.empty(cout, device=x.device, dtype=torch.float32)
-                check(lib.hn_act_bwd_bias(_ptr(dy), lddy, _ptr(y), cout, _ptr(dpre), cout, npix, cout, act, slope, _ptr(db), s),
-                      "hn_act_bwd_bias")
+                dslot = _new_scale_slot(x.device) if ctx.lm == "f16x2" else None  # (the scale the backward kernels split dpre with)
+                check(lib.hn_act_bwd_bias(_ptr(dy), lddy, _ptr(y), cout, _ptr(dpre), cout, npix, cout, act, slope, _ptr(db),
+                                          _ptr(dslot), s), "hn_act_bwd_bias")
+                if dslot is not None:
+                    dpre._hn_scale = (dpre._version, dslot)
                 ctx.db_done = db
             else:
                 check(lib.hn_act_bwd(_ptr(dy), lddy, _ptr(y), cout, _ptr(dpre), cout, npix, cout, act, slope, s),

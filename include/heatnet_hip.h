@@ -427,10 +427,11 @@ int hn_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, cons
 int hn_act_bwd(const float* dy, int lddy, const float* out, int ldo, float* dx, int lddx,
                int64_t npix, int C, int act, float leaky_slope, void* stream);
 
-/* hn_act_bwd that also returns the bias gradient dbias[c] = sum over pixels of dx (overwritten): one pass instead of
- * hn_act_bwd + hn_channel_sum for the critics' conv + LeakyReLU layers (cm/discriminator_model.py:40-58). */
+/* hn_act_bwd that also returns the bias gradient dbias[c] = sum over pixels of dx (overwritten) and, optionally, publishes
+ * the f16x2 scale of dx into dx_scale (a zeroed slot): one pass instead of hn_act_bwd + hn_channel_sum + hn_absmax_scale for
+ * the critics' conv + LeakyReLU layers (cm/discriminator_model.py:40-58). */
 int hn_act_bwd_bias(const float* dy, int lddy, const float* out, int ldo, float* dx, int lddx, int64_t npix, int C, int act,
-                    float leaky_slope, float* dbias, void* stream);
+                    float leaky_slope, float* dbias, float* dx_scale, void* stream);
 
 /* y[n,:,:,c] = x[n,:,:,c] * mask[n*C + c]: nn.Dropout2d forward and backward given a host-drawn
  * keep/(1-p) mask, cm/models/pspnet.py:49,55,63-72. */
