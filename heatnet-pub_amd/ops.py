@@ -492,6 +492,21 @@ def _h2_covers(kind_idx, d):
     return r
 
 
+TUNE_FLUSH = os.environ.get("HEATNET_TUNE_FLUSH", "1") != "0"  # 0: time candidates back to back (cache-resident operands), see _pick
+_flush = {}
+
+
+def _current_device():
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _flush_buffer(device):
+    buf = _flush.get(device)
+    if buf is None:
+        buf = _flush[device] = torch.zeros(192 * 1024 * 1024, device=device, dtype=torch.float32)  # 768 MB > Infinity Cache + L2
+    return buf
+
+
 def _pick(kind, d, candidates, launch):
     if not AUTOTUNE or DETERMINISTIC:  # (deterministic mode changes the split-K plans the cached timings were made for)
         return candidates[0]
@@ -504,6 +519,10 @@ def _pick(kind, d, candidates, launch):
     times = {c: float("inf") for c in candidates}
     for _ in range(4):  # interleaved rounds, best-of: robust against clock ramps and one-off hiccups
         for cand in candidates:
+            if TUNE_FLUSH:
+                # operands of up to ~250 MB stay in the Infinity Cache between repeated launches, inside a step they come from
+                # HBM: evict them, so that the HBM-bound short-reduction layers are timed as they will run
+                _flush_buffer(_current_device()).add_(1.0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             launch(cand)
