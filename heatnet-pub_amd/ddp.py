@@ -173,6 +173,11 @@ class GradBuckets:
                 from . import ops
                 if ops.side_stream_used.get(self.device):  # weight gradients may still be running on the side stream
                     self.comm_stream.wait_stream(ops._side_stream(self.device))
+                main = ops.dual_stream_used.get(self.device)
+                if main is not None:
+                    # the bucket's gradients come from BOTH encoder streams (ops.DUAL_STREAMS); this hook runs on one of them
+                    self.comm_stream.wait_stream(ops.dual_stream(self.device))
+                    self.comm_stream.wait_stream(main)
                 if self.average:
                     b["flat"].mul_(1.0 / self.world)
                 b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)

@@ -303,9 +303,11 @@ def set_deterministic(on):
 
 
 def _det_workspace(device, numel):
-    buf = _det_ws.get(device)
+    # one per STREAM: the two encoder streams of a late-fusion network (resnet.ResNet.forward) run weight gradients concurrently
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _det_ws.get(key)
     if buf is None or buf.numel() < numel:
-        buf = _det_ws[device] = torch.empty(numel, device=device, dtype=torch.float32)
+        buf = _det_ws[key] = torch.empty(numel, device=device, dtype=torch.float32)
     return buf
 
 
@@ -443,9 +445,12 @@ absmax_launches = 0  # hn_absmax_scale passes made so far (diagnostics: scales n
 
 
 def _new_scale_slot(device):
-    c = _scale_chunks.get(device)
+    # chunks are per STREAM: a chunk is zero-filled on the stream that is current when it is made, and its slots must not be
+    # written by another stream's kernels before that fill has run
+    key = (device, torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else device
+    c = _scale_chunks.get(key)
     if c is None or c[1] >= c[0].shape[0]:
-        c = _scale_chunks[device] = [torch.zeros((512, SCALE_SLOT_FLOATS), device=device, dtype=torch.float32), 0]
+        c = _scale_chunks[key] = [torch.zeros((512, SCALE_SLOT_FLOATS), device=device, dtype=torch.float32), 0]
     slot = c[0][c[1]]
     c[1] += 1
     return slot
@@ -613,6 +618,80 @@ def _side_stream(device):
 
 
 _main_streams = {}
+# ---- the two encoders of a late-fusion network on two streams ---------------------------------------------------------------
+# RGB and thermal encoders (stem, layer1, layer2; cm/models/extractors.py:172-186) are independent up to the concatenation in
+# front of layer3: mostly short-reduction 1x1 convolutions and BatchNorm passes over large maps, 30-60 us launches that leave
+# the chip half idle at their ramps and tails.  resnet.ResNet.forward runs the thermal chain on a second stream; autograd
+# replays every node's backward on its forward stream, so the backward overlaps the same way.  Shared state that had to become
+# per-stream: scale-slot chunks, the deterministic weight-gradient workspace; ddp.GradBuckets waits for both streams.
+# Measured (profiles/r03_dual_streams.txt, ms per step, one box): second stream 38.95 / N > 1 path on one rank 39.2 / bf16 25.5 /
+# train_seg 87.4 against 39.9 / 40.2 / 26.1 / 89.0 with one encoder stream and the weight gradients on a side stream
+# (WGRAD_STREAM); both together: 38.8 plain but 50.7 in the N > 1 path -- so the side stream stays off where this one is in use.
+DUAL_STREAMS = os.environ.get("HEATNET_DUAL_STREAMS", "1") != "0"
+_dual_streams = {}
+dual_stream_used = {}  # device -> True once an encoder ran on the second stream (ddp asks)
+
+
+def dual_stream(device):
+    s = _dual_streams.get(device)
+    if s is None:
+        s = _dual_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def dual_fork(device):
+    """(main, second): the second stream waits for everything queued on the current one so far."""
+    main = torch.cuda.current_stream(device)
+    second = dual_stream(device)
+    second.wait_stream(main)
+    dual_stream_used[device] = main  # (what ddp.GradBuckets has to wait for besides the hook's own stream)
+    return main, second
+
+
+_dual_join_task = [None]
+
+
+def note_backward_stream(device):
+    """Called by the convolution nodes' backward: when this one runs on the second encoder stream, the caller's stream (and the
+    main one) wait for that stream once the backward pass ends -- the engine's own end-of-pass synchronisation only follows
+    gradients it was handed, not a weight gradient added in place into its arena slot (second use of a layer: returns None)."""
+    if not dual_stream_used or device not in dual_stream_used:
+        return
+    second = _dual_streams.get(device)
+    if second is None or torch.cuda.current_stream(device) != second:
+        return
+    task = _graph_task()
+    if _dual_join_task[0] == task:
+        return
+    _dual_join_task[0] = task
+    main = dual_stream_used[device]
+
+    def join():
+        main.wait_stream(second)
+        cur = torch.cuda.current_stream(device)
+        if cur != main:
+            cur.wait_stream(second)
+    torch.autograd.Variable._execution_engine.queue_callback(join)
+
+
+def hand_over(t, stream):
+    """`t` was produced on another stream and is from now on read on `stream` (which already waits for the producer): tell the
+    caching allocator, for the tensor, its plane twin and its scale slot."""
+    t.record_stream(stream)
+    tw = getattr(t, "_hn_twin", None)
+    if tw is not None:
+        tw[1].record_stream(stream)
+        sl = _plane_slot(getattr(tw[1], "_hn_planes", None)) if is_planes(tw[1]) else None
+        if sl is not None:
+            sl.record_stream(stream)
+    if is_planes(t):
+        sl = _plane_slot(t._hn_planes)
+        if sl is not None:
+            sl.record_stream(stream)
+    hit = getattr(t, "_hn_scale", None)
+    if hit is not None:
+        hit[1].record_stream(stream)
+
 
 
 class main_stream:
@@ -904,6 +983,7 @@ class _Conv2d(torch.autograd.Function):
     def backward(ctx, dy, *extra):
         lib = _lib.load()
         x, w, y = ctx.saved_tensors
+        note_backward_stream(x.device)
         dskip = extra[0] if (ctx.passthrough and extra) else None  # gradient that by-passed this conv
         stride, pad, dil, act, slope = ctx.geom
         x, ldx = as_nhwc(x)
@@ -1594,6 +1674,7 @@ class _ConvBnAct(torch.autograd.Function):
     def backward(ctx, dz, *extra):
         lib = _lib.load()
         xp, w, y, par, gamma, prelu_w, rbits, z = ctx.saved_tensors
+        note_backward_stream(xp.device)
         stride, pad, dil, act, leaky, passthrough, has_res, out_mode = ctx.cfg
         dskip = extra[0] if (passthrough and extra) else None
         s = _stream()
@@ -1669,7 +1750,10 @@ class _ConvBnAct(torch.autograd.Function):
         # Only when the gradient goes into the parameter's arena slot: then nothing on the main stream touches it before the
         # end-of-backward join (a second use of the layer adds in place on the same side stream).  A free-standing dW is
         # handed to autograd, which may add to it on the main stream at once (a layer applied to the day and the night batch).
-        if WGRAD_STREAM and need_w and _conv_prof is None and not DETERMINISTIC and getattr(lw, "_hn_grad_slot", None) is not None:
+        # (not next to the two encoder streams of a late-fusion network, ops.DUAL_STREAMS: three compute streams beside the
+        # communication stream and RCCL's own cost 10 ms per step in the N > 1 path, and two already fill the bubbles)
+        if (WGRAD_STREAM and need_w and _conv_prof is None and not DETERMINISTIC and getattr(lw, "_hn_grad_slot", None) is not None
+                and dev not in dual_stream_used):
             main = torch.cuda.current_stream(dev)
             ready = torch.cuda.Event()
             ready.record(main)  # dy (and, far earlier, the cleared gradient arena) is complete up to here; dgrad comes after

@@ -145,10 +145,26 @@ class ResNet(nn.Module):
     def forward(self, modal_1, modal_2=None):
         if not self.late_fusion and modal_2 is not None:
             modal_1 = ops.concat([modal_1, modal_2])  # early fusion: one 4-channel stem
+        # (not while bench.py's instrumented pass brackets every conv launch with events: overlapped durations would not add up)
+        dual = ops.DUAL_STREAMS and self.late_fusion and modal_2 is not None and modal_1.is_cuda and ops._conv_prof is None
+        if dual:
+            # the thermal encoder (stem, layer1_2, layer2_2) is independent of the RGB one up to the fusion point: it runs on a
+            # second stream (ops.DUAL_STREAMS); autograd replays each node's backward on its forward stream
+            import torch
+            main, s2 = ops.dual_fork(modal_1.device)
+            with torch.cuda.stream(s2):
+                t_1 = self._stem(self.conv1_2, self.bn1_2, modal_2)
+                t_2 = run_layer(self.layer1_2, t_1)
+                t_3 = run_layer(self.layer2_2, t_2)
         x_1 = self._stem(self.conv1, self.bn1, modal_1)
         x_2 = run_layer(self.layer1, x_1)
         x_3 = run_layer(self.layer2, x_2)
-        if self.late_fusion and modal_2 is not None:
+        if dual:
+            main.wait_stream(s2)
+            for t in (t_1, t_2, t_3):
+                ops.hand_over(t, main)
+            x_3 = ops.concat([x_3, t_3])
+        elif self.late_fusion and modal_2 is not None:
             t_1 = self._stem(self.conv1_2, self.bn1_2, modal_2)
             t_2 = run_layer(self.layer1_2, t_1)
             t_3 = run_layer(self.layer2_2, t_2)

@@ -638,3 +638,56 @@ def test_feedback_seg_on_the_pspnet_head_raises_like_the_reference(dev):
     rgb, ir, _ = [t.to(dev) for t in seeded_inputs(1, 256, 256, seed=3)]
     with pytest.raises(RuntimeError, match="13 channels"):
         model([rgb, ir], [rgb, ir])
+
+
+@pytest.mark.parametrize("conv_math", ["f16x2"], indirect=True)
+def test_two_encoder_streams_change_nothing(dev, conv_math):
+    """The thermal encoder on a second stream (ops.DUAL_STREAMS, resnet.ResNet.forward) against the same step on one stream, in
+    deterministic mode (no float atomics): logits, feature maps, running statistics and EVERY parameter gradient equal to fp32
+    rounding of the double-precision BatchNorm sums (2e-6 of the tensor's magnitude; in practice bitwise), over three iterations
+    with an optimizer step in between (a missing stream dependency shows up as a difference)."""
+    from heatnet_amd import ops, optim, train_step
+    rgb, ir, lab = seeded_inputs(2, 128, 192, seed=9)
+    prev_det = ops.set_deterministic(True)
+
+    def run(dual):
+        prev, ops.DUAL_STREAMS = ops.DUAL_STREAMS, dual
+        try:
+            net = _build(True, 4, dev)
+            net.train()
+            arenas = optim.arenas_for(net)
+            opt = optim.FlatRMSprop(arenas, lr=1e-4)
+            out = []
+            for _ in range(3):
+                opt.zero_grad()
+                logits, feats, _ = net(rgb.to(dev), ir.to(dev))
+                loss = train_step.segmentation_loss(logits, lab.to(dev))
+                loss.backward()
+                grads = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+                out.append((logits.detach().clone(), [f.detach().clone() for f in feats[1:]], grads,
+                            {k: v.detach().clone() for k, v in net.state_dict().items() if "running" in k}))
+                opt.step()
+            torch.cuda.synchronize()
+            return out
+        finally:
+            ops.DUAL_STREAMS = prev
+    try:
+        a, b = run(True), run(False)
+    finally:
+        ops.set_deterministic(prev_det)
+    def same(x, y):
+        # first iteration: same weights, same kernels -- fp32 rounding of the double sums only.  Later ones: RMSprop turns a
+        # last-bit difference of a near-zero gradient into a +-lr step, the runs drift apart like any two fp32 runs do
+        if it == 0:
+            return float((x.double() - y.double()).abs().max()) <= 2e-6 * float(y.abs().max()) + 1e-30
+        return bool(torch.isfinite(x).all()) and float((x.double() - y.double()).norm()) <= 0.2 * float(y.double().norm()) + 1e-30
+
+    for it, ((la, fa, ga, ra), (lb, fb, gb, rb)) in enumerate(zip(a, b)):
+        assert same(la, lb), "logits, iteration %d" % it
+        for i, (x, y) in enumerate(zip(fa, fb)):
+            assert same(x, y), "feature map %d, iteration %d" % (i, it)
+        assert ga.keys() == gb.keys()
+        for k in ga:
+            assert same(ga[k], gb[k]), "gradient of %s, iteration %d" % (k, it)
+        for k in ra:
+            assert same(ra[k], rb[k]), "%s, iteration %d" % (k, it)
