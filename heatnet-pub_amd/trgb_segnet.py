@@ -187,8 +187,21 @@ class ResNeXt(nn.Module):
 
     def forward(self, modal_1, modal_2=None):
         if self.late_fusion and modal_2 is not None:
-            o1, o1b = run_init_block(self.mod1, modal_1), run_init_block(self.mod1_2, modal_2)
-            o2, o2b = self.mod2_1(o1), self.mod2_2(o1b)
+            if ops.DUAL_STREAMS and modal_1.is_cuda and ops._conv_prof is None:
+                # the thermal chain (mod1_2, mod2_2) on a second stream, as in resnet.ResNet.forward (ops.DUAL_STREAMS)
+                import torch
+                main, s2 = ops.dual_fork(modal_1.device)
+                with torch.cuda.stream(s2):
+                    o1b = run_init_block(self.mod1_2, modal_2)
+                    o2b = self.mod2_2(o1b)
+                o1 = run_init_block(self.mod1, modal_1)
+                o2 = self.mod2_1(o1)
+                main.wait_stream(s2)
+                ops.hand_over(o1b, main)
+                ops.hand_over(o2b, main)
+            else:
+                o1, o1b = run_init_block(self.mod1, modal_1), run_init_block(self.mod1_2, modal_2)
+                o2, o2b = self.mod2_1(o1), self.mod2_2(o1b)
             out_1, out_2 = ops.concat([o1, o1b]), ops.concat([o2, o2b])
         else:
             out_1 = run_init_block(self.mod1, ops.concat([modal_1, modal_2]))
