@@ -639,13 +639,37 @@ def dual_stream(device):
     return s
 
 
+dual_region = [False]  # inside the forward of the two-encoder part of a network (set by its forward around fork and join)
+SECOND_STREAM_WGRAD = os.environ.get("HEATNET_SECOND_STREAM_WGRAD", "0") != "0"  # experiment, see _ConvBnAct.backward
+
+
 def dual_fork(device):
     """(main, second): the second stream waits for everything queued on the current one so far."""
     main = torch.cuda.current_stream(device)
     second = dual_stream(device)
     second.wait_stream(main)
     dual_stream_used[device] = main  # (what ddp.GradBuckets has to wait for besides the hook's own stream)
+    dual_region[0] = True
     return main, second
+
+
+def dual_join(main, second):
+    main.wait_stream(second)
+    dual_region[0] = False
+
+
+def _queue_second_stream_join(device, main, second):
+    task = _graph_task()
+    if _dual_join_task[0] == task:
+        return
+    _dual_join_task[0] = task
+
+    def join():
+        main.wait_stream(second)
+        cur = torch.cuda.current_stream(device)
+        if cur != main:
+            cur.wait_stream(second)
+    torch.autograd.Variable._execution_engine.queue_callback(join)
 
 
 _dual_join_task = [None]
@@ -1579,6 +1603,7 @@ class _ConvBnAct(torch.autograd.Function):
         n, cin, h, wd = xp.shape
         w_in, w = w, weight_ohwi(w)
         cout, _, kh, kw = w.shape
+        ctx.in_dual_region = dual_region[0]
         in_link = getattr(x, "_hn_bn_link", None)
         ctx.in_link = in_link if (BN_REDUCE_FUSION and in_link is not None and stride == 1 and ctx.needs_input_grad[0]
                                   and in_link.cout == cin and in_link.npix == n * h * wd) else None
@@ -1758,6 +1783,16 @@ class _ConvBnAct(torch.autograd.Function):
             ready = torch.cuda.Event()
             ready.record(main)  # dy (and, far earlier, the cleared gradient arena) is complete up to here; dgrad comes after
             side = _wgrad_side_stream(dev, main)
+        elif (SECOND_STREAM_WGRAD and WGRAD_STREAM and need_w and _conv_prof is None and not DETERMINISTIC
+              and getattr(lw, "_hn_grad_slot", None) is not None and dev in dual_stream_used and not ctx.in_dual_region
+              and torch.cuda.current_stream(dev) != _dual_streams.get(dev)):
+            # EXPERIMENT: behind the fusion point the second encoder stream is idle -- the weight gradients of the single-chain part
+            # (layer3, layer4, decoder) run there, still two compute streams in all
+            main = torch.cuda.current_stream(dev)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side = _dual_streams[dev]
+            _queue_second_stream_join(dev, main, side)
         if RANGE_CENSUS and (need_x or need_w) and not bf16:
             _census_operand(lw, 1, None, dyp, cout, dy_slot, npix, cout)
         tag = ".bf16p" if bf16 else ".planes"

@@ -160,7 +160,7 @@ class ResNet(nn.Module):
         x_2 = run_layer(self.layer1, x_1)
         x_3 = run_layer(self.layer2, x_2)
         if dual:
-            main.wait_stream(s2)
+            ops.dual_join(main, s2)
             for t in (t_1, t_2, t_3):
                 ops.hand_over(t, main)
             x_3 = ops.concat([x_3, t_3])

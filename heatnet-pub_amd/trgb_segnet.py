@@ -196,7 +196,7 @@ class ResNeXt(nn.Module):
                     o2b = self.mod2_2(o1b)
                 o1 = run_init_block(self.mod1, modal_1)
                 o2 = self.mod2_1(o1)
-                main.wait_stream(s2)
+                ops.dual_join(main, s2)
                 ops.hand_over(o1b, main)
                 ops.hand_over(o2b, main)
             else:
