@@ -72,7 +72,19 @@ struct ConvArgs {
     const unsigned char* br_bits = nullptr;  // the forward's byte ReLU masks (a residual was added in front of the ReLU)
     double* br_sums = nullptr;           // [HN_STAT_REPLICAS][2K + 1]
     unsigned* br_gmax = nullptr;         // [HN_STAT_REPLICAS][K] or NULL
+#ifdef HN_STAMPS
+    long long* stamps = nullptr;         // diagnostic build (make STAMPS=1): 16 words per workgroup, tools/stamp_conv.py
+#endif
 };
+#ifdef HN_STAMPS
+extern long long* g_hn_stamps;  // conv_igemm.hip, set by hn_debug_set_stamps
+#define HN_STAMP(p, i)                                                                                   \
+    do {                                                                                                 \
+        if ((p).stamps != nullptr && threadIdx.x == 0) (p).stamps[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define HN_STAMP(p, i) do { } while (0)
+#endif
 
 // bf16x3 LDS image: [split][row][32 k] bf16 with 80-byte rows (64 B of data + 16 B pad: 16 consecutive rows start in
 // 16 distinct 16-B slots of the 256-B bank row -> conflict-free ds_read_b128 of a lane's 8 consecutive k)

@@ -1174,6 +1174,11 @@ int conv2d_dgrad_impl(const float* dy, const float* dy_scale, const float* wt, c
         if (!br->y || !br->scale || !br->shift || !br->mean || !br->invstd || !br->sums || br->ldy < d->Cin) return HN_EINVAL;
         if (br->act != HN_ACT_NONE && br->act != HN_ACT_RELU) return HN_EINVAL;
         if (br->relu_bits != nullptr && (d->Cin % 4 != 0 || br->act != HN_ACT_RELU)) return HN_EINVAL;
+        // the epilogue reads y and the four per-channel vectors 16 bytes (four channels) per lane (conv_epilogue_t.h)
+        if (d->Cin % 4 != 0 || br->ldy % 4 != 0 || !hn_aligned16(dx) || !hn_aligned16(br->scale) || !hn_aligned16(br->shift) ||
+            !hn_aligned16(br->mean) || !hn_aligned16(br->invstd) ||
+            (reinterpret_cast<uintptr_t>(br->y) & (br->y_bf16 ? 7u : 15u)) != 0)
+            return HN_ESHAPE;
     }
     if (dyh != nullptr && (wt_x3 == nullptr || dyh_plane <= 0)) return HN_EINVAL;
     if (dyh != nullptr && dy_scale == nullptr) variant = (variant & 63) | (3 << 6);  // one bf16 plane
@@ -1299,6 +1304,11 @@ int conv2d_dgrad_impl(const float* dy, const float* dy_scale, const float* wt, c
     return HN_OK;
 }
 }  // namespace
+
+#ifdef HN_STAMPS
+long long* hnconv::g_hn_stamps = nullptr;
+extern "C" int hn_debug_set_stamps(long long* buf) { hnconv::g_hn_stamps = buf; return HN_OK; }
+#endif
 
 extern "C" int hn_conv2d_dgrad(const float* dy, const float* wt, const void* wt_x3, float* dx, const float* addend, int ldadd,
                                const HnConvDesc* d, int variant, void* stream) {

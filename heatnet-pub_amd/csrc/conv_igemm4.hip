@@ -26,6 +26,7 @@
 #include <cstdlib>
 
 #include "conv_common.h"
+#include "conv_epilogue_t.h"
 
 namespace hnconv {
 namespace {
@@ -68,8 +69,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
     int tile_m, tile_n;
     conv_tile_of(p, logical, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    HN_STAMP(p, 0);
+#ifdef HN_STAMPS
+    if (p.stamps != nullptr && tid == 0) {
+        p.stamps[(size_t)blockIdx.x * 16 + 9] = (long long)__builtin_amdgcn_s_memrealtime();
+        p.stamps[(size_t)blockIdx.x * 16 + 11] = (long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));   // HW_ID
+        p.stamps[(size_t)blockIdx.x * 16 + 12] = (long long)__builtin_amdgcn_s_getreg(20 | (31 << 11));  // XCC_ID
+    }
+#endif
     conv_fill_rowinfo<BM>(p, rowinfo, m0, tid);
     __syncthreads();
+    HN_STAMP(p, 1);
     float o_s = 1.f, o_s2 = 1.f, i_s = 1.f, i_s2 = 1.f;
     if constexpr (NPL == 2) {
         float a_s, a_inv;
@@ -78,6 +88,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
         i_s = a_s; i_s2 = p.w_scale[0];
     }
 
+    HN_STAMP(p, 2);
     // ---- A operand: this lane's rows of the wave's 16-row blocks, source piece after the swizzle ------------------
     const int l_row = lane >> 2;
     const int l_src = (lane & 3) ^ hsw((lane >> 4) & 3);
@@ -142,9 +153,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
         ++f_chunk;
     };
 
-    const AccMap<TM, TN, true> am{wm, wn, lane, n0};
+    // TRANSPOSED accumulators (conv_epilogue_t.h): the weight fragment is the MFMA's first operand, so a lane holds one pixel and
+    // four consecutive output channels per 16 x 16 sub-block
+    const AccMapT<TM, TN> am{wm, wn, lane, n0};
     f32x16 acc[TM][TN];
-    conv_init_acc<TM, TN, true>(p, acc, am, rowinfo, m0, i_s, i_s2);
+    conv_init_acc_t<TM, TN>(p, acc, am, rowinfo, m0, i_s, i_s2);
 
     const int frag = (lane & 15) * 64 + (((lane >> 4) ^ hsw((lane >> 2) & 3)) * 16);
     const int a_frag = wm * TM * 32 * 64 + frag;
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
 #pragma unroll
             for (int s2 = 0; s2 < NPL; ++s2) fa[s2] = *reinterpret_cast<const frag_t*>(st + a_frag + s2 * T::A_PLANE + bi * 16 * 64);
             // per accumulator the order is lo*hi, hi*lo, hi*hi (as in conv_igemm.hip); consecutive MFMAs go to different
-            // accumulators
+            // accumulators.  Weight fragment first: the 16 x 16 result arrives transposed (one pixel, four channels per lane)
             f32x4 c[2 * TN];
 #pragma unroll
             for (int bj = 0; bj < 2 * TN; ++bj) {
@@ -173,14 +186,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
             }
             if constexpr (NPL == 2) {
 #pragma unroll
-                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[bj][0], c[bj], 0, 0, 0);
+                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[bj][0], fa[1], c[bj], 0, 0, 0);
 #pragma unroll
-                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][1], c[bj], 0, 0, 0);
+                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[bj][1], fa[0], c[bj], 0, 0, 0);
 #pragma unroll
-                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][0], c[bj], 0, 0, 0);
+                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[bj][0], fa[0], c[bj], 0, 0, 0);
             } else {
 #pragma unroll
-                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][0], c[bj], 0, 0, 0);
+                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[bj][0], fa[0], c[bj], 0, 0, 0);
             }
 #pragma unroll
             for (int bj = 0; bj < 2 * TN; ++bj) {
@@ -209,17 +222,29 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) dma_chunk(smem4 + s * T::STAGE);
     int st_cur = 0, st_free = NST - 1;  // stage of chunk kc; stage that becomes free at the barrier of step kc
+    HN_STAMP(p, 3);
     for (int kc = 0; kc < nchunks; ++kc) {
         wait_landed();
         barrier();
+#ifdef HN_STAMPS
+        if (kc == 0) HN_STAMP(p, 4);
+#endif
         dma_chunk(smem4 + st_free * T::STAGE);
         mfma_phase(smem4 + st_cur * T::STAGE);
         st_free = st_cur;
         st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
     }
+    HN_STAMP(p, 5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last, out-of-range DMAs)
+    HN_STAMP(p, 6);
 
-    conv_epilogue<TM, TN, true, BM, BN, NPL == 2, NPL == 1, true>(p, acc, am, rowinfo, m0, tile_m, 0, o_s, o_s2);
+    conv_epilogue_t<TM, TN, BM, BN, NPL == 2, NPL == 1>(p, acc, am, rowinfo, m0, tile_m, o_s, o_s2);
+#ifdef HN_STAMPS
+    HN_STAMP(p, 7);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HN_STAMP(p, 8);
+    if (p.stamps != nullptr && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 10] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int WM, int WN, int TM, int TN, int NST, int NPL = 2>
@@ -229,6 +254,9 @@ int launch4(const ConvArgs& a, hipStream_t stream) {
     if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm4_kernel<WM, WN, TM, TN, NST, NPL>), T::LDS, configured) != HN_OK)
         return HN_ELAUNCH;
     ConvArgs p = a;
+#ifdef HN_STAMPS
+    p.stamps = g_hn_stamps;
+#endif
     p.ntm = (a.M + T::BM - 1) / T::BM;
     p.ntn = (a.K + T::BN - 1) / T::BN;
     static const int gm_env = getenv("HN_GROUP_M") ? atoi(getenv("HN_GROUP_M")) : 0;  // experiment knob

@@ -86,6 +86,18 @@ def new_nhwc(n, c, h, w, device, dtype=torch.float32):
     return torch.empty((n, h, w, c), device=device, dtype=dtype).permute(0, 3, 1, 2)
 
 
+def _vector_grad(dz, lddz):
+    """The byte ReLU masks (and the bf16 y) exist for whole 16-byte pieces only: a gradient that autograd hands over as an
+    unaligned view, or with a pixel stride that is no multiple of four, is re-laid out dense (the saved z is gone, so the scalar
+    kernels are no alternative)."""
+    if dz.data_ptr() % 16 == 0 and lddz % 4 == 0:
+        return dz, lddz
+    n, c, h, w = dz.shape
+    out = new_nhwc(n, c, h, w, dz.device)
+    out.copy_(dz)
+    return out, c
+
+
 def weight_ohwi(w):
     """Conv weight (logical OIHW) as a dense [O][KH][KW][I] buffer; a no-op for channels-last parameters."""
     _require_gpu(w)
@@ -1340,6 +1352,8 @@ class _BnAct(torch.autograd.Function):
         training, act, leaky, has_res = ctx.cfg
         y, ldy = as_nhwc(y)
         dz, lddz = as_nhwc(dz)
+        if rbits is not None:
+            dz, lddz = _vector_grad(dz, lddz)
         n, c, h, w = y.shape
         npix = n * h * w
         s = _stream()
@@ -1709,6 +1723,8 @@ class _ConvBnAct(torch.autograd.Function):
         npix = n * ho * wo
         dev = y.device
         dz, lddz = as_nhwc(dz)
+        if rbits is not None or ctx.ybf:
+            dz, lddz = _vector_grad(dz, lddz)
         mean, invstd, scale, shift, xhat = (par[i * cout:(i + 1) * cout] for i in range(5))
         ws = ctx.ws
         link = ctx.link
