@@ -575,7 +575,7 @@ struct ConvPlan {
 int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
     if (variant < 0 || variant >= 64 * 5) return HN_EINVAL;
     const int bk_sel = variant & 3, tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3, math_sel = variant >> 6;
-    if (tm_sel == 3) return HN_EINVAL;
+    if (tm_sel == 3 && a.xh == nullptr) return HN_EINVAL;  // (plane-tensor launches: the low four bits are a tile code)
     const bool vec = (a.C % 32 == 0) && (a.ldx % 4 == 0) && hn_aligned16(a.x) && hn_aligned16(a.w);
     bool wide = a.K > 64;
     if (tn_sel) wide = tn_sel >= 2;
@@ -606,7 +606,7 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
         if (!conv4_covers(a)) return HN_ESHAPE;
         pl.family = FAM_V4; pl.math = math == HN_MATH_BF16 ? MATH3_BF16 : MATH_H2; pl.mode = MODE_VEC_BUF;
         const int tile = variant & 15;
-        if (tile > 6) return HN_EINVAL;
+        if (tile > 7) return HN_EINVAL;
         pl.wn = tile == 0 ? (a.K <= 64 ? 1 : 0) : tile;
         return HN_OK;
     }

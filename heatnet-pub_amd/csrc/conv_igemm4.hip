@@ -26,7 +26,6 @@
 #include <cstdlib>
 
 #include "conv_common.h"
-#include "conv_epilogue_t.h"
 
 namespace hnconv {
 namespace {
@@ -153,11 +152,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
         ++f_chunk;
     };
 
-    // TRANSPOSED accumulators (conv_epilogue_t.h): the weight fragment is the MFMA's first operand, so a lane holds one pixel and
-    // four consecutive output channels per 16 x 16 sub-block
-    const AccMapT<TM, TN> am{wm, wn, lane, n0};
+    const AccMap<TM, TN, true> am{wm, wn, lane, n0};
     f32x16 acc[TM][TN];
-    conv_init_acc_t<TM, TN>(p, acc, am, rowinfo, m0, i_s, i_s2);
+    conv_init_acc<TM, TN, true>(p, acc, am, rowinfo, m0, i_s, i_s2);
 
     const int frag = (lane & 15) * 64 + (((lane >> 4) ^ hsw((lane >> 2) & 3)) * 16);
     const int a_frag = wm * TM * 32 * 64 + frag;
@@ -176,7 +173,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
 #pragma unroll
             for (int s2 = 0; s2 < NPL; ++s2) fa[s2] = *reinterpret_cast<const frag_t*>(st + a_frag + s2 * T::A_PLANE + bi * 16 * 64);
             // per accumulator the order is lo*hi, hi*lo, hi*hi (as in conv_igemm.hip); consecutive MFMAs go to different
-            // accumulators.  Weight fragment first: the 16 x 16 result arrives transposed (one pixel, four channels per lane)
+            // accumulators
             f32x4 c[2 * TN];
 #pragma unroll
             for (int bj = 0; bj < 2 * TN; ++bj) {
@@ -186,14 +183,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
             }
             if constexpr (NPL == 2) {
 #pragma unroll
-                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[bj][0], fa[1], c[bj], 0, 0, 0);
+                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[bj][0], c[bj], 0, 0, 0);
 #pragma unroll
-                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[bj][1], fa[0], c[bj], 0, 0, 0);
+                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][1], c[bj], 0, 0, 0);
 #pragma unroll
-                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[bj][0], fa[0], c[bj], 0, 0, 0);
+                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[bj][0], c[bj], 0, 0, 0);
             } else {
 #pragma unroll
-                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[bj][0], fa[0], c[bj], 0, 0, 0);
+                for (int bj = 0; bj < 2 * TN; ++bj) c[bj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[bj][0], c[bj], 0, 0, 0);
             }
 #pragma unroll
             for (int bj = 0; bj < 2 * TN; ++bj) {
@@ -238,7 +235,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last, out-of-range DMAs)
     HN_STAMP(p, 6);
 
-    conv_epilogue_t<TM, TN, BM, BN, NPL == 2, NPL == 1>(p, acc, am, rowinfo, m0, tile_m, o_s, o_s2);
+    conv_epilogue<TM, TN, true, BM, BN, NPL == 2, NPL == 1, true>(p, acc, am, rowinfo, m0, tile_m, 0, o_s, o_s2);
 #ifdef HN_STAMPS
     HN_STAMP(p, 7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -277,7 +274,10 @@ bool conv4_covers(const ConvArgs& a) {
 }
 
 // tile: 0 = 128 x 128 (four waves, two workgroups per CU), 1 = 128 x 64 (four waves 4 x 1), 2 = 128 x 256 (eight waves, three
-// stages, one workgroup per CU), 3 = 256 x 128 (eight waves 4 x 2, three stages); 4 = 128 x 64, 5 = 64 x 128, 6 = 64 x 64 with
+// stages, one workgroup per CU), 3 = 256 x 128 (eight waves 4 x 2, three stages); 7 = 256 x 256 (eight waves 2 x 4 with 128 x 64
+// wave tiles, two stages of 64 KB: half the operand bytes per multiply-add of the 128 x 128 tile -- the K loop of the smaller
+// tiles is bound by what a CU can pull out of its L2, tools/probes/dma_line_probe.hip, tools/stamp_conv.py);
+// 4 = 128 x 64, 5 = 64 x 128, 6 = 64 x 64 with
 // THREE (6: four) stages and two workgroups per CU: the DMA runs two (three) K steps ahead -- for the layers whose K steps
 // carry little matrix work per byte (1x1 convolutions with few channels on one side), where a distance of one step leaves
 // every step waiting out the memory latency
@@ -290,6 +290,7 @@ int launch_conv4(const ConvArgs& a, int tile, hipStream_t stream) {
             case 4: return launch4<4, 1, 1, 2, 4, 1>(a, stream);
             case 5: return launch4<2, 2, 1, 2, 4, 1>(a, stream);
             case 6: return launch4<2, 2, 1, 1, 4, 1>(a, stream);
+            case 7: return launch4<2, 4, 4, 2, 3, 1>(a, stream);
             default: return launch4<2, 2, 2, 2, 3, 1>(a, stream);
         }
     }
@@ -300,6 +301,7 @@ int launch_conv4(const ConvArgs& a, int tile, hipStream_t stream) {
         case 4: return launch4<4, 1, 1, 2, 3>(a, stream);
         case 5: return launch4<2, 2, 1, 2, 3>(a, stream);
         case 6: return launch4<2, 2, 1, 1, 4>(a, stream);
+        case 7: return launch4<2, 4, 4, 2, 2>(a, stream);
         default: return launch4<2, 2, 2, 2, 2>(a, stream);
     }
 }
@@ -313,6 +315,7 @@ const char* conv4_kernel_name(int tile, bool bf16) {
             case 4: return "conv_igemm4_kernel<4, 1, 1, 2, 4, 1>";
             case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 4, 1>";
             case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4, 1>";
+            case 7: return "conv_igemm4_kernel<2, 4, 4, 2, 3, 1>";
             default: return "conv_igemm4_kernel<2, 2, 2, 2, 3, 1>";
         }
     }
@@ -323,6 +326,7 @@ const char* conv4_kernel_name(int tile, bool bf16) {
         case 4: return "conv_igemm4_kernel<4, 1, 1, 2, 3, 2>";
         case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 3, 2>";
         case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4, 2>";
+        case 7: return "conv_igemm4_kernel<2, 4, 4, 2, 2, 2>";
         default: return "conv_igemm4_kernel<2, 2, 2, 2, 2, 2>";
     }
 }

@@ -83,10 +83,12 @@ PLANE_CONV_CASES = [  # n, cin, h, w, cout, k, stride, pad, dil
     (2, 256, 40, 44, 512, 1, 2, 0, 1),    # strided 1x1 (downsample)
     (1, 512, 24, 40, 512, 3, 1, 4, 4),    # dilation 4
     (3, 96, 30, 30, 160, 1, 1, 0, 1),     # Cin % 64 != 0, Cout % 64 != 0
+    (4, 64, 80, 88, 256, 1, 1, 0, 1),     # several rounds of workgroups
+    (4, 64, 96, 100, 64, 3, 1, 1, 1),     # the same with a 3x3 filter, ragged last row tile, narrow output
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("case", PLANE_CONV_CASES, ids=str)
 def test_conv_planes_forward_dgrad_bitwise(dev, case, tile):
     from heatnet_amd import _lib, ops
@@ -402,7 +404,7 @@ def test_f16x2_range_guard_moves_heavy_tailed_layers_to_bf16x3(dev):
         ops._census.clear()
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("case", PLANE_CONV_CASES[:5] + PLANE_CONV_CASES[6:], ids=str)
 def test_conv_planes_bf16_bitwise(dev, case, tile):
     """The mixed-precision bf16 arithmetic on ONE bf16 image per operand (x_scale = NULL): forward, data gradient and weight
