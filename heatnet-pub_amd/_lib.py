@@ -120,6 +120,10 @@ SIGNATURES = {
     "hn_teacher_cert": [P, c_int, c_i64, c_int, P, P, P],
     "hn_adv_loss_fwd": [P, c_i64, c_float, c_int, P, P],
     "hn_adv_loss_bwd": [P, c_i64, c_float, c_int, P, P, P],
+    "hn_sigmoid_fwd": [P, P, c_i64, P],
+    "hn_sigmoid_bwd": [P, P, P, c_i64, P],
+    "hn_cert_loss_fwd": [P, c_int, P, P, c_int, c_i64, c_int, P, P],
+    "hn_cert_loss_bwd": [P, c_int, P, P, c_int, c_i64, c_int, P, P, P, c_int, P],
     "hn_argmax_confusion": [P, c_int, P, c_i64, c_int, c_int, P, P, P],
     "hn_rmsprop_step": [P, P, P, c_i64, c_float, c_float, c_float, c_float, P],
     "hn_adam_step": [P, P, P, P, c_i64, c_float, c_float, c_float, c_float, c_float, c_int, P],

@@ -2,8 +2,9 @@
 
 models/confusion_maximization/models/conf_segnet.py:22-140 for arch='pspnet' and arch='custom' (ResNeXt-50 + ASPP,
 trgb_segnet.py), disc_arch='cyclegan', with the `feedback_seg` branch (DownNets appended to the critic inputs,
-:61-70,121-125).  The remaining optional branches of the reference (ResNet critics, input adapter, cert branch) are not
-working configurations of its training loop and raise NotImplementedError.
+:61-70,121-125).  The remaining optional branches of the reference (ResNet critics, input adapter) are not working
+configurations of its training loop and raise NotImplementedError; `cert_branch` builds the certainty head
+of the custom architecture (early fusion; trgb_segnet.py:344-346, 383-387) and train_step adds the trainer's certainty loss.
 """
 import torch
 import torch.nn as nn
@@ -44,9 +45,7 @@ class conv_segnet(nn.Module):
             # reference raises TypeError in its first conv (verified by running it); there is nothing to be compatible with
             raise NotImplementedError("input_adapter: the reference's adapter takes a single tensor (arch='custom'); with the "
                                       "PSPNet path's [rgb, ir] inputs its own forward raises TypeError")
-        if cert_branch:
-            raise NotImplementedError("cert_branch (the certainty head of the ResNeXt 'custom' arch) is not built; PSPNet "
-                                      "returns cert = None")
+        self.cert_branch = bool(cert_branch)  # (arch='custom' only builds the head; PSPNet returns cert = None, as in the reference)
         num_input_channels = (3 if "rgb" in modalities else 0) + (1 if "ir" in modalities else 0)
         if arch == "custom":  # :38-43 -- ResNeXt-50 (64 groups) + ASPP, the reference's default architecture
             from .trgb_segnet import ResNeXt

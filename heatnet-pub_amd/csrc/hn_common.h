@@ -30,19 +30,6 @@ static inline int hn_ensure_dynamic_lds(const void* kernel, int bytes, std::atom
     return HN_OK;
 }
 
-// Compute units of the current device (MI355X: 256), cached per device ordinal.
-static inline int hn_num_cus() {
-    static std::atomic<int> cached[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    int v = cached[dev & 63].load(std::memory_order_relaxed);
-    if (v == 0) {
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        cached[dev & 63].store(v, std::memory_order_relaxed);
-    }
-    return v;
-}
-
 // bf16x3 weight planes: plane stride in elements for a matrix of n elements (HN_X3_PLANE in the header)
 static inline long long hn_x3_plane(long long n) { return HN_X3_PLANE(n); }
 

@@ -204,6 +204,90 @@ inline int flat_grid(int64_t n) {
     return (int)b;
 }
 
+
+// ---- the certainty branch of the custom architecture (cm/models/trgb_segnet.py:383-387, cm/train_trgb_segnet_conf.py:482-491) ----
+__global__ __launch_bounds__(256) void sigmoid_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = 1.f / (1.f + expf(-x[i]));
+}
+
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                         float* __restrict__ dx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * y[i] * (1.f - y[i]);
+}
+
+// probability of the labelled class, p_y = softmax(logits)[label]; 0 where the label is outside [0, C)
+__device__ __forceinline__ float prob_of_label(const float* row, int C, int64_t lab, float* probs) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (c < C) { probs[c] = row[c]; mx = fmaxf(mx, probs[c]); }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (c < C) { probs[c] = expf(probs[c] - mx); se += probs[c]; }
+    const float inv = 1.f / se;
+    float py = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (c < C) { probs[c] *= inv; if (c == (int)lab) py = probs[c]; }
+    return (lab >= 0 && lab < C) ? py : 0.f;
+}
+
+// The trainer's certainty loss as written: target t[m, p] = 1 - p_y (image m, pixel p), prediction a[n, p] (the sigmoid map,
+// [N, 1, H, W]); `a - t` broadcasts [N, 1, H, W] against [N, H, W] to [N, N, H, W], so the loss is
+//   10 / (N N HW) sum_p sum_n sum_m (a[n, p] - t[m, p])^2 = 10 / (N N HW) sum_p (N A2 + N T2 - 2 A1 T1),
+// A1, A2 = sum_n a, a^2 and T1, T2 = sum_m t, t^2 at pixel p.  One thread per pixel p; out[0] += the unscaled sum.
+__global__ __launch_bounds__(256) void cert_loss_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
+                                                           const float* __restrict__ a, int N, int64_t hw, int C,
+                                                           float* __restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
+        double a1 = 0., a2 = 0., t1 = 0., t2 = 0.;  // (the expanded square cancels: the four sums in double)
+        for (int n = 0; n < N; ++n) {
+            const int64_t pix = (int64_t)n * hw + p;
+            float probs[MAXC];
+            const double t = 1.0 - (double)prob_of_label(logits + pix * ld, C, labels[pix], probs);
+            const double av = a[pix];
+            a1 += av; a2 += av * av; t1 += t; t2 += t * t;
+        }
+        acc += (float)((double)N * (a2 + t2) - 2.0 * a1 * t1);
+    }
+    const float l = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, l);
+}
+
+// da[n, p] = s 2 (N a[n, p] - T1),  dt[m, p] = s 2 (N t[m, p] - A1),  dlogits[m, p, c] = -dt p_y (delta_cy - p_c),
+// s = 10 / (N N HW) * gout
+__global__ __launch_bounds__(256) void cert_loss_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
+                                                           const float* __restrict__ a, int N, int64_t hw, int C,
+                                                           const float* __restrict__ gout, float* __restrict__ da,
+                                                           float* __restrict__ dl, int lddl) {
+    const float s = 20.f / ((float)N * (float)N * (float)hw) * gout[0];
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (int64_t)gridDim.x * blockDim.x) {
+        float a1 = 0.f, t1 = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const int64_t pix = (int64_t)n * hw + p;
+            float probs[MAXC];
+            t1 += 1.f - prob_of_label(logits + pix * ld, C, labels[pix], probs);
+            a1 += a[pix];
+        }
+        for (int n = 0; n < N; ++n) {
+            const int64_t pix = (int64_t)n * hw + p;
+            float probs[MAXC];
+            const int64_t lab = labels[pix];
+            const float py = prob_of_label(logits + pix * ld, C, lab, probs);
+            if (da != nullptr) da[pix] = s * ((float)N * a[pix] - t1);
+            const float dt = s * ((float)N * (1.f - py) - a1);
+            float* row = dl + pix * lddl;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) row[c] = -dt * py * ((c == (int)lab ? 1.f : 0.f) - probs[c]);
+        }
+    }
+}
 }  // namespace
 
 extern "C" int hn_ce_fwd(const float* logits, int ld, const int64_t* labels, int64_t npix, int C, int64_t ignore_index,
@@ -273,6 +357,42 @@ extern "C" int hn_adv_loss_bwd(const float* x, int64_t n, float target, int kind
     hipStream_t s = static_cast<hipStream_t>(stream);
     HN_LAUNCH(adv_bwd_kernel, dim3(flat_grid(n)), dim3(256), 0, s, x, n, target, kind, (float)(1.0 / (double)n),
                        gout, dx);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+
+extern "C" int hn_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream) {
+    if (x == nullptr || y == nullptr || n <= 0) return HN_EINVAL;
+    HN_LAUNCH(sigmoid_fwd_kernel, dim3(flat_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_sigmoid_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream) {
+    if (y == nullptr || dy == nullptr || dx == nullptr || n <= 0) return HN_EINVAL;
+    HN_LAUNCH(sigmoid_bwd_kernel, dim3(flat_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), y, dy, dx, n);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_cert_loss_fwd(const float* logits, int ld, const int64_t* labels, const float* cert, int N, int64_t hw, int C,
+                                float* out, void* stream) {
+    if (logits == nullptr || labels == nullptr || cert == nullptr || out == nullptr || N <= 0 || hw <= 0) return HN_EINVAL;
+    if (C <= 0 || C > MAXC || ld < C) return HN_ESHAPE;
+    HN_LAUNCH(cert_loss_fwd_kernel, dim3(flat_grid(hw)), dim3(256), 0, static_cast<hipStream_t>(stream), logits, ld, labels, cert, N, hw,
+              C, out);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_cert_loss_bwd(const float* logits, int ld, const int64_t* labels, const float* cert, int N, int64_t hw, int C,
+                                const float* gout, float* dcert, float* dlogits, int lddl, void* stream) {
+    if (logits == nullptr || labels == nullptr || cert == nullptr || gout == nullptr || dlogits == nullptr || N <= 0 || hw <= 0)
+        return HN_EINVAL;
+    if (C <= 0 || C > MAXC || ld < C || lddl < C) return HN_ESHAPE;
+    HN_LAUNCH(cert_loss_bwd_kernel, dim3(flat_grid(hw)), dim3(256), 0, static_cast<hipStream_t>(stream), logits, ld, labels, cert, N, hw,
+              C, gout, dcert, dlogits, lddl);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

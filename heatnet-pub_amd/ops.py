@@ -524,10 +524,15 @@ def _flush_buffer(device):
     return buf
 
 
+_candidates_seen = None  # a dict while tools/insitu_tune.py records the candidate lists
+
+
 def _pick(kind, d, candidates, launch):
     if not AUTOTUNE or DETERMINISTIC:  # (deterministic mode changes the split-K plans the cached timings were made for)
         return candidates[0]
     key = (kind,) + tuple(getattr(d, f) for f, _ in HnConvDesc._fields_)
+    if _candidates_seen is not None:
+        _candidates_seen[key] = list(candidates)  # (tools/insitu_tune.py: which alternatives a geometry has)
     hit = _variant_cache.get(key)
     if hit is not None:
         return hit
@@ -2510,6 +2515,68 @@ class _CrossEntropyWeighted(torch.autograd.Function):
 
 def cross_entropy_weighted(logits, labels, weight):
     return _CrossEntropyWeighted.apply(logits, labels, weight)
+
+
+class _Sigmoid(torch.autograd.Function):
+    """torch.sigmoid on the certainty map of the custom architecture (cm/models/trgb_segnet.py:387)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(_lib.load().hn_sigmoid_fwd(_ptr(x), _ptr(y), x.numel(), _stream()), "hn_sigmoid_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        check(_lib.load().hn_sigmoid_bwd(_ptr(y), _ptr(dy), _ptr(dx), y.numel(), _stream()), "hn_sigmoid_bwd")
+        return dx
+
+
+def sigmoid(x):
+    return _Sigmoid.apply(as_f32(x))
+
+
+class _CertLoss(torch.autograd.Function):
+    """The trainer's certainty loss as written (cm/train_trgb_segnet_conf.py:482-491): 10 * mean((cert_a - (1 - p_label)) ** 2)
+    with cert_a [N, 1, H, W] broadcast against the [N, H, W] target to [N, N, H, W]; the target is not detached, so the
+    segmentation logits receive a gradient through it (hn_cert_loss_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, cert):
+        lib = _lib.load()
+        logits, ld = as_nhwc(logits)
+        n, c, h, w = logits.shape
+        if tuple(cert.shape) != (n, 1, h, w) or tuple(labels.shape) != (n, h, w):
+            raise RuntimeError("cert_loss: logits [N, C, H, W], labels [N, H, W], cert [N, 1, H, W]")
+        _require_gpu(cert)
+        cert = cert.contiguous()
+        labels = labels.contiguous()
+        out = torch.zeros(1, device=logits.device, dtype=torch.float32)
+        check(lib.hn_cert_loss_fwd(_ptr(logits), ld, _ptr(labels), _ptr(cert), n, h * w, c, _ptr(out), _stream()), "hn_cert_loss_fwd")
+        ctx.save_for_backward(logits, labels, cert)
+        ctx.ld = ld
+        return out[0] * (10.0 / (n * n * h * w))
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, cert = ctx.saved_tensors
+        n, c, h, w = logits.shape
+        g = g.reshape(1).to(torch.float32).contiguous()
+        dl = new_nhwc(n, c, h, w, logits.device)
+        dc = torch.empty_like(cert) if ctx.needs_input_grad[2] else None
+        check(_lib.load().hn_cert_loss_bwd(_ptr(logits), ctx.ld, _ptr(labels), _ptr(cert), n, h * w, c, _ptr(g), _ptr(dc), _ptr(dl), c,
+                                           _stream()), "hn_cert_loss_bwd")
+        return dl, None, dc
+
+
+def cert_loss(logits, labels, cert):
+    return _CertLoss.apply(logits, labels, cert)
 
 
 def teacher_outputs(logits, want_cert=True):

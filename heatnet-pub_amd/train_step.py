@@ -118,6 +118,14 @@ def train_step(model, optimizer, day, night, label_day, state, adv="MSE", conf_w
                 seg_night = segmentation_loss(out["pred_label_b"], pseudo)
             losses["seg_night"] = seg_night.detach()
             seg = seg + seg_night
+        inner = getattr(model, "module", model)
+        if getattr(inner, "cert_branch", False) and night_teacher is None:
+            # :482-491 (`--cert_branch`, no night supervision): the certainty head regresses 1 - p(true class) of the day pass
+            if out.get("cert_a") is None:
+                raise TypeError("cert_branch: the segmentation network returned no certainty map (only arch='custom' has the head)")
+            cert = ops.cert_loss(out["pred_label_a"], label_day, out["cert_a"])
+            losses["cert"] = cert.detach()
+            seg = seg + cert
         losses["seg"] = seg.detach()
         if "critics_a" in out:
             conf = confusion_loss(out, adv, weights=conf_scalars)

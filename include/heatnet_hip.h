@@ -512,6 +512,21 @@ int hn_adv_loss_fwd(const float* x, int64_t n, float target, int kind, float* ou
 /* dx = (*gout / n) * dloss/dx */
 int hn_adv_loss_bwd(const float* x, int64_t n, float target, int kind, const float* gout, float* dx, void* stream);
 
+/* The certainty branch of the custom architecture (cm/models/trgb_segnet.py:344-346, 383-387): y = sigmoid(x) over n floats and
+ * its gradient dx = dy * y * (1 - y). */
+int hn_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream);
+int hn_sigmoid_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
+
+/* The trainer's certainty loss AS WRITTEN (cm/train_trgb_segnet_conf.py:482-491): the target is t = 1 - softmax(logits)[label]
+ * ([N, H, W], NOT detached), the prediction `cert` is the sigmoid map [N, 1, H, W]; `cert - t` broadcasts to [N, N, H, W] and
+ * the loss is 10 * mean of its square.  out[0] (zero on entry) += sum over pixels, predictions n and targets m of
+ * (cert[n, p] - t[m, p])^2 -- the caller scales by 10 / (N N HW).  hw = H * W; logits [N * hw][ld], labels [N * hw].
+ * Backward: gout[0] = gradient of the (scaled) loss; dcert [N * hw] (may be NULL) and dlogits [N * hw][lddl] are WRITTEN. */
+int hn_cert_loss_fwd(const float* logits, int ld, const int64_t* labels, const float* cert, int N, int64_t hw, int C, float* out,
+                     void* stream);
+int hn_cert_loss_bwd(const float* logits, int ld, const int64_t* labels, const float* cert, int N, int64_t hw, int C,
+                     const float* gout, float* dcert, float* dlogits, int lddl, void* stream);
+
 /* argmax over C + confusion-matrix histogram: conf[label*K + pred] += 1 (int64, caller-zeroed), labels
  * outside [0,K) skipped.  scripts/iou_eval.py:19-98, cm/utils.py:134-163. */
 int hn_argmax_confusion(const float* logits, int ld, const int64_t* labels, int64_t npix, int C, int K,

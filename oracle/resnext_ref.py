@@ -92,9 +92,10 @@ def fuse_module(cin, cout):
 
 class RefResNeXt(nn.Module):
     def __init__(self, structure=(3, 4, 6, 3), groups=64, classes=13, dilation=(1, 1, 2, 4), base_channels=(128, 128, 256),
-                 input_channels=4, late_fusion=False):
+                 input_channels=4, late_fusion=False, cert_branch=False):
         super().__init__()
         self.late_fusion = late_fusion
+        self.cert_branch = cert_branch
         if late_fusion:
             self.mod1, self.mod1_2 = init_block(3), init_block(1)
         else:
@@ -120,6 +121,9 @@ class RefResNeXt(nn.Module):
         self.up_borders_3 = nn.ConvTranspose2d(5, 5, 4, 2, 1, bias=False)  # unused heads of the reference, kept for the keys
         self.up_inst_2 = nn.ConvTranspose2d(5, 5, 4, 2, 1, bias=False)
         self.fuse_seg = fuse_module((512 if late_fusion else 256) + classes, classes)
+        if cert_branch:  # cm/models/trgb_segnet.py:344-346
+            self.up_seg_2_cert = nn.ConvTranspose2d(1, 1, 4, 2, 1, bias=False)
+            self.fuse_seg_cert = fuse_module(256 + 1, 1)
 
     def forward(self, modal_1, modal_2=None):
         if self.late_fusion and modal_2 is not None:
@@ -132,7 +136,18 @@ class RefResNeXt(nn.Module):
         out_3 = self.mod3_1(out_2)
         out_4 = self.mod4_1(out_3)
         top = self.bn_out_1(self.mod5_1(out_4))
-        seg, fusion, _ = self.aspp(top)
+        seg, fusion, seg_cf = self.aspp(top)
         seg = self.fuse_seg(torch.cat([self.up_seg_2(seg), out_2], 1))
+        seg_cert = None
+        if self.cert_branch:  # :383-387
+            seg_cert = torch.sigmoid(self.fuse_seg_cert(torch.cat([self.up_seg_2_cert(seg_cf), out_2], 1)))
         skip = F.adaptive_avg_pool2d(out_2, (fusion.size(2), fusion.size(3)))
-        return seg, [seg, torch.cat([fusion, skip], 1), out_4, out_3, out_2, out_1], None
+        return seg, [seg, torch.cat([fusion, skip], 1), out_4, out_3, out_2, out_1], seg_cert
+
+
+def cert_loss(pred_label_a, label_day, cert_a):
+    """cm/train_trgb_segnet_conf.py:482-491 as written: the target 1 - p(true class) is [N, H, W] and NOT detached, the
+    prediction is [N, 1, H, W]; their difference broadcasts to [N, N, H, W]."""
+    one_hot = F.one_hot(label_day, pred_label_a.size(1)).permute(0, 3, 1, 2).to(pred_label_a.dtype)
+    cert = 1.0 - torch.sum(one_hot * F.softmax(pred_label_a, dim=1), 1)
+    return torch.mean((cert_a - cert) ** 2) * 10

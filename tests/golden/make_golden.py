@@ -310,7 +310,9 @@ RESNEXT_GRAD_KEYS = ["mod1.conv1_2.weight", "mod1_2.conv3.weight", "mod2_1.block
                      "mod5_1.block2.convs.conv2.weight", "mod5_1.block3.bn1.bn.weight", "bn_out_1.bn.bias",
                      "aspp.conv1.conv1.weight", "aspp.conv3.conv1.weight", "aspp.conv4.bn1.bn.weight", "aspp.conv5.conv1.weight",
                      "aspp.fuse_conv.conv1.weight", "aspp.final_conv.conv1.weight", "up_seg_2.weight", "fuse_seg.conv1.weight",
-                     "fuse_seg.bn2.bn.weight", "fuse_seg.conv3.weight", "fuse_seg.up.weight"]
+                     "fuse_seg.bn2.bn.weight", "fuse_seg.conv3.weight", "fuse_seg.up.weight",
+                     "aspp.final_conv2.conv1.weight", "up_seg_2_cert.weight", "fuse_seg_cert.conv1.weight", "fuse_seg_cert.bn2.bn.weight",
+                     "fuse_seg_cert.conv3.weight", "fuse_seg_cert.up.weight"]
 
 
 def part_resnext():
@@ -318,17 +320,28 @@ def part_resnext():
     conf_segnet builds it (models/conf_segnet.py:38-43): train-mode forward, cross-entropy, backward."""
     sys.path.insert(0, CM)
     from models import trgb_segnet
-    for tag, late in (("late", True), ("early", False)):
-        net = trgb_segnet.ResNeXt(structure=[3, 4, 6, 3], input_channels=4, cert_branch=False, late_fusion=late)
+    for tag, late in (("late", True), ("early", False), ("cert", False)):
+        net = trgb_segnet.ResNeXt(structure=[3, 4, 6, 3], input_channels=4, cert_branch=(tag == "cert"), late_fusion=late)
         net.load_state_dict(seeded_state(net, seed=21))
         rgb, ir, lab = seeded_inputs(2, 128, 192, seed=23)
         net.train()
         seg, feats, cert = net(rgb, ir)
-        assert cert is None
+        assert (cert is None) == (tag != "cert")
         loss = torch.nn.functional.cross_entropy(seg, lab)
+        extra = {}
+        if tag == "cert":
+            # the trainer's certainty loss, cm/train_trgb_segnet_conf.py:482-491 (the script itself cannot be imported: wandb,
+            # datasets); utils.make_one_hot scatters into a torch.cuda.FloatTensor -- the same one-hot built on the CPU
+            one_hot = torch.zeros(lab.size(0), seg.size(1), lab.size(1), lab.size(2)).scatter_(1, lab.unsqueeze(1), 1)
+            c = torch.sum((one_hot.float() * torch.nn.functional.softmax(seg, dim=1)), 1)
+            c = torch.ones_like(c) - c
+            cert_loss = torch.mean((cert - c) ** 2) * 10
+            extra = {"cert_sub": cert.detach()[..., ::2, ::2].numpy().copy(), "cert_loss": np.array(float(cert_loss.detach()))}
+            loss = loss + cert_loss
         loss.backward()
         d, _ = tensor_digest(seg, 1)
         out = {"logits_sub": seg.detach()[..., ::2, ::2].numpy().copy(), "logits_digest": d, "loss": np.array(float(loss.detach())),
+               **extra,
                "keys": np.array(list(net.state_dict().keys())),
                "shapes": np.array([list(v.shape) + [0] * (4 - v.dim()) for v in net.state_dict().values()])}
         _digests("feat", feats[1:], 31, out)

@@ -1039,6 +1039,32 @@ def test_bn_relu_byte_mask_equals_reading_z(dev, c):
         assert torch.equal(a, b)
 
 
+def test_bn_relu_byte_mask_takes_an_unaligned_gradient_view(dev):
+    """The byte ReLU masks replace the saved z, and the kernels that read them work on whole 16-byte pieces: a gradient that
+    reaches the backward as a channel slice of a wider buffer (pixel stride no multiple of four, base not 16-byte aligned)
+    used to fail with HN_EALIGN -- it is re-laid out instead.  Same gradients as for a dense copy of it."""
+    ops = _ops()
+    n, c, h, w = 2, 64, 12, 16
+    y, res = rnd(n, c, h, w, seed=195, scale=2.0), rnd(n, c, h, w, seed=196)
+    gamma, beta = rnd(c, seed=197).abs() + 0.5, rnd(c, seed=198) * 0.1
+    wide = rnd(n, c + 3, h, w, seed=199).to(dev).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for view in (True, False):
+        cl = torch.channels_last
+        yd = y.to(dev).contiguous(memory_format=cl).requires_grad_()
+        rd = res.to(dev).contiguous(memory_format=cl).requires_grad_()
+        gd, bd = gamma.to(dev).requires_grad_(), beta.to(dev).requires_grad_()
+        z = ops.bn_act(yd, None, gd, bd, torch.zeros(c, device=dev), torch.ones(c, device=dev), residual=rd, training=True,
+                       act=ops.ACT_RELU)
+        assert any(t is not None and t.dtype == torch.uint8 for t in z.grad_fn.saved_tensors)
+        gz = wide[:, 1:1 + c]  # pixel stride c + 3, base 4 bytes past a 16-byte boundary
+        assert gz.data_ptr() % 16 != 0 and ops.nhwc_ld(gz) == c + 3
+        z.backward(gz if view else gz.contiguous(memory_format=cl))
+        outs.append((yd.grad.clone(), rd.grad.clone(), gd.grad.clone(), bd.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("act", ["none", "leaky"])
 def test_overlap_knob_f16x2_weight_gradient(dev, act):
     """HEATNET_OVERLAP=1 (wgrad on a side stream beside dgrad) under f16x2: the operand scales the side stream reads -- found by

@@ -195,14 +195,14 @@ def test_gradient_tensors_match_reference_elementwise(golden_dir, adv, state):
         assert rel < 5e-3, (key, rel)
 
 
-@pytest.mark.parametrize("tag,late", [("late", True), ("early", False)])
+@pytest.mark.parametrize("tag,late", [("late", True), ("early", False), ("cert", False)])
 def test_resnext_oracle_matches_reference_fixture(golden_dir, tag, late):
     """oracle/resnext_ref.py (the ResNeXt-50 + ASPP "custom" architecture, cm/models/trgb_segnet.py:242-402) against the
     outputs of the reference's own module (make_golden.py --part resnext): state_dict keys and shapes, logits, loss, the five
     feature maps, the gradient norm of every parameter, BatchNorm running statistics."""
     from oracle import resnext_ref as R
     g = np.load(os.path.join(golden_dir, "resnext_%s_2x128x192.npz" % tag))
-    net = R.RefResNeXt(late_fusion=late)
+    net = R.RefResNeXt(late_fusion=late, cert_branch=(tag == "cert"))
     sd = net.state_dict()
     assert list(sd.keys()) == list(g["keys"])
     assert all(tuple(v.shape) == tuple(int(x) for x in sh[:v.dim()]) for v, sh in zip(sd.values(), g["shapes"]))
@@ -210,8 +210,13 @@ def test_resnext_oracle_matches_reference_fixture(golden_dir, tag, late):
     rgb, ir, lab = seeded_inputs(2, 128, 192, seed=23)
     net.train()
     seg, feats, cert = net(rgb, ir)
-    assert cert is None
+    assert (cert is None) == (tag != "cert")
     loss = torch.nn.functional.cross_entropy(seg, lab)
+    if tag == "cert":  # the certainty head and the trainer's certainty loss (cm/train_trgb_segnet_conf.py:482-491)
+        closs = R.cert_loss(seg, lab, cert)
+        assert float((cert.detach()[..., ::2, ::2] - torch.from_numpy(g["cert_sub"])).abs().max()) < 1e-4
+        assert abs(float(closs.detach()) - float(g["cert_loss"])) < 1e-5 * max(1.0, float(g["cert_loss"]))
+        loss = loss + closs
     loss.backward()
     assert float((seg.detach()[..., ::2, ::2] - torch.from_numpy(g["logits_sub"])).abs().max()) < 3e-4
     assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
