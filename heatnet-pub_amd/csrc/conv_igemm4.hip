@@ -79,13 +79,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
     conv_fill_rowinfo<BM>(p, rowinfo, m0, tid);
     __syncthreads();
     HN_STAMP(p, 1);
+    // The scale slot's words are REQUESTED here and reduced where they are first needed: behind the first operand DMAs when the
+    // accumulators start at zero (vector-memory operations return in order, so the request, issued ahead of the DMAs, costs them
+    // nothing and its latency hides behind their issue), in front of the addend loads otherwise.
+    unsigned slot_word = 0;
+    if constexpr (NPL == 2) slot_word = reinterpret_cast<const unsigned*>(p.a_scale)[(lane & (HN_SCALE_WORDS - 1)) * HN_SCALE_STRIDE];
     float o_s = 1.f, o_s2 = 1.f, i_s = 1.f, i_s2 = 1.f;
-    if constexpr (NPL == 2) {
-        float a_s, a_inv;
-        hn_h2_scales_of_slot(p.a_scale, a_s, a_inv);
-        o_s = a_inv; o_s2 = p.w_scale[1];  // applied one after the other (conv_common.h)
-        i_s = a_s; i_s2 = p.w_scale[0];
-    }
+    auto reduce_scales = [&] {
+        if constexpr (NPL == 2) {
+            float a_s, a_inv;
+            for (int o = 32; o > 0; o >>= 1) slot_word = max(slot_word, (unsigned)__shfl_xor((int)slot_word, o));
+            hn_h2_scales((unsigned)__builtin_amdgcn_readfirstlane((int)slot_word), a_s, a_inv);
+            o_s = a_inv; o_s2 = p.w_scale[1];  // applied one after the other (conv_common.h)
+            i_s = a_s; i_s2 = p.w_scale[0];
+        }
+    };
+    const bool has_addend = p.addend != nullptr;
+    if (has_addend) reduce_scales();
 
     HN_STAMP(p, 2);
     // ---- A operand: this lane's rows of the wave's 16-row blocks, source piece after the swizzle ------------------
@@ -213,11 +223,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    // the addend loads of conv_init_acc are vector-memory operations too: drain them before the counted waits start
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the addend loads of conv_init_acc are vector-memory operations too: drain them before the counted waits start (without an
+    // addend only the scale slot's request is in flight: it is older than every DMA, so the counted waits stay right)
+    if (has_addend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     barrier();  // rowinfo reads of every wave are done (init) before a DMA can reuse ... (rowinfo is not reused; keeps waves aligned)
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) dma_chunk(smem4 + s * T::STAGE);
+    if (!has_addend) reduce_scales();
     int st_cur = 0, st_free = NST - 1;  // stage of chunk kc; stage that becomes free at the barrier of step kc
     HN_STAMP(p, 3);
     for (int kc = 0; kc < nchunks; ++kc) {
