@@ -145,6 +145,7 @@ struct AccMap {
     static constexpr int NC = S16 ? 2 : 1;  // distinct columns a lane holds per 32-column block
     int wm, wn, lane, n0;
     __device__ __forceinline__ static int c2_of(int r) { return S16 ? (r >> 2) & 1 : 0; }
+    __device__ __forceinline__ static constexpr bool dead(int, int) { return false; }  // (a register that holds no output: never here)
     __device__ __forceinline__ int row(int i, int r) const {  // row inside the block tile
         return (wm * TM + i) * 32 + (S16 ? 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
     }
@@ -159,8 +160,8 @@ struct AccMap {
 // `iscale`, `iscale2` (f16x2: the two operand scales, powers of two): the accumulators live in the scaled domain.  The two
 // factors are applied one after the other -- their product can leave the fp32 range (a gradient of ~1e-30 against weights of
 // ~0.1: 2^114 * 2^17) and 0 * inf would turn a zero of the addend into NaN.
-template <int TM, int TN, bool S16>
-__device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[TM][TN], const AccMap<TM, TN, S16>& am,
+template <int TM, int TN, bool S16, class AM = AccMap<TM, TN, S16>>
+__device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[TM][TN], const AM& am,
                                               const int* rowinfo, int m0, float iscale = 1.f, float iscale2 = 1.f) {
     if (p.addend != nullptr && p.cps == 0) {
         const float* __restrict__ add = p.addend;
@@ -172,7 +173,7 @@ __device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[T
                 for (int r = 0; r < 16; ++r) {
                     const int row = am.row(i, r), col = am.col(j, am.c2_of(r));
                     float v = 0.f;
-                    if (m0 + row < p.M && col < p.K) v = add[(size_t)rowinfo[row * 4 + 3] * p.ldadd + col];
+                    if (!AM::dead(i, r) && m0 + row < p.M && col < p.K) v = add[(size_t)rowinfo[row * 4 + 3] * p.ldadd + col];
                     acc[i][j][r] = v * iscale * iscale2;
                 }
             }
@@ -193,11 +194,12 @@ __device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[T
 // in front of every store.
 // `oscale`, `oscale2` (f16x2: the inverse operand scales, powers of two, applied one after the other -- see conv_init_acc)
 // take the accumulators back to the tensor's own scale first.
-template <int TM, int TN, bool S16, int BM = 64 * TM, int BN = 64 * TN, bool SCALED = false, bool YB = false, bool BR = false>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], const AccMap<TM, TN, S16>& am,
+template <int TM, int TN, bool S16, int BM = 64 * TM, int BN = 64 * TN, bool SCALED = false, bool YB = false, bool BR = false,
+          class AM = AccMap<TM, TN, S16>>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], const AM& am,
                                               const int* rowinfo, int m0, int tile_m, int split, float oscale = 1.f,
                                               float oscale2 = 1.f) {
-    constexpr int NC = AccMap<TM, TN, S16>::NC;
+    constexpr int NC = AM::NC;
     const int lane = am.lane, n0 = am.n0;
     if constexpr (SCALED) {
 #pragma unroll
@@ -215,7 +217,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + am.row(i, r), col = am.col(j, am.c2_of(r));
-                    if (row < p.M && col < p.K) {
+                    if (!AM::dead(i, r) && row < p.M && col < p.K) {
                         const size_t opix = p.omap ? (size_t)rowinfo[(row - m0) * 4 + 3] : (size_t)row;
                         atomicAdd(p.y + opix * p.ldy + col, acc[i][j][r]);
                     }
@@ -260,7 +262,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                             int q = 0;
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
-                                if (am.c2_of(r) != c2) continue;
+                                if (am.c2_of(r) != c2 || AM::dead(i, r)) continue;
                                 const int row = min(m0 + am.row(i, r), p.M - 1);
                                 const size_t at = (size_t)row * p.br_ldy + cc;
                                 if constexpr (YBF) yv[i][q] = (float)reinterpret_cast<const __bf16*>(p.br_y)[at];
@@ -277,7 +279,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                             int q = 0;
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
-                                if (am.c2_of(r) != c2) continue;
+                                if (am.c2_of(r) != c2 || AM::dead(i, r)) continue;
                                 const bool in = (m0 + am.row(i, r) < p.M) && cok;
                                 bool on;
                                 if constexpr (BITS) on = (bb[i][q] >> (cc & 3)) & 1u;
@@ -336,7 +338,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                 for (int i = 0; i < TM; ++i) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        if (am.c2_of(r) != c2) continue;
+                        if (am.c2_of(r) != c2 || AM::dead(i, r)) continue;
                         const int row = m0 + am.row(i, r);
                         const float v = acc[i][j][r];
                         if (FULL || (row < p.M && cok)) {

@@ -30,6 +30,9 @@
 namespace hnconv {
 namespace {
 
+template <class T>
+constexpr int BM_BLOCKS() { return T::BM / 16; }
+
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voffset, unsigned soffset) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, soffset,
@@ -42,21 +45,41 @@ __device__ __forceinline__ int hsw(int t) { return (4 - t) & 3; }  // {0, 3, 2, 
 // WM x WN waves, each TM x TN blocks of 32 x 32 outputs; NST LDS stages; NPL planes per operand: 2 = f16x2 (hi / lo fp16, three
 // MFMAs per product), 1 = the mixed-precision bf16 arithmetic (ONE bf16 image per operand -- activations / gradients stored in
 // bf16 by the producing pass, plane 0 of the weight planes --, one v_mfma_f32_16x16x32_bf16 per product, no scales)
-template <int WM, int WN, int TM, int TN, int NST, int NPL = 2>
+// LIVE > 0: only the first LIVE 16-row blocks of the tile's WM * TM * 2 exist (BM = 16 * LIVE rows), dealt to the WM row waves in
+// turn (block g belongs to wave g % WM) so that every wave keeps the same number of them -- the 224-row tile below.
+template <int WM, int WN, int TM, int TN, int NST, int NPL = 2, int LIVE = 0>
 struct T4 {
-    static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN, NT = 64 * NW, BK = 32;
+    static constexpr int BM = LIVE > 0 ? LIVE * 16 : WM * TM * 32, BN = WN * TN * 32, NW = WM * WN, NT = 64 * NW, BK = 32;
     static constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;  // bytes
     static constexpr int A_BYTES = NPL * A_PLANE, B_BYTES = NPL * B_PLANE;
     static constexpr int STAGE = A_BYTES + B_BYTES;
-    static constexpr int QA = BM / 16 / NW, QB = BN / 16 / NW;  // 16-row blocks per wave and stage (per plane)
-    static constexpr int LDS = NST * STAGE + BM * 16;
-    static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "row blocks must divide over the waves");
+    static constexpr int QA = (BM / 16 + NW - 1) / NW, QB = BN / 16 / NW;  // 16-row blocks per wave and stage (per plane)
+    static constexpr int SINK = NST * STAGE + BM * 16;  // LIVE tiles: 1 KiB per wave for the DMAs of blocks that do not exist
+    static constexpr int LDS = SINK + (LIVE > 0 ? NW * 1024 : 0);
+    static_assert(LIVE > 0 || BM % (16 * NW) == 0, "row blocks must divide over the waves");
+    static_assert(BN % (16 * NW) == 0, "column blocks must divide over the waves");
+    static_assert(LIVE == 0 || (LIVE % WM == 0 && LIVE <= WM * TM * 2 && LIVE >= WM * (TM * 2 - 1)), "LIVE: whole rounds of blocks, at most the last one missing");
     static_assert(NPL * (QA + QB) * (NST - 2) < 64, "vmcnt immediate");
 };
 
-template <int WM, int WN, int TM, int TN, int NST, int NPL = 2>
+// accumulator map of a LIVE tile: 16-row block b of the wave (b = 2 * i + (r >> 3)) is block b * WM + wm of the tile
+template <int TM, int TN, int WM, int LIVE>
+struct AccMapI {
+    static constexpr int NC = 2;
+    int wm, wn, lane, n0;
+    __device__ __forceinline__ static int c2_of(int r) { return (r >> 2) & 1; }
+    __device__ __forceinline__ static constexpr bool dead(int i, int r) { return (2 * i + (r >> 3)) * WM >= LIVE; }
+    __device__ __forceinline__ int row(int i, int r) const {
+        return ((2 * i + (r >> 3)) * WM + wm) * 16 + 4 * (lane >> 4) + (r & 3);
+    }
+    __device__ __forceinline__ int col(int j, int c2) const { return n0 + (wn * TN + j) * 32 + 16 * c2 + (lane & 15); }
+};
+
+template <int WM, int WN, int TM, int TN, int NST, int NPL = 2, int LIVE = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_igemm4_kernel(const ConvArgs p) {
-    using T = T4<WM, WN, TM, TN, NST, NPL>;
+    using T = T4<WM, WN, TM, TN, NST, NPL, LIVE>;
+    using AM = std::conditional_t<(LIVE > 0), AccMapI<TM, TN, WM, LIVE>, AccMap<TM, TN, true>>;
+    constexpr int NBLK = BM_BLOCKS<T>();  // 16-row blocks of the tile
     constexpr int BM = T::BM, BN = T::BN, NW = T::NW, BK = T::BK, QA = T::QA, QB = T::QB;
     extern __shared__ __attribute__((aligned(16))) char smem4[];
     int* rowinfo = reinterpret_cast<int*>(smem4 + NST * T::STAGE);
@@ -112,8 +135,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
     int ahb[QA], awb[QA], aoff[QA];
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
-        const int r = (wave + NW * q) * 16 + l_row;
-        ahb[q] = rowinfo[r * 4 + 0];
+        const int blk = wave + NW * q;  // (LIVE tiles: the last round of blocks does not exist for every wave)
+        const int r = (blk < NBLK ? blk : 0) * 16 + l_row;
+        ahb[q] = blk < NBLK ? rowinfo[r * 4 + 0] : -0x40000000;
         awb[q] = rowinfo[r * 4 + 1];
         aoff[q] = (((rowinfo[r * 4 + 2] - nb0) + ahb[q] * p.W + awb[q]) * p.ldx + l_src * 8) * 2;
     }
@@ -140,7 +164,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
         for (int q = 0; q < QA; ++q) {
             const bool ok = live & ((unsigned)(ahb[q] + dh) < (unsigned)p.H) & ((unsigned)(awb[q] + dw) < (unsigned)p.W);
             const unsigned vo = ok ? (unsigned)(aoff[q] + doff) : a_records;
-            char* dst = stage + (wave + NW * q) * 1024;
+            // (a block past the tile's last -- LIVE tiles -- fetches nothing: an out-of-range DMA still WRITES its zeros, so it
+            // goes to a sink of its own; issued all the same, the counted waits assume the same number of DMAs from every wave)
+            char* dst = (wave + NW * q < NBLK) ? stage + (wave + NW * q) * 1024 : smem4 + T::SINK + wave * 1024;
             dma16(rsrc_a0, dst, vo, 0);
             if constexpr (NPL == 2) dma16(rsrc_a1, dst + T::A_PLANE, vo, 0);
         }
@@ -162,12 +188,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
         ++f_chunk;
     };
 
-    const AccMap<TM, TN, true> am{wm, wn, lane, n0};
+    const AM am{wm, wn, lane, n0};
     f32x16 acc[TM][TN];
-    conv_init_acc<TM, TN, true>(p, acc, am, rowinfo, m0, i_s, i_s2);
+    conv_init_acc<TM, TN, true, AM>(p, acc, am, rowinfo, m0, i_s, i_s2);
 
     const int frag = (lane & 15) * 64 + (((lane >> 4) ^ hsw((lane >> 2) & 3)) * 16);
-    const int a_frag = wm * TM * 32 * 64 + frag;
+    const int a_frag = (LIVE > 0 ? wm * 16 * 64 : wm * TM * 32 * 64) + frag;  // (LIVE: the wave's blocks are WM blocks apart)
+    constexpr int A_STEP = (LIVE > 0 ? WM : 1) * 16 * 64, NBI = LIVE > 0 ? LIVE / WM : 2 * TM;
     const int b_frag = T::A_BYTES + wn * TN * 32 * 64 + frag;
     auto mfma_phase = [&](const char* st) {
         using frag_t = std::conditional_t<NPL == 2, f16x8, bf16x8>;
@@ -178,10 +205,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
             for (int s2 = 0; s2 < NPL; ++s2)
                 fb[bj][s2] = *reinterpret_cast<const frag_t*>(st + b_frag + s2 * T::B_PLANE + bj * 16 * 64);
 #pragma unroll
-        for (int bi = 0; bi < 2 * TM; ++bi) {
+        for (int bi = 0; bi < NBI; ++bi) {
             frag_t fa[NPL];
 #pragma unroll
-            for (int s2 = 0; s2 < NPL; ++s2) fa[s2] = *reinterpret_cast<const frag_t*>(st + a_frag + s2 * T::A_PLANE + bi * 16 * 64);
+            for (int s2 = 0; s2 < NPL; ++s2) fa[s2] = *reinterpret_cast<const frag_t*>(st + a_frag + s2 * T::A_PLANE + bi * A_STEP);
             // per accumulator the order is lo*hi, hi*lo, hi*hi (as in conv_igemm.hip); consecutive MFMAs go to different
             // accumulators
             f32x4 c[2 * TN];
@@ -247,7 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last, out-of-range DMAs)
     HN_STAMP(p, 6);
 
-    conv_epilogue<TM, TN, true, BM, BN, NPL == 2, NPL == 1, true>(p, acc, am, rowinfo, m0, tile_m, 0, o_s, o_s2);
+    conv_epilogue<TM, TN, true, BM, BN, NPL == 2, NPL == 1, true, AM>(p, acc, am, rowinfo, m0, tile_m, 0, o_s, o_s2);
 #ifdef HN_STAMPS
     HN_STAMP(p, 7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -256,11 +283,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_ige
 #endif
 }
 
-template <int WM, int WN, int TM, int TN, int NST, int NPL = 2>
+template <int WM, int WN, int TM, int TN, int NST, int NPL = 2, int LIVE = 0>
 int launch4(const ConvArgs& a, hipStream_t stream) {
-    using T = T4<WM, WN, TM, TN, NST, NPL>;
+    using T = T4<WM, WN, TM, TN, NST, NPL, LIVE>;
     static std::atomic<unsigned long long> configured{0};
-    if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm4_kernel<WM, WN, TM, TN, NST, NPL>), T::LDS, configured) != HN_OK)
+    if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm4_kernel<WM, WN, TM, TN, NST, NPL, LIVE>), T::LDS, configured) != HN_OK)
         return HN_ELAUNCH;
     ConvArgs p = a;
 #ifdef HN_STAMPS
@@ -271,7 +298,7 @@ int launch4(const ConvArgs& a, hipStream_t stream) {
     static const int gm_env = getenv("HN_GROUP_M") ? atoi(getenv("HN_GROUP_M")) : 0;  // experiment knob
     p.gm = gm_env > 0 ? gm_env : (p.ntn >= (T::BN >= 256 ? 4 : 8) ? 8 : 1);
     if (p.gm > p.ntm) p.gm = p.ntm;
-    HN_LAUNCH((conv_igemm4_kernel<WM, WN, TM, TN, NST, NPL>), dim3(p.ntm * p.ntn), dim3(T::NT), T::LDS, stream, p);
+    HN_LAUNCH((conv_igemm4_kernel<WM, WN, TM, TN, NST, NPL, LIVE>), dim3(p.ntm * p.ntn), dim3(T::NT), T::LDS, stream, p);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -286,9 +313,12 @@ bool conv4_covers(const ConvArgs& a) {
 }
 
 // tile: 0 = 128 x 128 (four waves, two workgroups per CU), 1 = 128 x 64 (four waves 4 x 1), 2 = 128 x 256 (eight waves, three
-// stages, one workgroup per CU), 3 = 256 x 128 (eight waves 4 x 2, three stages); 7 = 256 x 256 (eight waves 2 x 4 with 128 x 64
-// wave tiles, two stages of 64 KB: half the operand bytes per multiply-add of the 128 x 128 tile -- the K loop of the smaller
-// tiles is bound by what a CU can pull out of its L2, tools/probes/dma_line_probe.hip, tools/stamp_conv.py);
+// stages, one workgroup per CU), 3 = 256 x 128 (eight waves 4 x 2, three stages); 7 = 224 x 256 (eight waves 2 x 4, each row wave
+// SEVEN 16-row blocks of the fourteen, dealt in turn -- T4<.., LIVE = 14> --, two stages of 60 KB).  Two reasons: fewer operand
+// bytes per multiply-add than the 128-row tiles (their K loop is bound by what a CU can pull out of its L2,
+// tools/probes/dma_line_probe.hip, tools/stamp_conv.py), and the HEIGHT: 8 x 40 x 88 = 28160 = 125.7 x 224 rows and 8 x 80 x 176
+// = 502.9 x 224, so the layers on those maps make 126 / 503 row tiles -- with 2, 4 or 8 column tiles a whole number of rounds
+// on 256 CUs (0.98, 1.97, 3.94) where 128-row tiles make 1.72 / 3.44 / 6.9;
 // 4 = 128 x 64, 5 = 64 x 128, 6 = 64 x 64 with
 // THREE (6: four) stages and two workgroups per CU: the DMA runs two (three) K steps ahead -- for the layers whose K steps
 // carry little matrix work per byte (1x1 convolutions with few channels on one side), where a distance of one step leaves
@@ -302,7 +332,7 @@ int launch_conv4(const ConvArgs& a, int tile, hipStream_t stream) {
             case 4: return launch4<4, 1, 1, 2, 4, 1>(a, stream);
             case 5: return launch4<2, 2, 1, 2, 4, 1>(a, stream);
             case 6: return launch4<2, 2, 1, 1, 4, 1>(a, stream);
-            case 7: return launch4<2, 4, 4, 2, 3, 1>(a, stream);
+            case 7: return launch4<2, 4, 4, 2, 3, 1, 14>(a, stream);
             default: return launch4<2, 2, 2, 2, 3, 1>(a, stream);
         }
     }
@@ -313,7 +343,7 @@ int launch_conv4(const ConvArgs& a, int tile, hipStream_t stream) {
         case 4: return launch4<4, 1, 1, 2, 3>(a, stream);
         case 5: return launch4<2, 2, 1, 2, 3>(a, stream);
         case 6: return launch4<2, 2, 1, 1, 4>(a, stream);
-        case 7: return launch4<2, 4, 4, 2, 2>(a, stream);
+        case 7: return launch4<2, 4, 4, 2, 2, 2, 14>(a, stream);
         default: return launch4<2, 2, 2, 2, 2>(a, stream);
     }
 }
@@ -321,25 +351,25 @@ int launch_conv4(const ConvArgs& a, int tile, hipStream_t stream) {
 const char* conv4_kernel_name(int tile, bool bf16) {
     if (bf16) {
         switch (tile) {
-            case 1: return "conv_igemm4_kernel<4, 1, 1, 2, 3, 1>";
-            case 2: return "conv_igemm4_kernel<2, 4, 2, 2, 4, 1>";
-            case 3: return "conv_igemm4_kernel<4, 2, 2, 2, 4, 1>";
-            case 4: return "conv_igemm4_kernel<4, 1, 1, 2, 4, 1>";
-            case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 4, 1>";
-            case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4, 1>";
-            case 7: return "conv_igemm4_kernel<2, 4, 4, 2, 3, 1>";
-            default: return "conv_igemm4_kernel<2, 2, 2, 2, 3, 1>";
+            case 1: return "conv_igemm4_kernel<4, 1, 1, 2, 3, 1, 0>";
+            case 2: return "conv_igemm4_kernel<2, 4, 2, 2, 4, 1, 0>";
+            case 3: return "conv_igemm4_kernel<4, 2, 2, 2, 4, 1, 0>";
+            case 4: return "conv_igemm4_kernel<4, 1, 1, 2, 4, 1, 0>";
+            case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 4, 1, 0>";
+            case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4, 1, 0>";
+            case 7: return "conv_igemm4_kernel<2, 4, 4, 2, 3, 1, 14>";
+            default: return "conv_igemm4_kernel<2, 2, 2, 2, 3, 1, 0>";
         }
     }
     switch (tile) {
-        case 1: return "conv_igemm4_kernel<4, 1, 1, 2, 2, 2>";
-        case 2: return "conv_igemm4_kernel<2, 4, 2, 2, 3, 2>";
-        case 3: return "conv_igemm4_kernel<4, 2, 2, 2, 3, 2>";
-        case 4: return "conv_igemm4_kernel<4, 1, 1, 2, 3, 2>";
-        case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 3, 2>";
-        case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4, 2>";
-        case 7: return "conv_igemm4_kernel<2, 4, 4, 2, 2, 2>";
-        default: return "conv_igemm4_kernel<2, 2, 2, 2, 2, 2>";
+        case 1: return "conv_igemm4_kernel<4, 1, 1, 2, 2, 2, 0>";
+        case 2: return "conv_igemm4_kernel<2, 4, 2, 2, 3, 2, 0>";
+        case 3: return "conv_igemm4_kernel<4, 2, 2, 2, 3, 2, 0>";
+        case 4: return "conv_igemm4_kernel<4, 1, 1, 2, 3, 2, 0>";
+        case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 3, 2, 0>";
+        case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4, 2, 0>";
+        case 7: return "conv_igemm4_kernel<2, 4, 4, 2, 2, 2, 14>";
+        default: return "conv_igemm4_kernel<2, 2, 2, 2, 2, 2, 0>";
     }
 }
 
