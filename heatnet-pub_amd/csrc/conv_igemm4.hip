@@ -27,6 +27,15 @@
 
 #include "conv_common.h"
 
+// Register budget of the four-wave kernels, as "workgroups per CU" for __launch_bounds__: 2 = 256 registers per lane (what the LDS
+// allows anyway); 3 = 168 -- still two workgroups per CU (LDS), but a third of the register file stays free, so the HBM-bound
+// kernels of the other stream (the second encoder, weight gradients) can share a CU with a convolution instead of waiting for
+// one of its workgroups to retire.  The K loop needs ~140 registers (no spills there at 168); the epilogue spills 90-150 dwords
+// per tile.  Measured inside the step: -0.14 ms (gpurun_out/r4/ab9: 38.04 38.15 38.09 against 38.15 38.26 38.31).
+#ifndef HN_C4_OCC
+#define HN_C4_OCC 3
+#endif
+
 namespace hnconv {
 namespace {
 
@@ -76,7 +85,7 @@ struct AccMapI {
 };
 
 template <int WM, int WN, int TM, int TN, int NST, int NPL = 2, int LIVE = 0>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_igemm4_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? HN_C4_OCC : 1) void conv_igemm4_kernel(const ConvArgs p) {
     using T = T4<WM, WN, TM, TN, NST, NPL, LIVE>;
     using AM = std::conditional_t<(LIVE > 0), AccMapI<TM, TN, WM, LIVE>, AccMap<TM, TN, true>>;
     constexpr int NBLK = BM_BLOCKS<T>();  // 16-row blocks of the tile

@@ -248,11 +248,23 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const SmallArgs p) {
         stem_load_patch<CIN>(p, patch, img, ho0, wo0);
         __syncthreads();
         const int ho = ho0 + wv;  // wave wv: output row ho0 + wv, 16 groups of 4 consecutive columns
-        for (int grp = 0; grp < STEM_TW / 4; ++grp) {
+        // dy of a group is needed by its first MFMA: fetched PF groups ahead (a load in front of every group left the matrix
+        // pipe idle for the whole memory latency, 16 times per tile: the kernel ran at a quarter of its arithmetic time)
+        constexpr int PF = 4, NG = STEM_TW / 4;
+        auto load_dy = [&](int grp) {
             const int wo = wo0 + 4 * grp + kk;
-            const bool pok = ho < p.Ho && wo < p.Wo;
-            const long long pix = ((long long)img * p.Ho + ho) * p.Wo + wo;
-            const f32x4 gv = pok ? *reinterpret_cast<const f32x4*>(p.dy + pix * p.ldy + 4 * n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool pok = grp < NG && ho < p.Ho && wo < p.Wo;
+            const long long pix = ((long long)img * p.Ho + (ho < p.Ho ? ho : 0)) * p.Wo + (pok ? wo : 0);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.dy + pix * p.ldy + 4 * n);  // (unconditional, clamped: no queue drain)
+            return pok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        f32x4 ring[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) ring[i] = load_dy(i);
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp) {
+            const f32x4 gv = ring[grp % PF];
+            ring[grp % PF] = load_dy(grp + PF);
             const int pbase = (2 * wv * STEM_PW + 2 * (4 * grp + kk)) * CIN;
 #pragma unroll
             for (int b = 0; b < S::KB; ++b) {

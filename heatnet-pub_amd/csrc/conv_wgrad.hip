@@ -771,21 +771,24 @@ __device__ __forceinline__ int x3_piece_at(int k, int pp) {
 }
 
 // NPL = 1: the mixed-precision bf16 arithmetic on one bf16 image per operand (no scales, one MFMA per product).
-template <int TM, int TN, int NST = 2, int NPL = 2>
-__global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) {
-    constexpr int BKP = 32;
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+// WM x WN waves, each TM x TN blocks of 32 x 32: 2 x 2 waves (two workgroups per CU) up to 128 x 128; 2 x 4 waves with 4 x 2 blocks
+// = 256 x 256 (one workgroup per CU, two stages of 64 KB): half the operand bytes per multiply-add -- the reduction loop of the
+// smaller tiles is bound by what a CU can pull out of its L2, like the forward kernels' (DESIGN.md section 6, round 4).
+template <int TM, int TN, int NST = 2, int NPL = 2, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void conv_wgrad4_kernel(const WgradArgs p) {
+    constexpr int BKP = 32, NW = WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int PLANE_A = BKP * BM * 2, PLANE_B = BKP * BN * 2;  // bytes per 16-bit plane
     constexpr int STAGE = NPL * (PLANE_A + PLANE_B);
     constexpr int ROWS_A = 1024 / (2 * BM), ROWS_B = 1024 / (2 * BN);  // pixel rows one 1-KiB DMA covers
     constexpr int PPR_A = BM / 8, PPR_B = BN / 8;                       // 16-byte pieces per pixel row
-    constexpr int QA = BKP / ROWS_A / 4, QB = BKP / ROWS_B / 4;         // DMA row groups per wave, plane and stage
+    constexpr int QA = BKP / ROWS_A / NW, QB = BKP / ROWS_B / NW;         // DMA row groups per wave, plane and stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int tiles = p.ntm * p.ntn;
     const int logical = hn_xcd_remap(blockIdx.x, gridDim.x);
     const int split = logical / tiles, tile = logical - split * tiles;
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) 
     unsigned a_voff[QA];
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
-        const int k = (wave + 4 * q) * ROWS_A + lane / PPR_A;
+        const int k = (wave + NW * q) * ROWS_A + lane / PPR_A;
         const int cp = x3_piece_at<BM>(k, lane % PPR_A);
         const bool ok = co0 + cp * 8 < p.K;
         a_voff[q] = ok ? (unsigned)((k * p.ldy + co0 + cp * 8) * 2) : dy_records;
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) 
     long long xoff[QB];  // fp16-element offset of (pixel, channel piece)
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
-        const int k = (wave + 4 * q) * ROWS_B + lane / PPR_B;
+        const int k = (wave + NW * q) * ROWS_B + lane / PPR_B;
         const int cp = x3_piece_at<BN>(k, lane % PPR_B);
         const int pix = c_begin * BKP + k;
         const int n = pix / hw, rem = pix - n * hw;
@@ -854,16 +857,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad4_kernel(const WgradArgs p) 
         for (int q = 0; q < QA; ++q) {
             const unsigned off = a_voff[q] + adv;
             const unsigned vo = (off < a_voff[q] || !live) ? 0xFFFFFFFFu : off;
-            char* dst = st + (wave + 4 * q) * 1024;
+            char* dst = st + (wave + NW * q) * 1024;
             wg_dma16(rsrc_d0, dst, vo);
             if constexpr (NPL == 2) wg_dma16(rsrc_d1, dst + PLANE_A, vo);
         }
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
-            const int k = (wave + 4 * q) * ROWS_B + lane / PPR_B;
+            const int k = (wave + NW * q) * ROWS_B + lane / PPR_B;
             const bool ok = live & (p0 + k < p.M) & ((unsigned)hq[q] < (unsigned)p.H) & ((unsigned)wq[q] < (unsigned)p.W);
             const unsigned vo = ok ? (unsigned)(xoff[q] * 2) : x_records;
-            char* dst = st + NPL * PLANE_A + (wave + 4 * q) * 1024;
+            char* dst = st + NPL * PLANE_A + (wave + NW * q) * 1024;
             wg_dma16(rsrc_x0, dst, vo);
             if constexpr (NPL == 2) wg_dma16(rsrc_x1, dst + PLANE_B, vo);
             wo_[q] += BKP;
@@ -1057,6 +1060,37 @@ int launch_wgrad(WgradArgs a, int split_k, hipStream_t stream) {
     return HN_OK;
 }
 
+// 256 x 256 tile of the plane-tensor kernel (eight waves, one workgroup per CU): Cout % 256 == 0, Cin % 256 == 0
+int launch_wgrad4_huge(WgradArgs a, int split_k, hipStream_t stream) {
+    constexpr int BM = 256, BN = 256, BKP = 32;
+    constexpr int lds = 2 * 2 * BKP * (BM + BN) * 2;
+    const void* kern = reinterpret_cast<const void*>(conv_wgrad4_kernel<4, 2, 2, 2, 2, 4>);
+    static std::atomic<unsigned long long> configured{0};
+    if (hn_ensure_dynamic_lds(kern, lds, configured) != HN_OK) return HN_ELAUNCH;
+    a.ntm = (a.K + BM - 1) / BM;
+    a.ntn = (a.Kdim + BN - 1) / BN;
+    const int tiles = a.ntm * a.ntn;
+    const int total_chunks = (a.M + BKP - 1) / BKP;
+    if (split_k <= 0) {  // whole rounds of the 256 workgroups the chip holds (as launch_wgrad: 0 / -1 two rounds, -2 one, -3 / -4: 3 / 4)
+        const int code = split_k;
+        const int rounds = code == -2 ? 1 : code == -3 ? 3 : code == -4 ? 4 : code == -5 ? 6 : 2;
+        split_k = (256 * rounds) / tiles;
+        const int cap = (total_chunks * BKP / 32 + 3) / 4;
+        if (split_k > cap) split_k = cap;
+        if (split_k < 1) split_k = 1;
+    }
+    if (split_k > total_chunks) split_k = total_chunks;
+    a.chunks_per_split = (total_chunks + split_k - 1) / split_k;
+    split_k = (total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    a.atomic = (split_k > 1 || a.accumulate) && a.slab == nullptr;
+    if (a.atomic && !a.dw_zeroed && !a.accumulate) {
+        if (hipMemsetAsync(a.dw, 0, (size_t)a.K * a.Kdim * sizeof(float), stream) != hipSuccess) return HN_ELAUNCH;
+    }
+    HN_LAUNCH((conv_wgrad4_kernel<4, 2, 2, 2, 2, 4>), dim3(tiles * split_k), dim3(512), lds, stream, a);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
 template <int MODE, int BKP, int X3 = 0>
 int dispatch_wgrad(const WgradArgs& a, bool wide_m, bool wide_n, int split_k, hipStream_t s) {
     if (wide_m)
@@ -1172,7 +1206,8 @@ int wgrad_planes_impl(const void* xh, long long xh_plane, const float* x_scale, 
         d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->dil <= 0 || d->pad < 0 || d->ldx < d->Cin || d->ldy < d->Cout)
         return HN_EINVAL;
     const int tm_sel = (variant >> 2) & 3, tn_sel = (variant >> 4) & 3;
-    if (tm_sel == 3 || tn_sel == 3) return HN_EINVAL;
+    const bool huge = tm_sel == 3 && tn_sel == 3;  // the 256 x 256 tile (f16x2 planes only)
+    if ((tm_sel == 3 || tn_sel == 3) && !huge) return HN_EINVAL;
     WgradArgs a;
     a.x = nullptr; a.dy = nullptr; a.dw = dw;
     a.xh = static_cast<const unsigned short*>(xh); a.dyh = static_cast<const unsigned short*>(dyh);
@@ -1195,6 +1230,10 @@ int wgrad_planes_impl(const void* xh, long long xh_plane, const float* x_scale, 
                     hn_aligned16(dyh) && xh_plane % 8 == 0 && dyh_plane % 8 == 0 && a.x_bytes < 0xFFFF0000ll &&
                     a.dy_bytes + 64ll * d->ldy * 2 < 0xFFFF0000ll;
     if (!ok) return HN_ESHAPE;
+    if (huge) {
+        if (bf16 || d->Cout % 256 != 0 || d->Cin % 256 != 0) return HN_ESHAPE;
+        return launch_wgrad4_huge(a, split_k, static_cast<hipStream_t>(stream));
+    }
     bool wide_m = d->Cout % 128 == 0, wide_n = d->Cin % 128 == 0;
     if (tm_sel == 1) wide_m = false;
     if (tn_sel == 1) wide_n = false;
@@ -1250,10 +1289,13 @@ extern "C" int hn_conv2d_wgrad_plan(const HnConvDesc* d, int mode, int variant, 
     if (mode == 2) {
         if (d->Cin % 64 != 0 || d->Cout % 64 != 0) return HN_ESHAPE;
         const bool wm = d->Cout % 128 == 0 && tm_sel != 1, wn = d->Cin % 128 == 0 && tn_sel != 1;
-        if (math_sel == 3)  // the one-plane bf16 arithmetic
-            snprintf(name, name_len, "conv_wgrad4_kernel<%d, %d, %d, 1>", wm ? 2 : 1, wn ? 2 : 1, bk_sel == 2 ? 4 : 3);
+        if (tm_sel == 3 && tn_sel == 3) {
+            if (math_sel == 3 || d->Cout % 256 != 0 || d->Cin % 256 != 0) return HN_ESHAPE;
+            snprintf(name, name_len, "conv_wgrad4_kernel<4, 2, 2, 2, 2, 4>");
+        } else if (math_sel == 3)  // the one-plane bf16 arithmetic
+            snprintf(name, name_len, "conv_wgrad4_kernel<%d, %d, %d, 1, 2, 2>", wm ? 2 : 1, wn ? 2 : 1, bk_sel == 2 ? 4 : 3);
         else
-            snprintf(name, name_len, "conv_wgrad4_kernel<%d, %d, %d, 2>", wm ? 2 : 1, wn ? 2 : 1, (bk_sel == 2 && !(wm && wn)) ? 3 : 2);
+            snprintf(name, name_len, "conv_wgrad4_kernel<%d, %d, %d, 2, 2, 2>", wm ? 2 : 1, wn ? 2 : 1, (bk_sel == 2 && !(wm && wn)) ? 3 : 2);
         return HN_OK;
     }
     bool wide_m = d->Cout > 64;

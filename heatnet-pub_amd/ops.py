@@ -852,6 +852,11 @@ SMALL_KERNELS = os.environ.get("HEATNET_SMALL_KERNELS", "1") != "0"
 # they stay built and tested but are off unless HEATNET_SMALL_STEM=1.  The head kernels are on: weight gradient 0.35 -> 0.15 ms,
 # data gradient 0.21 -> 0.12 ms.
 SMALL_STEM = os.environ.get("HEATNET_SMALL_STEM", "0") == "1"
+# Round 4: the stem WEIGHT GRADIENT fetches dy four pixel groups ahead (a load in front of every group had left the matrix pipe
+# idle for a memory latency sixteen times per tile): 0.34 -> 0.28 ms for the RGB stem alone, and with its 70-120 registers per
+# lane the kernel shares a CU with the other encoder stream's kernels -- the step got 0.25 ms shorter (gpurun_out/r4/ab7).  On by
+# default, independently of the forward kernel (which stays behind HEATNET_SMALL_STEM: 0.23 against 0.14 ms generic).
+SMALL_STEM_WGRAD = os.environ.get("HEATNET_SMALL_STEM_WGRAD", "1") != "0"
 
 
 def _stem_geometry(d):
@@ -979,7 +984,10 @@ class _Conv2d(torch.autograd.Function):
         ctx.lm = lm
         ctx.x_scale = None
         ctx.small = None
-        if SMALL_KERNELS and SMALL_STEM and _stem_geometry(d) and b is None and act == ACT_NONE and want_stats is not True:
+        if SMALL_KERNELS and SMALL_STEM_WGRAD and _stem_geometry(d):
+            ctx.small = "stem"  # (the weight gradient; the forward below only with HEATNET_SMALL_STEM)
+        stem_fwd = SMALL_KERNELS and SMALL_STEM and _stem_geometry(d) and b is None and act == ACT_NONE and want_stats is not True
+        if stem_fwd:
             # 7x7 / stride-2 stem with 1, 3 or 4 input channels: its own fp32-MFMA streaming kernel (csrc/conv_small.hip)
             ctx.small = "stem"
             with _ConvTimer("fwd", d, "stem_fwd_kernel<%d>" % cin):
@@ -999,7 +1007,7 @@ class _Conv2d(torch.autograd.Function):
             def launch(v, st):
                 check(lib.hn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(wx3), _ptr(b), _ptr(y), _ptr(st), ctypes.byref(d), act, slope,
                                         v, s), "hn_conv2d_fwd")
-        if ctx.small is None:
+        if ctx.small is None or (ctx.small == "stem" and not stem_fwd):
             if SMALL_KERNELS and _narrow_geometry(d):
                 ctx.small = "narrow"  # (13-class head: forward on the generic kernel -- already at its HBM time --, backward below)
             var = _pick(_kind("fwd", lm), d, _igemm_candidates(cout, "fwd", cin, lm), lambda v: launch(v, None))
@@ -1571,7 +1579,14 @@ def _wgrad_plane_candidates(cout, cin, bf16=False):
             # bk 2: f16x2 -- three LDS stages instead of two (not on the 128 x 128 tile); bf16 -- four instead of three
             for bk in ((0, 2) if (bf16 or not wide) else (0,)):
                 cands += [(split, bk + 4 * tm + 16 * tn) for split in (0, -2, -3, -4)]
+    if WGRAD_HUGE and not bf16 and cout % 256 == 0 and cin % 256 == 0:
+        cands += [(split, 4 * 3 + 16 * 3) for split in (0, -2, -3, -4)]  # 256 x 256, eight waves (conv_wgrad4_kernel<4, 2, 2, 2, 2, 4>)
     return cands
+
+
+# Offer the 256 x 256 weight-gradient tile to the tuner.  Built, bitwise-tested, taken by the tuner for the long 3x3 layers in
+# isolation -- and the step measured 0.1 ms SLOWER with it (gpurun_out/r4/ab8: 38.12 38.01 38.20 against 37.94 37.94 38.15): off.
+WGRAD_HUGE = os.environ.get("HEATNET_WGRAD_HUGE", "0") == "1"
 
 
 def fused_conv_bn_ok(x, conv_w, stride, pad, dil, bn_training, shape=None):

@@ -209,6 +209,13 @@ def test_wgrad_planes_bitwise(dev, case):
                    "wgrad_planes")
         assert torch.equal(dw0v, dw1), (tm, tn)
         assert torch.equal(dw0, dw1)  # (tilings agree bitwise as well)
+    if cin % 256 == 0 and cout % 256 == 0:  # the 256 x 256 eight-wave tile (variant 60)
+        dw1 = torch.full_like(dw0, float("nan"))
+        _lib.check(lib.hn_conv2d_wgrad_planes(P(xh), xplane, P(xs), P(gh), gplane, P(gs), P(dw1), ctypes.byref(d), 1, 60, 0, s),
+                   "wgrad_planes 256 x 256")
+        assert torch.equal(dw0, dw1)
+    else:
+        assert lib.hn_conv2d_wgrad_planes(P(xh), xplane, P(xs), P(gh), gplane, P(gs), P(dw1), ctypes.byref(d), 1, 60, 0, s) == -4
     # default split: float atomics
     dw2 = torch.empty_like(dw0)
     _lib.check(lib.hn_conv2d_wgrad_planes(P(xh), xplane, P(xs), P(gh), gplane, P(gs), P(dw2), ctypes.byref(d), 0, 0, 0, s), "split")

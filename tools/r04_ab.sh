@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of two builds of the kernel library on one box (GPU box): alternating headline runs, then per-shape conv tables.
 #   bash tools/r04_ab.sh <tag> [old_lib]     old_lib defaults to heatnet-pub_amd/lib/libheatnet_hip_r3.so
-#   NEWENV="VAR=val ..." applies to the runs of the new library, ROUNDS (default 3) = alternations
+#   NEWENV="VAR=val ..." / OLDENV="..." apply to the runs of the new / old library, ROUNDS (default 3) = alternations
 root="$GRAFT_REPO_ROOT"; [ -z "$root" ] && root=$(pwd)
 tag=${1:-ab}; old=${2:-$root/heatnet-pub_amd/lib/libheatnet_hip_r3.so}
 out="$root/gpurun_out/r4/$tag"; mkdir -p "$out"
@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$root" || exit 1
 B="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-other-workloads --no-roofline"
 val() { python3 -c "import json,sys; b=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1].split('/')[-1], b['value'], b['ms_per_step'])" "$1"; }
 new() { env $NEWENV HEATNET_TUNE_CACHE=$out/tune_new.json "$@"; }
-oldr() { env HEATNET_BIG_TILE=0 HEATNET_HIP_LIB=$old HEATNET_TUNE_CACHE=$out/tune_old.json "$@"; }
+oldr() { env $OLDENV HEATNET_HIP_LIB=$old HEATNET_TUNE_CACHE=$out/tune_old.json "$@"; }
 new $B > $out/new0.json 2> $out/err.log || exit 1
 oldr $B > $out/old0.json 2>> $out/err.log || exit 1
 for i in $(seq 1 ${ROUNDS:-3}); do
