@@ -82,6 +82,91 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     }
 }
 
+// The same two kernels for DENSE rows (ld == C, lddl == C: the segmentation head's output): a thread's row is C consecutive floats
+// 4 C bytes from its neighbour's, so per-thread row loads reach memory as C strided dword instructions -- 135 us for the 112 MB of
+// the headline step's logits and labels, 6 x the HBM time.  Here a block stages 256 rows (one contiguous run of 256 C floats)
+// through LDS with coalesced dword accesses, both ways; a thread reads its row at stride C floats (any odd C: conflict-free).
+__global__ __launch_bounds__(256) void ce_fwd_dense_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                          int64_t npix, int C, int64_t ignore, float* __restrict__ out,
+                                                          const float* __restrict__ weight) {
+    __shared__ float red[4];
+    __shared__ float tile[256 * MAXC];
+    float loss = 0.f, cnt = 0.f;
+    const int64_t nchunks = (npix + 255) / 256;
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int64_t p0 = chunk * 256;
+        const int rows = (int)min((int64_t)256, npix - p0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < rows * C; i += 256) tile[i] = logits[p0 * C + i];
+        __syncthreads();
+        const int64_t pix = p0 + threadIdx.x;
+        if ((int)threadIdx.x >= rows) continue;
+        if (weight != nullptr) cnt += 1.f;  // mean over every pixel of the map
+        const int64_t lab = labels[pix];
+        if (lab == ignore || lab < 0 || lab >= C) continue;
+        const float* row = tile + threadIdx.x * C;
+        float v[MAXC];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) { v[c] = row[c]; mx = fmaxf(mx, v[c]); }
+        float se = 0.f, xl = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) { se += expf(v[c] - mx); if (c == (int)lab) xl = v[c]; }
+        loss += ((mx + logf(se)) - xl) * (weight != nullptr ? weight[pix] : 1.f);
+        if (weight == nullptr) cnt += 1.f;
+    }
+    const float l = block_sum(loss, red);
+    const float n = block_sum(cnt, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(out + 0, l);
+        atomicAdd(out + 1, n);
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_dense_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                          int64_t npix, int C, int64_t ignore, const float* __restrict__ out,
+                                                          const float* __restrict__ gout, float* __restrict__ dl,
+                                                          const float* __restrict__ weight) {
+    __shared__ float tile[256 * MAXC];
+    const float cnt = out[1];
+    const float g0 = cnt > 0.f ? gout[0] / cnt : 0.f;
+    const int64_t nchunks = (npix + 255) / 256;
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int64_t p0 = chunk * 256;
+        const int rows = (int)min((int64_t)256, npix - p0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < rows * C; i += 256) tile[i] = logits[p0 * C + i];
+        __syncthreads();
+        if ((int)threadIdx.x < rows) {
+            const int64_t pix = p0 + threadIdx.x;
+            const int64_t lab = labels[pix];
+            float* row = tile + threadIdx.x * C;  // (only this thread touches its row between the barriers)
+            if (lab == ignore || lab < 0 || lab >= C) {
+                for (int c = 0; c < C; ++c) row[c] = 0.f;
+            } else {
+                const float g = weight != nullptr ? g0 * weight[pix] : g0;
+                float v[MAXC];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < C) { v[c] = row[c]; mx = fmaxf(mx, v[c]); }
+                float se = 0.f;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < C) { v[c] = expf(v[c] - mx); se += v[c]; }
+                const float inv = g / se;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < C) row[c] = v[c] * inv - (c == (int)lab ? g : 0.f);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < rows * C; i += 256) dl[p0 * C + i] = tile[i];
+    }
+}
+
 // Night-supervision teacher outputs (cm/train_trgb_segnet_conf.py:430-434, 468-472): p = softmax(logits) per pixel;
 // label = argmax p (first maximum); cert = max softmax(p) -- the reference applies softmax to the already normalised
 // probabilities (`cert = softmax(out_night_ir_only)` where out_night_ir_only is itself a softmax output), restated as is.
@@ -295,8 +380,12 @@ extern "C" int hn_ce_fwd(const float* logits, int ld, const int64_t* labels, int
     if (!logits || !labels || !out || npix <= 0 || C <= 0 || C > MAXC || ld < C) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(out, 0, 2 * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
-    HN_LAUNCH(ce_fwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, ignore_index, out,
-              static_cast<const float*>(nullptr));
+    if (ld == C)
+        HN_LAUNCH(ce_fwd_dense_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, labels, npix, C, ignore_index, out,
+                  static_cast<const float*>(nullptr));
+    else
+        HN_LAUNCH(ce_fwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, ignore_index, out,
+                  static_cast<const float*>(nullptr));
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -306,7 +395,8 @@ extern "C" int hn_ce_weighted_fwd(const float* logits, int ld, const int64_t* la
     if (!logits || !labels || !weight || !out || npix <= 0 || C <= 0 || C > MAXC || ld < C) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(out, 0, 2 * sizeof(float), s) != hipSuccess) return HN_ELAUNCH;
-    HN_LAUNCH(ce_fwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, (int64_t)-100, out, weight);
+    if (ld == C) HN_LAUNCH(ce_fwd_dense_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, labels, npix, C, (int64_t)-100, out, weight);
+    else HN_LAUNCH(ce_fwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, (int64_t)-100, out, weight);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -315,8 +405,12 @@ extern "C" int hn_ce_weighted_bwd(const float* logits, int ld, const int64_t* la
                                   const float* out, const float* gout, float* dlogits, int lddl, void* stream) {
     if (!logits || !labels || !weight || !out || !gout || !dlogits || npix <= 0 || C <= 0 || C > MAXC || ld < C || lddl < C)
         return HN_EINVAL;
-    HN_LAUNCH(ce_bwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, static_cast<hipStream_t>(stream), logits, ld, labels, npix, C,
-              (int64_t)-100, out, gout, dlogits, lddl, weight);
+    if (ld == C && lddl == C)
+        HN_LAUNCH(ce_bwd_dense_kernel, dim3(flat_grid(npix)), dim3(256), 0, static_cast<hipStream_t>(stream), logits, labels, npix, C,
+                  (int64_t)-100, out, gout, dlogits, weight);
+    else
+        HN_LAUNCH(ce_bwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, static_cast<hipStream_t>(stream), logits, ld, labels, npix, C,
+                  (int64_t)-100, out, gout, dlogits, lddl, weight);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }
@@ -334,8 +428,12 @@ extern "C" int hn_ce_bwd(const float* logits, int ld, const int64_t* labels, int
     if (!logits || !labels || !out || !gout || !dlogits || npix <= 0 || C <= 0 || C > MAXC || ld < C || lddl < C)
         return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    HN_LAUNCH(ce_bwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, ignore_index, out,
-                       gout, dlogits, lddl, static_cast<const float*>(nullptr));
+    if (ld == C && lddl == C)
+        HN_LAUNCH(ce_bwd_dense_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, labels, npix, C, ignore_index, out, gout,
+                  dlogits, static_cast<const float*>(nullptr));
+    else
+        HN_LAUNCH(ce_bwd_kernel, dim3(flat_grid(npix)), dim3(256), 0, s, logits, ld, labels, npix, C, ignore_index, out,
+                  gout, dlogits, lddl, static_cast<const float*>(nullptr));
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

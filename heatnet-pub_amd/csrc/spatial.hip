@@ -308,9 +308,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
 }
 
 // ---- exact x2 upsampling (the decoder's F.upsample before every PSPUpsample conv, cm/models/pspnet.py:36) ----------
-// One thread-iteration owns one INPUT pixel: it reads the 3x3 input neighbourhood once and produces the 2x2 output pixels
-// (2h..2h+1, 2w..2w+1) with the generic weights (bilinear_src: the border clamps come out identically) -- a quarter of
-// the index arithmetic and 9 instead of 16 loads per four outputs.
+// An INPUT pixel's 3x3 neighbourhood produces its 2x2 output pixels (2h..2h+1, 2w..2w+1) with the generic weights
+// (bilinear_src: the border clamps come out identically).
 typedef _Float16 h16x4s __attribute__((ext_vector_type(4)));
 
 // PL: the output is written as a plane tensor (hi / lo fp16 images, include/heatnet_hip.h) with the scale of `slot` -- the
@@ -323,18 +322,30 @@ __global__ __launch_bounds__(256) void bilinear_up2_fwd_kernel(const float* __re
     if constexpr (PL) { if (slot != nullptr) hn_h2_scales_of_slot(slot, ps, pi); }
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (c >= C) return;
-    const int64_t npix = (int64_t)N * H * W;
+    // a thread-iteration owns a 2 x 2 block of input pixels: its 4 x 4 (clamped) neighbourhood is read once -- 16 loads for
+    // sixteen outputs where the one-pixel form read 9 per four; every output is the same expression of the same operands
+    const int Hb = (H + 1) / 2, Wb = (W + 1) / 2;
+    const int64_t nblk = (int64_t)N * Hb * Wb;
     const int Wo = 2 * W;
-    HN_PIX_LOOP(npix) {
-        const int w = (int)(pix % W);
-        const int64_t t = pix / W;
-        const int h = (int)(t % H), n = (int)(t / H);
-        const int hr[3] = {max(h - 1, 0), h, min(h + 1, H - 1)}, wc[3] = {max(w - 1, 0), w, min(w + 1, W - 1)};
-        float g[3][3][V];
+    HN_PIX_LOOP(nblk) {
+        const int wb = (int)(pix % Wb);
+        const int64_t t = pix / Wb;
+        const int hb = (int)(t % Hb), n = (int)(t / Hb);
+        const int hq = 2 * hb, wq = 2 * wb;
+        float g[4][4][V];
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) ldv<V>(x + ((int64_t)(n * H + hr[a]) * W + wc[b]) * ldx + c, g[a][b]);
+            for (int b = 0; b < 4; ++b) {
+                const int hr = min(max(hq - 1 + a, 0), H - 1), wc = min(max(wq - 1 + b, 0), W - 1);
+                ldv<V>(x + ((int64_t)(n * H + hr) * W + wc) * ldx + c, g[a][b]);
+            }
+#pragma unroll
+        for (int pi_ = 0; pi_ < 2; ++pi_)
+#pragma unroll
+        for (int pj = 0; pj < 2; ++pj) {
+        const int h = hq + pi_, w = wq + pj;
+        if (h >= H || w >= W) continue;
         // output row 2h+dh reads neighbourhood rows (dh, dh+1) = input rows (h-1, h) / (h, h+1); at the borders the clamped
         // row repeats and bilinear_src's weights (1, 0 at the top / left edge) make the sum the same value as the generic
         // kernel's
@@ -350,8 +361,8 @@ __global__ __launch_bounds__(256) void bilinear_up2_fwd_kernel(const float* __re
                 bilinear_src(2 * w + dw, 0.5f, W, w0, w1, lw0, lw1);
 #pragma unroll
                 for (int i = 0; i < V; ++i)
-                    o[i] = lh0 * (lw0 * g[dh][dw][i] + lw1 * g[dh][dw + 1][i]) +
-                           lh1 * (lw0 * g[dh + 1][dw][i] + lw1 * g[dh + 1][dw + 1][i]);
+                    o[i] = lh0 * (lw0 * g[pi_ + dh][pj + dw][i] + lw1 * g[pi_ + dh][pj + dw + 1][i]) +
+                           lh1 * (lw0 * g[pi_ + dh + 1][pj + dw][i] + lw1 * g[pi_ + dh + 1][pj + dw + 1][i]);
                 const int64_t opix = ((int64_t)(n * 2 * H + 2 * h + dh) * Wo + 2 * w + dw);
                 if constexpr (PL) {
                     unsigned short* dst = yh + opix * ldy + c;
@@ -379,45 +390,79 @@ __global__ __launch_bounds__(256) void bilinear_up2_fwd_kernel(const float* __re
                 }
             }
         }
+        }
     }
 }
 
-// gradient of the exact x2 upsampling: input pixel (h, w) is read by output rows 2h-1 .. 2h+2 and the same four columns
+// gradient of the exact x2 upsampling: input pixel (h, w) is read by output rows 2h-1 .. 2h+2 and the same four columns.  A
+// thread-iteration owns a 2 x 2 block of INPUT pixels: their 4 x 4 windows overlap in a 6 x 6 patch of dy, read once (36 loads
+// for four results instead of 64 -- the one-pixel form moved four times the tensor through the L1 and ran at half the HBM rate),
+// row by row: the two horizontal sums of a row, then their share in the two rows of results.  Gather form, fixed order.
 template <int V>
 __global__ __launch_bounds__(256) void bilinear_up2_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx,
                                                               int lddx, int N, int H, int W, int C) {
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (c >= C) return;
-    const int64_t npix = (int64_t)N * H * W;
+    const int Hb = (H + 1) / 2, Wb = (W + 1) / 2;
+    const int64_t nblk = (int64_t)N * Hb * Wb;
     const int Ho = 2 * H, Wo = 2 * W;
-    HN_PIX_LOOP(npix) {
-        const int w = (int)(pix % W);
-        const int64_t t = pix / W;
-        const int h = (int)(t % H), n = (int)(t / H);
-        float wh[4], ww[4];
+    HN_PIX_LOOP(nblk) {
+        const int wb = (int)(pix % Wb);
+        const int64_t t = pix / Wb;
+        const int hb = (int)(t % Hb), n = (int)(t / Hb);
+        const int h0 = 2 * hb, w0 = 2 * wb;
+        float ww[2][6];  // weight of dy column 2 w0 - 1 + b in result column w0 + j (zero: not a source, outside, no such result)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ho = 2 * h - 1 + k, wo = 2 * w - 1 + k;
-            wh[k] = (ho >= 0 && ho < Ho) ? bilinear_weight(ho, h, 0.5f, H) : 0.f;
-            ww[k] = (wo >= 0 && wo < Wo) ? bilinear_weight(wo, w, 0.5f, W) : 0.f;
-        }
-        float acc[V];
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < V; ++i) acc[i] = 0.f;
+            for (int k = 0; k < 6; ++k) {
+                const int wo = 2 * w0 - 1 + k;
+                ww[j][k] = (wo >= 0 && wo < Wo && w0 + j < W) ? bilinear_weight(wo, w0 + j, 0.5f, W) : 0.f;
+            }
+        float acc[2][2][V];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int ho = min(max(2 * h - 1 + a, 0), Ho - 1);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int wo = min(max(2 * w - 1 + b, 0), Wo - 1);
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[i][j][e] = 0.f;
+        // a real loop over the six rows (six loads in flight per thread): unrolled, the 36 loads are hoisted together, take 144
+        // registers and the occupancy an HBM-bound kernel lives on
+#pragma unroll 1
+        for (int a = 0; a < 6; ++a) {
+            const int hu = 2 * h0 - 1 + a;
+            const bool rin = hu >= 0 && hu < Ho;
+            const float wh0 = rin ? bilinear_weight(hu, h0, 0.5f, H) : 0.f;
+            const float wh1 = (rin && h0 + 1 < H) ? bilinear_weight(hu, h0 + 1, 0.5f, H) : 0.f;
+            const int ho = min(max(hu, 0), Ho - 1);
+            float rs[2][V];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < V; ++e) rs[j][e] = 0.f;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const int wo = min(max(2 * w0 - 1 + b, 0), Wo - 1);
                 float g[V];
                 ldv<V>(dy + ((int64_t)(n * Ho + ho) * Wo + wo) * lddy + c, g);
-                const float k = wh[a] * ww[b];  // zero for clamped (out-of-range) taps
 #pragma unroll
-                for (int i = 0; i < V; ++i) acc[i] += k * g[i];
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) rs[j][e] += ww[j][b] * g[e];  // (zero for clamped / foreign columns)
             }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    acc[0][j][e] += wh0 * rs[j][e];
+                    acc[1][j][e] += wh1 * rs[j][e];
+                }
         }
-        stv<V>(dx + pix * lddx + c, acc);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (h0 + i < H && w0 + j < W) stv<V>(dx + ((int64_t)(n * H + h0 + i) * W + w0 + j) * lddx + c, acc[i][j]);
     }
 }
 
@@ -577,6 +622,140 @@ bool bad_geom(int N, int H, int W, int C, int Ho, int Wo, int lda, int ldb) {
 
 }  // namespace
 
+// ---- backward of the pyramid merge in two passes over ONE read of the gradient -------------------------------------------
+// out = relu(main + sum_k up(prior_k)).  The gradient of every prior is a bilinear down-gather of du = dout * [out > 0] over the
+// whole map; done level by level (hn_bilinear_bwd: one block per prior pixel) each of the four levels read the 115 MB of du
+// again at a quarter of the HBM rate (4 x 84 us in the headline step).  The bilinear weights are separable:
+//   d prior_k[n, i, j] = sum_h wh_k(h, i) * ( sum_w ww_k(w, j) * du[n, h, w] ).
+// Pass 1 (one thread-iteration per row (n, h) and channel piece): reads dout and out once, writes du, and sums every row into
+// the pw_k column bins of every level -- the source column of a level moves on monotonically with w, so two running
+// accumulators per level (the current bin and its right neighbour) suffice; S_k[n][h][j][c] goes to a workspace (N H sum(pw_k) C
+// floats).  Pass 2: the column of row sums of every prior pixel, weighted (gather form, fixed order: bitwise reproducible).
+namespace {
+struct PyramidBwdArgs {
+    float* dp[8];   // gradient of prior k: [N][h_k][w_k][ld_k]
+    int h[8], w[8], ld[8];
+    int soff[8];    // column-bin offset of level k inside a row of the workspace ([N][H][sum w_k][C])
+    int count, sumw;
+};
+
+template <int V>
+__global__ __launch_bounds__(256) void pyramid_merge_bwd_rows_kernel(const float* __restrict__ dout, int lddo,
+                                                                    const float* __restrict__ out, int ldo, float* __restrict__ du,
+                                                                    int lddu, PyramidBwdArgs a, float* __restrict__ S, int N, int H,
+                                                                    int W, int C, int nseg, int segw) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (c >= C) return;
+    const int64_t nitems = (int64_t)N * H * nseg;  // a row is cut into nseg segments of segw columns (more threads in flight)
+    HN_PIX_LOOP(nitems) {
+        const int seg = (int)(pix % nseg);
+        const int64_t row = pix / nseg;
+        const int w_lo = seg * segw, w_hi = min(W, w_lo + segw);
+        float accA[8][V], accB[8][V];
+        int cur[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int j1;
+            float l0, l1;
+            cur[k] = 0;
+            if (k < a.count && w_lo < w_hi) bilinear_src(w_lo, (float)a.w[k] / (float)W, a.w[k], cur[k], j1, l0, l1);
+#pragma unroll
+            for (int e = 0; e < V; ++e) accA[k][e] = accB[k][e] = 0.f;
+        }
+        float* srow = S + (row * nseg + seg) * a.sumw * C + c;  // this segment's own slice: [row][seg][bins][C]
+        for (int w = w_lo; w < w_hi; ++w) {
+            float g[V], o[V], d[V];
+            const int64_t at = row * W + w;
+            ldv<V>(dout + at * lddo + c, g);
+            ldv<V>(out + at * ldo + c, o);
+#pragma unroll
+            for (int e = 0; e < V; ++e) d[e] = o[e] > 0.f ? g[e] : 0.f;
+            stv<V>(du + at * lddu + c, d);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k >= a.count) continue;
+                int j0, j1;
+                float l0, l1;
+                bilinear_src(w, (float)a.w[k] / (float)W, a.w[k], j0, j1, l0, l1);
+                if (j0 != cur[k]) {  // the source column moved on (by one: W >= w_k): bin cur[k] is complete
+                    stv<V>(srow + (a.soff[k] + cur[k]) * C, accA[k]);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        accA[k][e] = accB[k][e];
+                        accB[k][e] = 0.f;
+                    }
+                    cur[k] = j0;
+                }
+                if (j1 == j0) {  // (clamped at the last column: both weights on the same bin)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) accA[k][e] += (l0 + l1) * d[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        accA[k][e] += l0 * d[e];
+                        accB[k][e] += l1 * d[e];
+                    }
+                }
+            }
+        }
+        if (w_lo < w_hi) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k >= a.count) continue;
+                stv<V>(srow + (a.soff[k] + cur[k]) * C, accA[k]);
+                if (cur[k] + 1 < a.w[k]) stv<V>(srow + (a.soff[k] + cur[k] + 1) * C, accB[k]);
+            }
+        }
+    }
+}
+
+// Pass 2.  Segment `seg` of a row wrote the bins from j0(first column) to min(j0(last column) + 1, w_k - 1) of level k and
+// nothing else: exactly those slices are read.
+template <int V>
+__global__ __launch_bounds__(256) void pyramid_merge_bwd_cols_kernel(PyramidBwdArgs a, const float* __restrict__ S, int N, int H,
+                                                                    int W, int C, int nseg, int segw) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (c >= C) return;
+    int64_t total = 0;
+    for (int k = 0; k < a.count; ++k) total += (int64_t)N * a.h[k] * a.w[k];
+    HN_PIX_LOOP(total) {
+        int k = 0;
+        int64_t rem = pix;
+        while (rem >= (int64_t)N * a.h[k] * a.w[k]) {
+            rem -= (int64_t)N * a.h[k] * a.w[k];
+            ++k;
+        }
+        const int ph = a.h[k], pw = a.w[k];
+        const int j = (int)(rem % pw);
+        const int64_t t = rem / pw;
+        const int i = (int)(t % ph), n = (int)(t / ph);
+        const float sh = (float)ph / (float)H, sw = (float)pw / (float)W;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int seg = 0; seg < nseg; ++seg) {
+            const int w_lo = seg * segw, w_hi = min(W, w_lo + segw);
+            if (w_lo >= w_hi) continue;
+            int f0, f1, g0, g1;
+            float l0, l1;
+            bilinear_src(w_lo, sw, pw, f0, f1, l0, l1);
+            bilinear_src(w_hi - 1, sw, pw, g0, g1, l0, l1);
+            if (j < f0 || j > min(g0 + 1, pw - 1)) continue;  // this segment never touched bin j
+            for (int h = 0; h < H; ++h) {
+                const float wh = bilinear_weight(h, i, sh, ph);
+                if (wh == 0.f) continue;
+                float g[V];
+                ldv<V>(S + ((((int64_t)n * H + h) * nseg + seg) * a.sumw + a.soff[k] + j) * C + c, g);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] += wh * g[e];
+            }
+        }
+        stv<V>(a.dp[k] + rem * a.ld[k] + c, acc);
+    }
+}
+
+}  // namespace
+
 #define HN_LAUNCH_V(plan, kern, ...)                                                                     \
     do {                                                                                                 \
         if ((plan).V == 4) HN_LAUNCH((kern<4>), (plan).grid, (plan).block, 0, s, __VA_ARGS__);  \
@@ -637,7 +816,7 @@ extern "C" int hn_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N
     if (!x || !y || bad_geom(N, Hin, Win, C, Hout, Wout, ldx, ldy)) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (Hout == 2 * Hin && Wout == 2 * Win) {
-        const RowLaunch p2 = plan_rows((int64_t)N * Hin * Win, C, {x, y}, {ldx, ldy});
+        const RowLaunch p2 = plan_rows((int64_t)N * ((Hin + 1) / 2) * ((Win + 1) / 2), C, {x, y}, {ldx, ldy});  // per 2 x 2 input block
         HN_LAUNCH_V(p2, bilinear_up2_fwd_kernel, x, ldx, y, ldy, N, Hin, Win, C);
         HN_CHECK_LAUNCH();
         return HN_OK;
@@ -655,7 +834,8 @@ extern "C" int hn_bilinear_up2_planes(const float* x, int ldx, const float* slot
     if (plane_elems < ((int64_t)N * 4 * Hin * Win - 1) * ldp + C) return HN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool v4 = (reinterpret_cast<uintptr_t>(y_planes) & 7u) == 0 && plane_elems % 4 == 0 && ldp % 4 == 0;
-    const RowLaunch p2 = plan_rows((int64_t)N * Hin * Win, C, {x, v4 ? nullptr : reinterpret_cast<const void*>(uintptr_t(1))}, {ldx});
+    const RowLaunch p2 = plan_rows((int64_t)N * ((Hin + 1) / 2) * ((Win + 1) / 2), C,
+                                   {x, v4 ? nullptr : reinterpret_cast<const void*>(uintptr_t(1))}, {ldx});
     unsigned short* yh = static_cast<unsigned short*>(y_planes);
     if (p2.V == 4)
         HN_LAUNCH((bilinear_up2_fwd_kernel<4, true>), p2.grid, p2.block, 0, s, x, ldx, (float*)nullptr, ldp, N, Hin, Win, C, yh,
@@ -679,12 +859,13 @@ extern "C" int hn_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, i
         HN_CHECK_LAUNCH();
         return HN_OK;
     }
-    const RowLaunch pl = plan_rows(ipix, C, {dy, dx}, {lddy, lddx});
-    if (Hout == 2 * Hin && Wout == 2 * Win) {
-        HN_LAUNCH_V(pl, bilinear_up2_bwd_kernel, dy, lddy, dx, lddx, N, Hin, Win, C);
+    if (Hout == 2 * Hin && Wout == 2 * Win) {  // a thread-iteration per 2 x 2 block of input pixels
+        const RowLaunch pb2 = plan_rows((int64_t)N * ((Hin + 1) / 2) * ((Win + 1) / 2), C, {dy, dx}, {lddy, lddx});
+        HN_LAUNCH_V(pb2, bilinear_up2_bwd_kernel, dy, lddy, dx, lddx, N, Hin, Win, C);
         HN_CHECK_LAUNCH();
         return HN_OK;
     }
+    const RowLaunch pl = plan_rows(ipix, C, {dy, dx}, {lddy, lddx});
     HN_LAUNCH_V(pl, bilinear_bwd_kernel, dy, lddy, dx, lddx, N, Hin, Win, C, Hout, Wout, sh, sw);
     HN_CHECK_LAUNCH();
     return HN_OK;
@@ -710,6 +891,52 @@ extern "C" int hn_pyramid_merge_fwd(const float* mainp, int ldm, int n_priors, c
     hipStream_t s = static_cast<hipStream_t>(stream);
     const RowLaunch pl = plan_rows((int64_t)N * H * W, C, {mainp, out, aligned ? nullptr : (const void*)1}, {ldm, ldo});
     HN_LAUNCH_V(pl, pyramid_merge_kernel, mainp, ldm, a, out, ldo, N, H, W, C, relu);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+// segments a row is cut into (workspace: N * H * segments * sum(w_k) * C floats)
+extern "C" int hn_pyramid_merge_bwd_segments(int N, int H, int W) {
+    int nseg = (int)((1536 + (int64_t)N * H - 1) / ((int64_t)N * H));
+    nseg = nseg < 1 ? 1 : (nseg > 8 ? 8 : nseg);
+    return nseg > W ? W : nseg;
+}
+
+extern "C" int hn_pyramid_merge_bwd(const float* dout, int lddo, const float* out, int ldo, float* du, int lddu, int n_priors,
+                                    float* const* dps, const int* hs, const int* ws, const int* lds, float* workspace, int N,
+                                    int H, int W, int C, void* stream) {
+    if (!dout || !out || !du || !workspace || n_priors <= 0 || n_priors > 8 || !dps || !hs || !ws || !lds || N <= 0 || H <= 0 ||
+        W <= 0 || C <= 0 || lddo < C || ldo < C || lddu < C)
+        return HN_EINVAL;
+    PyramidBwdArgs a;
+    a.count = n_priors;
+    a.sumw = 0;
+    bool aligned = hn_aligned16(workspace);
+    for (int k = 0; k < 8; ++k) {
+        a.dp[k] = k < n_priors ? dps[k] : nullptr;
+        a.h[k] = k < n_priors ? hs[k] : 1;
+        a.w[k] = k < n_priors ? ws[k] : 1;
+        a.ld[k] = k < n_priors ? lds[k] : 4;
+        a.soff[k] = a.sumw;
+        if (k < n_priors) {
+            if (!dps[k] || hs[k] <= 0 || ws[k] <= 0 || lds[k] < C) return HN_EINVAL;
+            if (hs[k] > H || ws[k] > W) return HN_ESHAPE;  // priors are upsampled: the running-bin scheme needs w_k <= W
+            a.sumw += ws[k];
+            aligned = aligned && hn_aligned16(dps[k]) && (lds[k] % 4 == 0);
+        }
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nseg = hn_pyramid_merge_bwd_segments(N, H, W);
+    const int segw = (W + nseg - 1) / nseg;
+    const RowLaunch pr = plan_rows((int64_t)N * H * nseg, C, {dout, out, du, aligned ? nullptr : (const void*)1}, {lddo, ldo, lddu});
+    HN_LAUNCH_V(pr, pyramid_merge_bwd_rows_kernel, dout, lddo, out, ldo, du, lddu, a, workspace, N, H, W, C, nseg, segw);
+    HN_CHECK_LAUNCH();
+    int64_t total = 0;
+    for (int k = 0; k < n_priors; ++k) total += (int64_t)N * hs[k] * ws[k];
+    RowLaunch pc = plan_rows(total, C, {aligned ? nullptr : (const void*)1}, {});
+    pc.V = pr.V;  // (the workspace rows were written with that vector width's alignment assumptions)
+    if (pc.V == 4) HN_LAUNCH((pyramid_merge_bwd_cols_kernel<4>), pc.grid, pc.block, 0, s, a, workspace, N, H, W, C, nseg, segw);
+    else HN_LAUNCH((pyramid_merge_bwd_cols_kernel<1>), pc.grid, pc.block, 0, s, a, workspace, N, H, W, C, nseg, segw);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

@@ -2154,6 +2154,9 @@ def bilinear(x, size):
     return _inherit_scale(_Bilinear.apply(x, int(size[0]), int(size[1])), x)
 
 
+PYRAMID_BWD_FUSED = os.environ.get("HEATNET_PYRAMID_BWD_FUSED", "1") != "0"  # A/B knob
+
+
 class _PyramidMerge(torch.autograd.Function):
     """relu(main + sum_i bilinear_up(prior_i)): see hn_pyramid_merge_fwd."""
 
@@ -2183,6 +2186,20 @@ class _PyramidMerge(torch.autograd.Function):
         n, c, h, w = out.shape
         s = _stream()
         du = new_nhwc(n, c, h, w, out.device)
+        k = len(ctx.sizes)
+        if (PYRAMID_BWD_FUSED and k > 0 and all(ctx.needs_input_grad[1:1 + k]) and all(ph <= h and pw <= w for ph, pw in ctx.sizes)):
+            # one read of dout for du AND every prior's gradient (hn_pyramid_merge_bwd): level by level, hn_bilinear_bwd read the
+            # 115 MB of du four more times at a quarter of the HBM rate
+            dps = [new_nhwc(n, c, ph, pw, out.device) for ph, pw in ctx.sizes]
+            ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in dps])
+            hs = (ctypes.c_int * k)(*[ph for ph, _ in ctx.sizes])
+            ws = (ctypes.c_int * k)(*[pw for _, pw in ctx.sizes])
+            lds = (ctypes.c_int * k)(*[c] * k)
+            nseg = lib.hn_pyramid_merge_bwd_segments(n, h, w)
+            wsp = torch.empty(n * h * nseg * sum(pw for _, pw in ctx.sizes) * c, device=out.device, dtype=torch.float32)
+            check(lib.hn_pyramid_merge_bwd(_ptr(dout), ldd, _ptr(out), c, _ptr(du), c, k, ptrs, hs, ws, lds, _ptr(wsp), n, h, w, c, s),
+                  "hn_pyramid_merge_bwd")
+            return (du,) + tuple(dps)
         check(lib.hn_act_bwd(_ptr(dout), ldd, _ptr(out), c, _ptr(du), c, n * h * w, c, ACT_RELU, 0.0, s), "hn_act_bwd")
         grads = [du]
         for i, (ph, pw) in enumerate(ctx.sizes):

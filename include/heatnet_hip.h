@@ -477,6 +477,16 @@ int hn_pyramid_merge_fwd(const float* main, int ldm, int n_priors, const float* 
                          const int* ws, const int* lds, float* out, int ldo, int N, int H, int W, int C, int relu,
                          void* stream);
 
+/* Backward of hn_pyramid_merge_fwd (relu = 1) in two passes over ONE read of the gradient: du = dout * [out > 0] is written
+ * ([N*H*W][lddu]) and every prior's gradient dps[k] ([N][hs[k]][ws[k]][lds[k]], written) is the bilinear down-gather of du --
+ * row sums into column bins first (workspace: N * H * hn_pyramid_merge_bwd_segments(N, H, W) * sum(ws) * C floats, contents
+ * irrelevant on entry), then the weighted column of row sums.  Gather form, fixed order: bitwise reproducible.  Priors are
+ * upsampled (hs[k] <= H, ws[k] <= W), at most 8. */
+int hn_pyramid_merge_bwd_segments(int N, int H, int W);
+int hn_pyramid_merge_bwd(const float* dout, int lddo, const float* out, int ldo, float* du, int lddu, int n_priors,
+                         float* const* dps, const int* hs, const int* ws, const int* lds, float* workspace, int N, int H, int W,
+                         int C, void* stream);
+
 /* dx[n,h,w,c] = sum over levels l of adaptive_avg_pool2d backward of dys[l] ([N, hos[l], wos[l], C], row stride lds[l])
  * at input size H x W: the gradient of the four pyramid poolings of PSPModule (cm/models/pspnet.py:22-24,30) written in
  * one pass.  n_levels <= 8.  dx is overwritten. */

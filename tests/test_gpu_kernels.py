@@ -253,6 +253,37 @@ def test_pyramid_pool_fused_backward(dev, shape):
     close(xd2.grad, xr.grad, atol=1e-6, rtol=1e-5, what="dx(level 2 only)")
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 40, 88), (1, 12, 7, 9), (3, 8, 24, 40), (2, 64, 6, 6)])
+def test_pyramid_merge_forward_and_fused_backward(dev, shape):
+    """ops.pyramid_merge = relu(main + sum_k bilinear_up(prior_k)) (reference pspnet.py:22-25 after the bottleneck was applied per
+    level) against stock torch on the CPU; the backward through hn_pyramid_merge_bwd (one read of the gradient: du and every
+    prior's gradient from row sums, then columns of row sums) and, with the knob off, level by level through hn_bilinear_bwd."""
+    ops = _ops()
+    n, c, h, w = shape
+    sizes = (1, 2, 3, 6)
+    main = rnd(n, c, h, w, seed=31)
+    priors = [rnd(n, c, s, s, seed=32 + s) for s in sizes]
+    gy = rnd(n, c, h, w, seed=39)
+    mr = main.double().requires_grad_()
+    pr = [p.double().requires_grad_() for p in priors]
+    ref = F.relu(mr + sum(F.interpolate(p, size=(h, w), mode="bilinear", align_corners=False) for p in pr))
+    ref.backward(gy.double())
+    prev = ops.PYRAMID_BWD_FUSED
+    try:
+        for fused in (True, False):
+            ops.PYRAMID_BWD_FUSED = fused
+            md = main.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+            pd = [p.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_() for p in priors]
+            out = ops.pyramid_merge(md, pd)
+            close(out, ref.detach().float(), atol=2e-6, rtol=1e-5, what="out")
+            out.backward(gy.to(dev))
+            close(md.grad, mr.grad.float(), atol=1e-6, rtol=1e-5, what="dmain fused=%s" % fused)
+            for a, b, s in zip(pd, pr, sizes):
+                close(a.grad, b.grad.float(), atol=2e-5 * float(b.grad.abs().max()), rtol=1e-5, what="dprior%d fused=%s" % (s, fused))
+    finally:
+        ops.PYRAMID_BWD_FUSED = prev
+
+
 def test_bn_accumulators_recover_from_an_interrupted_step(dev):
     """The per-layer double accumulators must be zero when a kernel starts adding into them.  If an exception interrupts a
     step between the producer (conv epilogue / backward reduction) and the consumer that re-zeroes them, the host-side
