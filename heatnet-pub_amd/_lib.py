@@ -114,6 +114,7 @@ SIGNATURES = {
     "hn_conv2d_plan": [c_int, DP, c_int, c_int, ctypes.c_char_p, c_int],
     "hn_pyramid_merge_bwd_segments": [c_int, c_int, c_int],
     "hn_pyramid_merge_bwd": [P, c_int, P, c_int, P, c_int, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "hn_pyramid_pool_fwd": [P, c_int, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "hn_pyramid_pool_bwd": [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "hn_ce_fwd": [P, c_int, P, c_i64, c_int, c_i64, P, P],
     "hn_ce_bwd": [P, c_int, P, c_i64, c_int, c_i64, P, P, P, c_int, P],

@@ -754,6 +754,108 @@ __global__ __launch_bounds__(256) void pyramid_merge_bwd_cols_kernel(PyramidBwdA
     }
 }
 
+
+// ---- the adaptive average poolings of all pyramid levels from ONE read of the map --------------------------------------------
+// Level by level (hn_adaptive_avgpool_fwd: one block per bin) the four levels read the 231 MB of the encoder output four times.
+// Same two passes as the merge's backward: pass 1 sums every row segment into the column bins of every level (a column lies in
+// one bin, or in two where bins overlap -- the bin it FIRST lies in moves on monotonically, so two running sums per level),
+// pass 2 adds the rows of a bin and divides by its area.  The PyramidBwdArgs fields are used as: dp = the pooled outputs.
+template <int V>
+__global__ __launch_bounds__(256) void pyramid_pool_fwd_rows_kernel(const float* __restrict__ x, int ldx, PyramidBwdArgs a,
+                                                                   float* __restrict__ S, int N, int H, int W, int C, int nseg,
+                                                                   int segw) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (c >= C) return;
+    const int64_t nitems = (int64_t)N * H * nseg;
+    HN_PIX_LOOP(nitems) {
+        const int seg = (int)(pix % nseg);
+        const int64_t row = pix / nseg;
+        const int w_lo = seg * segw, w_hi = min(W, w_lo + segw);
+        if (w_lo >= w_hi) continue;
+        float accA[8][V], accB[8][V];
+        int cur[8];  // first bin whose end lies behind the current column
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            cur[k] = 0;
+            if (k < a.count)
+                while (bin_end(cur[k], W, a.w[k]) <= w_lo) ++cur[k];
+#pragma unroll
+            for (int e = 0; e < V; ++e) accA[k][e] = accB[k][e] = 0.f;
+        }
+        float* srow = S + (row * nseg + seg) * a.sumw * C + c;
+        for (int w = w_lo; w < w_hi; ++w) {
+            float v[V];
+            ldv<V>(x + (row * W + w) * ldx + c, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k >= a.count) continue;
+                if (bin_end(cur[k], W, a.w[k]) <= w) {  // bin cur[k] is complete (bins are at least one column wide: one step)
+                    stv<V>(srow + (a.soff[k] + cur[k]) * C, accA[k]);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        accA[k][e] = accB[k][e];
+                        accB[k][e] = 0.f;
+                    }
+                    ++cur[k];
+                }
+                const bool second = cur[k] + 1 < a.w[k] && bin_start(cur[k] + 1, W, a.w[k]) <= w;  // overlapping neighbour
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    accA[k][e] += v[e];
+                    if (second) accB[k][e] += v[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k >= a.count) continue;
+            stv<V>(srow + (a.soff[k] + cur[k]) * C, accA[k]);
+            if (cur[k] + 1 < a.w[k]) stv<V>(srow + (a.soff[k] + cur[k] + 1) * C, accB[k]);
+        }
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void pyramid_pool_fwd_cols_kernel(PyramidBwdArgs a, const float* __restrict__ S, int N, int H,
+                                                                   int W, int C, int nseg, int segw) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (c >= C) return;
+    int64_t total = 0;
+    for (int k = 0; k < a.count; ++k) total += (int64_t)N * a.h[k] * a.w[k];
+    HN_PIX_LOOP(total) {
+        int k = 0;
+        int64_t rem = pix;
+        while (rem >= (int64_t)N * a.h[k] * a.w[k]) {
+            rem -= (int64_t)N * a.h[k] * a.w[k];
+            ++k;
+        }
+        const int ph = a.h[k], pw = a.w[k];
+        const int j = (int)(rem % pw);
+        const int64_t t = rem / pw;
+        const int i = (int)(t % ph), n = (int)(t / ph);
+        const int h0 = bin_start(i, H, ph), h1 = bin_end(i, H, ph), w0 = bin_start(j, W, pw), w1 = bin_end(j, W, pw);
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int seg = 0; seg < nseg; ++seg) {
+            const int w_lo = seg * segw, w_hi = min(W, w_lo + segw);
+            if (w_lo >= w_hi || w1 <= w_lo || w0 >= w_hi) continue;  // the segment holds no column of bin j
+            // (a segment writes the bins from the first one that ends behind its first column to the neighbour of the last one
+            //  it completes: every bin with a column in the segment is among them)
+            for (int h = h0; h < h1; ++h) {
+                float g[V];
+                ldv<V>(S + ((((int64_t)n * H + h) * nseg + seg) * a.sumw + a.soff[k] + j) * C + c, g);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] += g[e];
+            }
+        }
+        const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] *= inv;
+        stv<V>(a.dp[k] + rem * a.ld[k] + c, acc);
+    }
+}
+
 }  // namespace
 
 #define HN_LAUNCH_V(plan, kern, ...)                                                                     \
@@ -937,6 +1039,44 @@ extern "C" int hn_pyramid_merge_bwd(const float* dout, int lddo, const float* ou
     pc.V = pr.V;  // (the workspace rows were written with that vector width's alignment assumptions)
     if (pc.V == 4) HN_LAUNCH((pyramid_merge_bwd_cols_kernel<4>), pc.grid, pc.block, 0, s, a, workspace, N, H, W, C, nseg, segw);
     else HN_LAUNCH((pyramid_merge_bwd_cols_kernel<1>), pc.grid, pc.block, 0, s, a, workspace, N, H, W, C, nseg, segw);
+    HN_CHECK_LAUNCH();
+    return HN_OK;
+}
+
+extern "C" int hn_pyramid_pool_fwd(const float* x, int ldx, int n_levels, float* const* ys, const int* hos, const int* wos,
+                                   const int* lds, float* workspace, int N, int H, int W, int C, void* stream) {
+    if (!x || !workspace || n_levels <= 0 || n_levels > 8 || !ys || !hos || !wos || !lds || N <= 0 || H <= 0 || W <= 0 || C <= 0 ||
+        ldx < C)
+        return HN_EINVAL;
+    PyramidBwdArgs a;
+    a.count = n_levels;
+    a.sumw = 0;
+    bool aligned = hn_aligned16(workspace);
+    for (int k = 0; k < 8; ++k) {
+        a.dp[k] = k < n_levels ? ys[k] : nullptr;
+        a.h[k] = k < n_levels ? hos[k] : 1;
+        a.w[k] = k < n_levels ? wos[k] : 1;
+        a.ld[k] = k < n_levels ? lds[k] : 4;
+        a.soff[k] = a.sumw;
+        if (k < n_levels) {
+            if (!ys[k] || hos[k] <= 0 || wos[k] <= 0 || lds[k] < C) return HN_EINVAL;
+            if (hos[k] > H || wos[k] > W) return HN_ESHAPE;  // pooling: every bin at least one pixel wide
+            a.sumw += wos[k];
+            aligned = aligned && hn_aligned16(ys[k]) && (lds[k] % 4 == 0);
+        }
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nseg = hn_pyramid_merge_bwd_segments(N, H, W);
+    const int segw = (W + nseg - 1) / nseg;
+    const RowLaunch pr = plan_rows((int64_t)N * H * nseg, C, {x, aligned ? nullptr : (const void*)1}, {ldx});
+    HN_LAUNCH_V(pr, pyramid_pool_fwd_rows_kernel, x, ldx, a, workspace, N, H, W, C, nseg, segw);
+    HN_CHECK_LAUNCH();
+    int64_t total = 0;
+    for (int k = 0; k < n_levels; ++k) total += (int64_t)N * hos[k] * wos[k];
+    RowLaunch pc = plan_rows(total, C, {aligned ? nullptr : (const void*)1}, {});
+    pc.V = pr.V;
+    if (pc.V == 4) HN_LAUNCH((pyramid_pool_fwd_cols_kernel<4>), pc.grid, pc.block, 0, s, a, workspace, N, H, W, C, nseg, segw);
+    else HN_LAUNCH((pyramid_pool_fwd_cols_kernel<1>), pc.grid, pc.block, 0, s, a, workspace, N, H, W, C, nseg, segw);
     HN_CHECK_LAUNCH();
     return HN_OK;
 }

@@ -487,6 +487,13 @@ int hn_pyramid_merge_bwd(const float* dout, int lddo, const float* out, int ldo,
                          float* const* dps, const int* hs, const int* ws, const int* lds, float* workspace, int N, int H, int W,
                          int C, void* stream);
 
+/* The adaptive average poolings of all pyramid levels (nn.AdaptiveAvgPool2d((hos[k], wos[k])), cm/models/pspnet.py:17-18) from ONE
+ * read of x: ys[k] ([N][hos[k]][wos[k]][lds[k]], written) = the mean over PyTorch's bins (start = floor(i * H / ho), end =
+ * ceil((i + 1) * H / ho)); row sums into column bins first (workspace as for hn_pyramid_merge_bwd: N * H *
+ * hn_pyramid_merge_bwd_segments(N, H, W) * sum(wos) * C floats), then the rows of a bin.  hos[k] <= H, wos[k] <= W, at most 8. */
+int hn_pyramid_pool_fwd(const float* x, int ldx, int n_levels, float* const* ys, const int* hos, const int* wos, const int* lds,
+                        float* workspace, int N, int H, int W, int C, void* stream);
+
 /* dx[n,h,w,c] = sum over levels l of adaptive_avg_pool2d backward of dys[l] ([N, hos[l], wos[l], C], row stride lds[l])
  * at input size H x W: the gradient of the four pyramid poolings of PSPModule (cm/models/pspnet.py:22-24,30) written in
  * one pass.  n_levels <= 8.  dx is overwritten. */

@@ -234,6 +234,18 @@ def test_pyramid_pool_fused_backward(dev, shape):
     n, c, h, w = shape
     sizes = (1, 2, 3, 6)
     x = rnd(n, c, h, w, seed=21)
+    if h >= 6 and w >= 6:  # the one-read forward (hn_pyramid_pool_fwd; off by default) against the level-by-level kernels
+        prev = ops.PYRAMID_FWD_FUSED
+        try:
+            xg = x.to(dev).contiguous(memory_format=torch.channels_last)
+            ops.PYRAMID_FWD_FUSED = True
+            ya = ops.pyramid_pool(xg, sizes)
+            ops.PYRAMID_FWD_FUSED = False
+            yb = ops.pyramid_pool(xg, sizes)
+        finally:
+            ops.PYRAMID_FWD_FUSED = prev
+        for a, b, s in zip(ya, yb, sizes):
+            close(a, b.cpu(), atol=1e-6, rtol=1e-5, what="one-read pool%d" % s)
     gs = [rnd(n, c, s, s, seed=22 + s) for s in sizes]
     xr = x.clone().requires_grad_()
     yr = [F.adaptive_avg_pool2d(xr, (s, s)) for s in sizes]
