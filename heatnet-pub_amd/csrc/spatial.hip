@@ -710,30 +710,36 @@ __global__ __launch_bounds__(256) void pyramid_merge_bwd_rows_kernel(const float
 }
 
 // Pass 2.  Segment `seg` of a row wrote the bins from j0(first column) to min(j0(last column) + 1, w_k - 1) of level k and
-// nothing else: exactly those slices are read.
+// nothing else: exactly those slices are read.  One block per prior pixel and channel slab, threadIdx.y strides over the
+// (segment, row) pairs -- the 1 x 1 level sums 8 x 40 row sums per pixel; one thread doing that alone took 139 us -- and an
+// LDS reduction in fixed order closes it.
 template <int V>
 __global__ __launch_bounds__(256) void pyramid_merge_bwd_cols_kernel(PyramidBwdArgs a, const float* __restrict__ S, int N, int H,
                                                                     int W, int C, int nseg, int segw) {
+    __shared__ float red[256 * 4];
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
-    if (c >= C) return;
-    int64_t total = 0;
-    for (int k = 0; k < a.count; ++k) total += (int64_t)N * a.h[k] * a.w[k];
-    HN_PIX_LOOP(total) {
-        int k = 0;
-        int64_t rem = pix;
-        while (rem >= (int64_t)N * a.h[k] * a.w[k]) {
-            rem -= (int64_t)N * a.h[k] * a.w[k];
-            ++k;
-        }
-        const int ph = a.h[k], pw = a.w[k];
-        const int j = (int)(rem % pw);
-        const int64_t t = rem / pw;
-        const int i = (int)(t % ph), n = (int)(t / ph);
-        const float sh = (float)ph / (float)H, sw = (float)pw / (float)W;
-        float acc[V];
+    const bool live = c < C;
+    int k = 0;
+    int64_t rem = blockIdx.y;
+    while (rem >= (int64_t)N * a.h[k] * a.w[k]) {
+        rem -= (int64_t)N * a.h[k] * a.w[k];
+        ++k;
+    }
+    const int ph = a.h[k], pw = a.w[k];
+    const int j = (int)(rem % pw);
+    const int64_t t = rem / pw;
+    const int i = (int)(t % ph), n = (int)(t / ph);
+    const float sh = (float)ph / (float)H, sw = (float)pw / (float)W;
+    // rows that can read prior row i: source coordinate (h + 0.5) * sh - 0.5 within (i - 1, i + 1), one row of slack each way
+    const int h_lo = max(0, (int)floorf(((float)i - 0.5f) / sh - 0.5f) - 1);
+    const int h_hi = min(H - 1, (int)ceilf(((float)i + 1.5f) / sh - 0.5f) + 1);
+    const int nh = h_hi - h_lo + 1;
+    float acc[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) acc[e] = 0.f;
-        for (int seg = 0; seg < nseg; ++seg) {
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    if (live) {
+        for (int q = threadIdx.y; q < nseg * nh; q += blockDim.y) {
+            const int seg = q / nh, h = h_lo + q - seg * nh;
             const int w_lo = seg * segw, w_hi = min(W, w_lo + segw);
             if (w_lo >= w_hi) continue;
             int f0, f1, g0, g1;
@@ -741,19 +747,29 @@ __global__ __launch_bounds__(256) void pyramid_merge_bwd_cols_kernel(PyramidBwdA
             bilinear_src(w_lo, sw, pw, f0, f1, l0, l1);
             bilinear_src(w_hi - 1, sw, pw, g0, g1, l0, l1);
             if (j < f0 || j > min(g0 + 1, pw - 1)) continue;  // this segment never touched bin j
-            for (int h = 0; h < H; ++h) {
-                const float wh = bilinear_weight(h, i, sh, ph);
-                if (wh == 0.f) continue;
-                float g[V];
-                ldv<V>(S + ((((int64_t)n * H + h) * nseg + seg) * a.sumw + a.soff[k] + j) * C + c, g);
+            const float wh = bilinear_weight(h, i, sh, ph);
+            if (wh == 0.f) continue;
+            float g[V];
+            ldv<V>(S + ((((int64_t)n * H + h) * nseg + seg) * a.sumw + a.soff[k] + j) * C + c, g);
 #pragma unroll
-                for (int e = 0; e < V; ++e) acc[e] += wh * g[e];
-            }
+            for (int e = 0; e < V; ++e) acc[e] += wh * g[e];
         }
-        stv<V>(a.dp[k] + rem * a.ld[k] + c, acc);
+    }
+    const int bx = blockDim.x, by = blockDim.y, tx = threadIdx.x, ty = threadIdx.y;
+#pragma unroll
+    for (int e = 0; e < V; ++e) red[(ty * bx + tx) * V + e] = acc[e];
+    __syncthreads();
+    if (ty == 0 && live) {
+        float o[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float v = 0.f;
+            for (int q = 0; q < by; ++q) v += red[(q * bx + tx) * V + e];
+            o[e] = v;
+        }
+        stv<V>(a.dp[k] + rem * a.ld[k] + c, o);
     }
 }
-
 
 // ---- the adaptive average poolings of all pyramid levels from ONE read of the map --------------------------------------------
 // Level by level (hn_adaptive_avgpool_fwd: one block per bin) the four levels read the 231 MB of the encoder output four times.
@@ -1035,8 +1051,10 @@ extern "C" int hn_pyramid_merge_bwd(const float* dout, int lddo, const float* ou
     HN_CHECK_LAUNCH();
     int64_t total = 0;
     for (int k = 0; k < n_priors; ++k) total += (int64_t)N * hs[k] * ws[k];
-    RowLaunch pc = plan_rows(total, C, {aligned ? nullptr : (const void*)1}, {});
+    if (total > 65535) return HN_ESHAPE;
+    RowLaunch pc = plan_pixel_blocks(total, C, {aligned ? nullptr : (const void*)1}, {});  // one block per prior pixel
     pc.V = pr.V;  // (the workspace rows were written with that vector width's alignment assumptions)
+    if (pc.V == 1) { pc.grid = dim3((C + 15) / 16, (unsigned)total); pc.block = dim3(16, 16); }
     if (pc.V == 4) HN_LAUNCH((pyramid_merge_bwd_cols_kernel<4>), pc.grid, pc.block, 0, s, a, workspace, N, H, W, C, nseg, segw);
     else HN_LAUNCH((pyramid_merge_bwd_cols_kernel<1>), pc.grid, pc.block, 0, s, a, workspace, N, H, W, C, nseg, segw);
     HN_CHECK_LAUNCH();
