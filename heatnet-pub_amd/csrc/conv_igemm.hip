@@ -606,7 +606,7 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
         if (!conv4_covers(a)) return HN_ESHAPE;
         pl.family = FAM_V4; pl.math = math == HN_MATH_BF16 ? MATH3_BF16 : MATH_H2; pl.mode = MODE_VEC_BUF;
         const int tile = variant & 15;
-        if (tile > 7) return HN_EINVAL;
+        if (tile > 8) return HN_EINVAL;
         pl.wn = tile == 0 ? (a.K <= 64 ? 1 : 0) : tile;
         return HN_OK;
     }

@@ -327,7 +327,9 @@ bool conv4_covers(const ConvArgs& a) {
 // bytes per multiply-add than the 128-row tiles (their K loop is bound by what a CU can pull out of its L2,
 // tools/probes/dma_line_probe.hip, tools/stamp_conv.py), and the HEIGHT: 8 x 40 x 88 = 28160 = 125.7 x 224 rows and 8 x 80 x 176
 // = 502.9 x 224, so the layers on those maps make 126 / 503 row tiles -- with 2, 4 or 8 column tiles a whole number of rounds
-// on 256 CUs (0.98, 1.97, 3.94) where 128-row tiles make 1.72 / 3.44 / 6.9;
+// on 256 CUs (0.98, 1.97, 3.94) where 128-row tiles make 1.72 / 3.44 / 6.9; 8 = 112 x 128, its two-workgroups-per-CU sibling (four
+// waves side by side, each all seven row blocks of its 32 columns: 252 / 1006 row tiles -- 0.98 .. 3.94 rounds on the 512 slots
+// for the layers with 256 .. 2048 output channels that make 0.86 / 1.72 / 3.44 rounds with 128 rows);
 // 4 = 128 x 64, 5 = 64 x 128, 6 = 64 x 64 with
 // THREE (6: four) stages and two workgroups per CU: the DMA runs two (three) K steps ahead -- for the layers whose K steps
 // carry little matrix work per byte (1x1 convolutions with few channels on one side), where a distance of one step leaves
@@ -342,6 +344,7 @@ int launch_conv4(const ConvArgs& a, int tile, hipStream_t stream) {
             case 5: return launch4<2, 2, 1, 2, 4, 1>(a, stream);
             case 6: return launch4<2, 2, 1, 1, 4, 1>(a, stream);
             case 7: return launch4<2, 4, 4, 2, 3, 1, 14>(a, stream);
+            case 8: return launch4<1, 4, 4, 1, 4, 1, 7>(a, stream);
             default: return launch4<2, 2, 2, 2, 3, 1>(a, stream);
         }
     }
@@ -353,6 +356,7 @@ int launch_conv4(const ConvArgs& a, int tile, hipStream_t stream) {
         case 5: return launch4<2, 2, 1, 2, 3>(a, stream);
         case 6: return launch4<2, 2, 1, 1, 4>(a, stream);
         case 7: return launch4<2, 4, 4, 2, 2, 2, 14>(a, stream);
+        case 8: return launch4<1, 4, 4, 1, 2, 2, 7>(a, stream);
         default: return launch4<2, 2, 2, 2, 2>(a, stream);
     }
 }
@@ -367,6 +371,7 @@ const char* conv4_kernel_name(int tile, bool bf16) {
             case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 4, 1, 0>";
             case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4, 1, 0>";
             case 7: return "conv_igemm4_kernel<2, 4, 4, 2, 3, 1, 14>";
+            case 8: return "conv_igemm4_kernel<1, 4, 4, 1, 4, 1, 7>";
             default: return "conv_igemm4_kernel<2, 2, 2, 2, 3, 1, 0>";
         }
     }
@@ -378,6 +383,7 @@ const char* conv4_kernel_name(int tile, bool bf16) {
         case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 3, 2, 0>";
         case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4, 2, 0>";
         case 7: return "conv_igemm4_kernel<2, 4, 4, 2, 2, 2, 14>";
+        case 8: return "conv_igemm4_kernel<1, 4, 4, 1, 2, 2, 7>";
         default: return "conv_igemm4_kernel<2, 2, 2, 2, 2, 2, 0>";
     }
 }

@@ -1558,15 +1558,20 @@ def _plane_variants(cout, cred, taps):
     """Tiles of conv_igemm4 offered to the tuner for `cout` output channels, `cred` reduction channels and `taps` filter taps:
     0 = 128 x 128 (two workgroups per CU), 1 = 128 x 64, 2 = 128 x 256, 3 = 256 x 128 (eight waves, three stages), 7 = 224 x 256
     (eight waves, seven 16-row blocks per row wave: fewer operand bytes per multiply-add, and a tile HEIGHT that turns the 1.72 /
-    3.44 rounds the 128-row tiles of the 40 x 88 and 80 x 176 layers make on 256 CUs into 0.98 / 1.97); 4 = 128 x 64, 5 = 64 x 128, 6 = 64 x 64 with the DMA two / three K steps ahead -- for the layers with
+    3.44 rounds the 128-row tiles of the 40 x 88 and 80 x 176 layers make on 256 CUs into 0.98 / 1.97), 8 = 112 x 128 (four waves side by
+    side, the same trick for the 512 slots of the two-workgroups-per-CU kernels); 4 = 128 x 64, 5 = 64 x 128, 6 = 64 x 64 with the DMA two / three K steps ahead -- for the layers with
     little matrix work per byte (1x1 convolutions, few channels), which otherwise wait out the memory latency every K step."""
     if cout <= 64:
         return [1, 4, 6]
     light = taps == 1 or cred <= 128
-    return [0, 1, 2, 3] + ([7] if (BIG_TILE and cout >= 256 and cred * taps >= 256) else []) + ([4, 5, 6] if light else [])
+    return ([0, 1, 2, 3] + ([7] if (BIG_TILE and cout >= 256 and cred * taps >= 256) else []) +
+            ([8] if (ROW7_TILE and cout >= 128) else []) + ([4, 5, 6] if light else []))
 
 
-BIG_TILE = os.environ.get("HEATNET_BIG_TILE", "1") != "0"  # A/B knob: offer the 256 x 256 tile to the tuner
+BIG_TILE = os.environ.get("HEATNET_BIG_TILE", "1") != "0"  # A/B knobs: offer the 224 x 256 tile (code 7) /
+ROW7_TILE = os.environ.get("HEATNET_ROW7_TILE", "0") == "1"  # the 112 x 128 tile (code 8) to the tuner -- bitwise-tested, chosen by
+# the isolated tuner for a dozen geometries, and the step 0.25 ms SLOWER with it (37.60 37.51 37.87 against 37.33 37.45 37.46,
+# gpurun_out/r4/ab15): off
 
 
 def _wgrad_plane_candidates(cout, cin, bf16=False):

@@ -88,7 +88,7 @@ PLANE_CONV_CASES = [  # n, cin, h, w, cout, k, stride, pad, dil
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("case", PLANE_CONV_CASES, ids=str)
 def test_conv_planes_forward_dgrad_bitwise(dev, case, tile):
     from heatnet_amd import _lib, ops
@@ -411,7 +411,7 @@ def test_f16x2_range_guard_moves_heavy_tailed_layers_to_bf16x3(dev):
         ops._census.clear()
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("case", PLANE_CONV_CASES[:5] + PLANE_CONV_CASES[6:], ids=str)
 def test_conv_planes_bf16_bitwise(dev, case, tile):
     """The mixed-precision bf16 arithmetic on ONE bf16 image per operand (x_scale = NULL): forward, data gradient and weight
