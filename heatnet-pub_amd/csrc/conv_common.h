@@ -31,6 +31,7 @@ struct ConvArgs {
     int cps;
     int M, Kdim, ntm, ntn;
     int gm;  // row tiles per group of the tile order (see the kernel)
+    int tap_inner = 0;  // conv_igemm4: the K loop walks the filter taps INSIDE a 32-channel chunk (see the kernel)
     int act;
     float slope;
     long long x_bytes;  // extent of the gathered tensor from p.x, for the buffer descriptors

@@ -186,14 +186,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? HN_C4_OCC : 1) void 
             dma16(rsrc_b0, dst, vo, (unsigned)(f_k0 * 2));
             if constexpr (NPL == 2) dma16(rsrc_b1, dst + T::B_PLANE, vo, (unsigned)(f_k0 * 2));
         }
-        f_c0 += BK;
-        const int wrap_c = f_c0 >= p.C ? 1 : 0;
-        f_c0 = wrap_c ? 0 : f_c0;
-        f_kw += wrap_c;
-        const int wrap_w = f_kw == p.KW ? 1 : 0;
-        f_kw = wrap_w ? 0 : f_kw;
-        f_kh += wrap_w;
-        f_k0 += BK;
+        if (p.tap_inner) {
+            // all taps of a 32-channel chunk, then the next chunk: the KH x KW shifted reads of the same rows follow one another
+            // while those rows' 64-byte pieces are still in the L2 (channels-outermost walks the whole row footprint, C / 32
+            // chunks, between two taps: every tap came from memory again -- 4.9 x the algorithmic bytes on the 3x3 layers)
+            ++f_kw;
+            const int wrap_w = f_kw == p.KW ? 1 : 0;
+            f_kw = wrap_w ? 0 : f_kw;
+            f_kh += wrap_w;
+            const int wrap_h = f_kh == p.KH ? 1 : 0;
+            f_kh = wrap_h ? 0 : f_kh;
+            f_c0 += wrap_h ? BK : 0;
+            f_k0 = (f_kh * p.KW + f_kw) * p.C + f_c0;
+        } else {
+            f_c0 += BK;
+            const int wrap_c = f_c0 >= p.C ? 1 : 0;
+            f_c0 = wrap_c ? 0 : f_c0;
+            f_kw += wrap_c;
+            const int wrap_w = f_kw == p.KW ? 1 : 0;
+            f_kw = wrap_w ? 0 : f_kw;
+            f_kh += wrap_w;
+            f_k0 += BK;
+        }
         ++f_chunk;
     };
 
@@ -305,6 +319,8 @@ int launch4(const ConvArgs& a, hipStream_t stream) {
     p.ntm = (a.M + T::BM - 1) / T::BM;
     p.ntn = (a.K + T::BN - 1) / T::BN;
     static const int gm_env = getenv("HN_GROUP_M") ? atoi(getenv("HN_GROUP_M")) : 0;  // experiment knob
+    static const int tap_env = getenv("HN_TAP_INNER") ? atoi(getenv("HN_TAP_INNER")) : 1;  // experiment knob (0: channels innermost)
+    p.tap_inner = (tap_env && a.KH * a.KW > 1) ? 1 : 0;
     p.gm = gm_env > 0 ? gm_env : (p.ntn >= (T::BN >= 256 ? 4 : 8) ? 8 : 1);
     if (p.gm > p.ntm) p.gm = p.ntm;
     HN_LAUNCH((conv_igemm4_kernel<WM, WN, TM, TN, NST, NPL, LIVE>), dim3(p.ntm * p.ntn), dim3(T::NT), T::LDS, stream, p);

@@ -895,7 +895,7 @@ def _wgrad_plan_name(d, mode, variant):
 class _ConvTimer:
     """HIP events on the launch stream (torch's current stream) around one conv-kernel launch."""
 
-    def __init__(self, kind, d, kname=None):
+    def __init__(self, kind, d, kname=None, extra_bytes=0.0):
         self.on = _conv_prof is not None
         if self.on:
             self.kind = kind
@@ -903,12 +903,15 @@ class _ConvTimer:
             self.flops = 2.0 * d.N * d.Hout * d.Wout * d.Cout * d.KH * d.KW * d.Cin
             self.shape = (d.N, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.Cout, d.KH, d.stride, d.dil)
             # compulsory HBM traffic: each of the three tensors of the convolution touched once
-            self.bytes = 4.0 * (d.N * d.Hin * d.Win * d.Cin + d.Cout * d.KH * d.KW * d.Cin + d.N * d.Hout * d.Wout * d.Cout)
+            # (+ extra_bytes: what the launch's fused epilogue reads on top -- the gradient of the by-passing branch it adds,
+            # the BatchNorm output whose backward reduction rides along)
+            self.bytes = 4.0 * (d.N * d.Hin * d.Win * d.Cin + d.Cout * d.KH * d.KW * d.Cin + d.N * d.Hout * d.Wout * d.Cout) + extra_bytes
             self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def __enter__(self):
         if self.on:
             self.e0.record()
+        return self
 
     def __exit__(self, *exc):
         if self.on:
@@ -1110,7 +1113,8 @@ class _Conv2d(torch.autograd.Function):
                     check(lib.hn_conv2d_dgrad(_ptr(dy), _ptr(wt), _ptr(wtx3), _ptr(dx), _ptr(ad), ld, ctypes.byref(dd), v, s),
                           "hn_conv2d_dgrad")
             var = _pick(_kind("dgrad", dm), dd, _igemm_candidates(cin, "dgrad", cout, dm), lambda v: launch(v, None, 0))
-            with _ConvTimer("dgrad", dd, lambda: _plan_name(1, dd, wtx3 is not None, var)):
+            with _ConvTimer("dgrad", dd, lambda: _plan_name(1, dd, wtx3 is not None, var),
+                            4.0 * n * h * wd * cin if add is not None else 0.0):
                 launch(var, add, ldadd)
         elif dskip is not None:
             dx = dskip
@@ -1864,8 +1868,13 @@ class _ConvBnAct(torch.autograd.Function):
                 lmean, linvstd, lscale, lshift = (il.par[i * cin:(i + 1) * cin] for i in range(4))
                 bn_args = _lib.HnBnReduceArgs(_ptr(il.y), cin, int(il.ybf), il.act, 0, _ptr(lscale), _ptr(lshift), _ptr(lmean),
                                               _ptr(linvstd), _ptr(il.rbits), _ptr(il.ws.bwd), None if bf16 else _ptr(il.ws.gmax))
-            with _ConvTimer("dgrad", d, lambda: _plan_name(1, d, 3, _variant(var & 3, var >> 2, 0, mcode))):
+            extra = bn_extra = 4.0 * n * h * wd * cin if add is not None else 0.0
+            if bn_args is not None:  # y of the producing layer (fp32 or bf16) and its byte masks, read by the epilogue
+                bn_extra = extra + ((2.0 if il.ybf else 4.0) + (1.0 if il.rbits is not None else 0.0)) * n * h * wd * cin
+            with _ConvTimer("dgrad", d, lambda: _plan_name(1, d, 3, _variant(var & 3, var >> 2, 0, mcode)), extra) as tm:
                 if launch(var, add, ldadd, bn_args):
+                    if tm.on:
+                        tm.bytes += bn_extra - extra
                     il.ws.fused_owner, il.ws.bwd_open, il.fused_ptr = il, True, dx.data_ptr()
         elif dskip is not None:
             dx = dskip

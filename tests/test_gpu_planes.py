@@ -88,6 +88,15 @@ PLANE_CONV_CASES = [  # n, cin, h, w, cout, k, stride, pad, dil
 ]
 
 
+def _same_conv(got, ref, taps):
+    """1x1 filters: bit for bit.  Larger filters: conv_igemm4_kernel walks the K dimension taps-inside-a-32-channel-chunk, the
+    fp32-input kernels channels-inside-a-tap -- the same products summed in fp32 in another order (measured <= 3e-6 of the
+    largest output); the tiles of conv_igemm4_kernel agree among themselves bit for bit (checked by the callers)."""
+    if taps == 1:
+        return torch.equal(got, ref)
+    return float((got - ref).abs().max()) <= 6e-6 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("case", PLANE_CONV_CASES, ids=str)
 def test_conv_planes_forward_dgrad_bitwise(dev, case, tile):
@@ -124,7 +133,11 @@ def test_conv_planes_forward_dgrad_bitwise(dev, case, tile):
     keys = torch.zeros(ops.STAT_REPLICAS * 2 * cout, device=dev, dtype=torch.int32)
     _lib.check(lib.hn_conv2d_fwd_planes(P(xh), xplane, P(xs), P(wh), P(b), P(y1), P(st1), P(keys), ctypes.byref(d), 0, 0.0, tile, s),
                "fwd_planes")
-    assert torch.equal(y0, y1)
+    assert _same_conv(y1, y0, k * k)
+    if k > 1 and tile != 0:  # the tiles among themselves: bit for bit
+        yt = torch.full_like(y1, float("nan"))
+        _lib.check(lib.hn_conv2d_fwd_planes(P(xh), xplane, P(xs), P(wh), P(b), P(yt), None, None, ctypes.byref(d), 0, 0.0, 0, s), "tile 0")
+        assert torch.equal(yt, y1)
     # statistics: per-lane fp32 partial sums over a tile's rows, then double -- the grouping depends on the tile
     a1 = st1.view(ops.STAT_REPLICAS, 2, cout).sum(0)
     yd = y1.double().reshape(-1, cout)
@@ -142,7 +155,11 @@ def test_conv_planes_forward_dgrad_bitwise(dev, case, tile):
     assert np.array_equal(ymax, yc.max(0)) and np.array_equal(ymin, yc.min(0))
     dx1 = torch.full_like(x, float("nan"))
     _lib.check(lib.hn_conv2d_dgrad_planes(P(gh), gplane, P(gs), P(wth), P(dx1), P(skip), cin, ctypes.byref(d), tile, s), "dgrad_planes")
-    assert torch.equal(dx0, dx1)
+    assert _same_conv(dx1, dx0, k * k)
+    if k > 1 and tile != 0:
+        dxt = torch.full_like(x, float("nan"))
+        _lib.check(lib.hn_conv2d_dgrad_planes(P(gh), gplane, P(gs), P(wth), P(dxt), P(skip), cin, ctypes.byref(d), 0, s), "tile 0")
+        assert torch.equal(dxt, dx1)
     # fused ReLU epilogue
     y2 = torch.empty_like(y1)
     _lib.check(lib.hn_conv2d_fwd_planes(P(xh), xplane, P(xs), P(wh), P(b), P(y2), None, None, ctypes.byref(d), 1, 0.0, tile, s), "relu")
@@ -354,6 +371,13 @@ def test_fused_conv_bn_act_matches_unfused(dev, case, math):
             # white-noise dz every flipped mask is a whole element of error -- sqrt(0.003) ~ 5 % in the norm)
             assert float((a[key] - ref).norm()) <= (8e-2 if y16 else 3e-2) * float(ref.norm()), key  # (db: both exactly zero)
             continue
+        if k > 1 and key not in ("z", "rm", "rv"):
+            # filters with taps: conv_igemm4_kernel sums the K dimension taps-inside-a-chunk, the fp32-input kernels of the
+            # unfused path channels-inside-a-tap -- y agrees to fp32 rounding, not bit for bit, so the ReLU mask of an element with
+            # u = y * scale + shift within a rounding of zero may flip, and with it one whole element of this test's white-noise
+            # dz (seen: one element of 1.5 M, 6 % of the largest dx around it) -- compared in the norm
+            assert float((a[key] - ref).norm()) <= 3e-3 * float(ref.norm()), key
+            continue
         err = float((a[key] - ref).abs().max())
         assert err <= tol * max(float(ref.abs().max()), 1e-30), (key, err, float(ref.abs().max()))
 
@@ -447,7 +471,11 @@ def test_conv_planes_bf16_bitwise(dev, case, tile):
     assert torch.equal(xb.view(torch.bfloat16).float().view(n, h, w_, cin), x.to(torch.bfloat16).float())
     y1 = torch.full_like(y0, float("nan"))
     _lib.check(lib.hn_conv2d_fwd_planes(P(xb), xb.numel(), None, P(w3), P(b), P(y1), None, None, ctypes.byref(d), 0, 0.0, tile, s), "fwd")
-    assert torch.equal(y0, y1)
+    assert _same_conv(y1, y0, k * k)
+    if k > 1 and tile != 0:
+        yt = torch.full_like(y0, float("nan"))
+        _lib.check(lib.hn_conv2d_fwd_planes(P(xb), xb.numel(), None, P(w3), P(b), P(yt), None, None, ctypes.byref(d), 0, 0.0, 0, s), "tile 0")
+        assert torch.equal(yt, y1)
     # HN_Y_BF16: the same output rounded (to nearest even) to bf16 elements, the batch statistics still from the fp32 values
     y2 = torch.zeros(n, ho, wo, cout, device=dev, dtype=torch.bfloat16)
     st1, st2 = (torch.zeros(ops.STAT_REPLICAS * 2 * cout, device=dev, dtype=torch.float64) for _ in range(2))
@@ -461,7 +489,7 @@ def test_conv_planes_bf16_bitwise(dev, case, tile):
                                     tile, s) == -1
     dx1 = torch.full_like(x, float("nan"))
     _lib.check(lib.hn_conv2d_dgrad_planes(P(gb), gb.numel(), None, P(wt3), P(dx1), P(skip), cin, ctypes.byref(d), tile, s), "dgrad")
-    assert torch.equal(dx0, dx1)
+    assert _same_conv(dx1, dx0, k * k)
     if cin % 64 == 0 and cout % 64 == 0 and tile < 2:
         dw0, dw1 = torch.empty_like(wt), torch.full_like(wt, float("nan"))
         _lib.check(lib.hn_conv2d_wgrad(P(x), P(gy), P(dw0), ctypes.byref(d), 1, vb, 0, s), "wgrad")
