@@ -150,6 +150,9 @@ struct AccMap {
     __device__ __forceinline__ int row(int i, int r) const {  // row inside the block tile
         return (wm * TM + i) * 32 + (S16 ? 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
     }
+    // S16: row = row_base (the same for the whole wave) + row_lane (the same for all of a lane's rows)
+    __device__ __forceinline__ int row_base(int i, int r) const { return (wm * TM + i) * 32 + 16 * (r >> 3) + (r & 3); }
+    __device__ __forceinline__ int row_lane() const { return 4 * (lane >> 4); }
     __device__ __forceinline__ int col(int j, int c2) const {  // global output channel
         return n0 + (wn * TN + j) * 32 + (S16 ? 16 * c2 + (lane & 15) : (lane & 31));
     }

@@ -562,6 +562,7 @@ struct ConvPlan {
     int wn;          // FAM_V1 bf16x3: 4 = the eight-wave 128 x 256 tile (tn_sel 3), else 2
     int mode, bk;    // FAM_V1: loader variant and K step
     int math;        // FAM_V1: MATH_F32 / MATH_X3 / MATH_H2; FAM_V2: bf16 planes per operand (3 = bf16x3, 1 = bf16)
+    int epi = 0;     // FAM_V4: the kernel's EPI argument (1: BatchNorm-backward reduction in the epilogue)
 };
 
 // variant: 0 = heuristics; otherwise (bk_sel) + 4 * (tm_sel) + 16 * (tn_sel) + 64 * (math_sel).
@@ -608,6 +609,7 @@ int plan_conv(const ConvArgs& a, int variant, ConvPlan& pl) {
         const int tile = variant & 15;
         if (tile > 8) return HN_EINVAL;
         pl.wn = tile == 0 ? (a.K <= 64 ? 1 : 0) : tile;
+        pl.epi = a.br_y != nullptr ? 1 : 0;
         return HN_OK;
     }
     if (math == HN_MATH_F16X2) {
@@ -679,7 +681,7 @@ int dispatch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
 // the kernel's name as rocprofv3 prints it (tools/pmc_aggregate.py keys), for per-instantiation accounting
 void plan_name(const ConvPlan& pl, char* buf, int n) {
     const int tm = pl.tall ? 2 : 1, tn = pl.wide ? 2 : 1;
-    if (pl.family == FAM_V4) snprintf(buf, n, "%s", conv4_kernel_name(pl.wn, pl.math == MATH3_BF16));
+    if (pl.family == FAM_V4) snprintf(buf, n, "%s, %d>", conv4_kernel_name(pl.wn, pl.math == MATH3_BF16), pl.epi);
     else if (pl.family == FAM_V3) {
         const int planes = pl.math == MATH_H2 ? 2 : (pl.math == MATH3_BF16 ? 1 : 3);
         const bool small = planes != 3 && pl.wn != 4;  // the 128 x 128 four-wave tile with two A staging sets
@@ -1053,6 +1055,7 @@ extern "C" int hn_conv2d_plan(int kind, const HnConvDesc* d, int has_planes, int
         a.xh = reinterpret_cast<const unsigned short*>(al);
         a.xh_plane = 1ll << 20;
     }
+    if (has_planes & 4) a.br_y = al;  // hn_conv2d_dgrad_planes_bnreduce: the instantiation with the reduction in its epilogue
     bool can_split = d->ldy == d->Cout;
     if (kind == 1) {  // data gradient: the gathered tensor is dY, the produced one dX (first parity class when strided)
         const bool classes = parity_decomposable(d->KH, d->KW, d->stride, d->dil);

@@ -26,6 +26,7 @@
 #include <cstdlib>
 
 #include "conv_common.h"
+#include "conv_epilogue4.h"
 
 // Register budget of the four-wave kernels, as "workgroups per CU" for __launch_bounds__: 2 = 256 registers per lane (what the LDS
 // allows anyway); 3 = 168 -- still two workgroups per CU (LDS), but a third of the register file stays free, so the HBM-bound
@@ -81,11 +82,14 @@ struct AccMapI {
     __device__ __forceinline__ int row(int i, int r) const {
         return ((2 * i + (r >> 3)) * WM + wm) * 16 + 4 * (lane >> 4) + (r & 3);
     }
+    // row = row_base (the same for the whole wave) + row_lane (the same for all of a lane's rows)
+    __device__ __forceinline__ int row_base(int i, int r) const { return ((2 * i + (r >> 3)) * WM + wm) * 16 + (r & 3); }
+    __device__ __forceinline__ int row_lane() const { return 4 * (lane >> 4); }
     __device__ __forceinline__ int col(int j, int c2) const { return n0 + (wn * TN + j) * 32 + 16 * c2 + (lane & 15); }
 };
 
-template <int WM, int WN, int TM, int TN, int NST, int NPL = 2, int LIVE = 0>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? HN_C4_OCC : 1) void conv_igemm4_kernel(const ConvArgs p) {
+template <int WM, int WN, int TM, int TN, int NST, int NPL = 2, int LIVE = 0, int EPI = 0>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? ((EPI & 1) && TM * TN >= 4 ? 2 : HN_C4_OCC) : 1) void conv_igemm4_kernel(const ConvArgs p) {
     using T = T4<WM, WN, TM, TN, NST, NPL, LIVE>;
     using AM = std::conditional_t<(LIVE > 0), AccMapI<TM, TN, WM, LIVE>, AccMap<TM, TN, true>>;
     constexpr int NBLK = BM_BLOCKS<T>();  // 16-row blocks of the tile
@@ -179,12 +183,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? HN_C4_OCC : 1) void 
             dma16(rsrc_a0, dst, vo, 0);
             if constexpr (NPL == 2) dma16(rsrc_a1, dst + T::A_PLANE, vo, 0);
         }
+        // (the scalar offset operand: said to be uniform in so many words, or the tap-inner arithmetic below lands in vector
+        // registers and every weight DMA is wrapped in a readfirstlane loop)
+        const unsigned ko = (unsigned)__builtin_amdgcn_readfirstlane(f_k0 * 2);
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
             const unsigned vo = live ? bvoff[q] : b_records;
             char* dst = stage + T::A_BYTES + (wave + NW * q) * 1024;
-            dma16(rsrc_b0, dst, vo, (unsigned)(f_k0 * 2));
-            if constexpr (NPL == 2) dma16(rsrc_b1, dst + T::B_PLANE, vo, (unsigned)(f_k0 * 2));
+            dma16(rsrc_b0, dst, vo, ko);
+            if constexpr (NPL == 2) dma16(rsrc_b1, dst + T::B_PLANE, vo, ko);
         }
         if (p.tap_inner) {
             // all taps of a 32-channel chunk, then the next chunk: the KH x KW shifted reads of the same rows follow one another
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? HN_C4_OCC : 1) void 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last, out-of-range DMAs)
     HN_STAMP(p, 6);
 
-    conv_epilogue<TM, TN, true, BM, BN, NPL == 2, NPL == 1, true, AM>(p, acc, am, rowinfo, m0, tile_m, 0, o_s, o_s2);
+    conv_epilogue4<TM, TN, BM, BN, NPL == 2, NPL == 1, (EPI & 1) != 0, AM>(p, acc, am, rowinfo, m0, tile_m, o_s, o_s2);
 #ifdef HN_STAMPS
     HN_STAMP(p, 7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -306,11 +313,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? HN_C4_OCC : 1) void 
 #endif
 }
 
-template <int WM, int WN, int TM, int TN, int NST, int NPL = 2, int LIVE = 0>
-int launch4(const ConvArgs& a, hipStream_t stream) {
+template <int WM, int WN, int TM, int TN, int NST, int NPL, int LIVE, int EPI>
+int launch4e(const ConvArgs& a, hipStream_t stream) {
     using T = T4<WM, WN, TM, TN, NST, NPL, LIVE>;
     static std::atomic<unsigned long long> configured{0};
-    if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm4_kernel<WM, WN, TM, TN, NST, NPL, LIVE>), T::LDS, configured) != HN_OK)
+    if (hn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_igemm4_kernel<WM, WN, TM, TN, NST, NPL, LIVE, EPI>), T::LDS, configured) != HN_OK)
         return HN_ELAUNCH;
     ConvArgs p = a;
 #ifdef HN_STAMPS
@@ -323,9 +330,16 @@ int launch4(const ConvArgs& a, hipStream_t stream) {
     p.tap_inner = (tap_env && a.KH * a.KW > 1) ? 1 : 0;
     p.gm = gm_env > 0 ? gm_env : (p.ntn >= (T::BN >= 256 ? 4 : 8) ? 8 : 1);
     if (p.gm > p.ntm) p.gm = p.ntm;
-    HN_LAUNCH((conv_igemm4_kernel<WM, WN, TM, TN, NST, NPL, LIVE>), dim3(p.ntm * p.ntn), dim3(T::NT), T::LDS, stream, p);
+    HN_LAUNCH((conv_igemm4_kernel<WM, WN, TM, TN, NST, NPL, LIVE, EPI>), dim3(p.ntm * p.ntn), dim3(T::NT), T::LDS, stream, p);
     HN_CHECK_LAUNCH();
     return HN_OK;
+}
+
+// EPI (the kernel's last template argument): 1 = the launch carries the BatchNorm-backward reduction (ConvArgs::br_y) -- an
+// instantiation of its own, so that the launches without it do not pay for its registers (conv_epilogue4.h)
+template <int WM, int WN, int TM, int TN, int NST, int NPL = 2, int LIVE = 0>
+int launch4(const ConvArgs& a, hipStream_t stream) {
+    return a.br_y != nullptr ? launch4e<WM, WN, TM, TN, NST, NPL, LIVE, 1>(a, stream) : launch4e<WM, WN, TM, TN, NST, NPL, LIVE, 0>(a, stream);
 }
 
 }  // namespace
@@ -377,30 +391,31 @@ int launch_conv4(const ConvArgs& a, int tile, hipStream_t stream) {
     }
 }
 
+// (without the last template argument and the closing bracket: plan_name appends ", EPI>")
 const char* conv4_kernel_name(int tile, bool bf16) {
     if (bf16) {
         switch (tile) {
-            case 1: return "conv_igemm4_kernel<4, 1, 1, 2, 3, 1, 0>";
-            case 2: return "conv_igemm4_kernel<2, 4, 2, 2, 4, 1, 0>";
-            case 3: return "conv_igemm4_kernel<4, 2, 2, 2, 4, 1, 0>";
-            case 4: return "conv_igemm4_kernel<4, 1, 1, 2, 4, 1, 0>";
-            case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 4, 1, 0>";
-            case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4, 1, 0>";
-            case 7: return "conv_igemm4_kernel<2, 4, 4, 2, 3, 1, 14>";
-            case 8: return "conv_igemm4_kernel<1, 4, 4, 1, 4, 1, 7>";
-            default: return "conv_igemm4_kernel<2, 2, 2, 2, 3, 1, 0>";
+            case 1: return "conv_igemm4_kernel<4, 1, 1, 2, 3, 1, 0";
+            case 2: return "conv_igemm4_kernel<2, 4, 2, 2, 4, 1, 0";
+            case 3: return "conv_igemm4_kernel<4, 2, 2, 2, 4, 1, 0";
+            case 4: return "conv_igemm4_kernel<4, 1, 1, 2, 4, 1, 0";
+            case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 4, 1, 0";
+            case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4, 1, 0";
+            case 7: return "conv_igemm4_kernel<2, 4, 4, 2, 3, 1, 14";
+            case 8: return "conv_igemm4_kernel<1, 4, 4, 1, 4, 1, 7";
+            default: return "conv_igemm4_kernel<2, 2, 2, 2, 3, 1, 0";
         }
     }
     switch (tile) {
-        case 1: return "conv_igemm4_kernel<4, 1, 1, 2, 2, 2, 0>";
-        case 2: return "conv_igemm4_kernel<2, 4, 2, 2, 3, 2, 0>";
-        case 3: return "conv_igemm4_kernel<4, 2, 2, 2, 3, 2, 0>";
-        case 4: return "conv_igemm4_kernel<4, 1, 1, 2, 3, 2, 0>";
-        case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 3, 2, 0>";
-        case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4, 2, 0>";
-        case 7: return "conv_igemm4_kernel<2, 4, 4, 2, 2, 2, 14>";
-        case 8: return "conv_igemm4_kernel<1, 4, 4, 1, 2, 2, 7>";
-        default: return "conv_igemm4_kernel<2, 2, 2, 2, 2, 2, 0>";
+        case 1: return "conv_igemm4_kernel<4, 1, 1, 2, 2, 2, 0";
+        case 2: return "conv_igemm4_kernel<2, 4, 2, 2, 3, 2, 0";
+        case 3: return "conv_igemm4_kernel<4, 2, 2, 2, 3, 2, 0";
+        case 4: return "conv_igemm4_kernel<4, 1, 1, 2, 3, 2, 0";
+        case 5: return "conv_igemm4_kernel<2, 2, 1, 2, 3, 2, 0";
+        case 6: return "conv_igemm4_kernel<2, 2, 1, 1, 4, 2, 0";
+        case 7: return "conv_igemm4_kernel<2, 4, 4, 2, 2, 2, 14";
+        case 8: return "conv_igemm4_kernel<1, 4, 4, 1, 2, 2, 7";
+        default: return "conv_igemm4_kernel<2, 2, 2, 2, 2, 2, 0";
     }
 }
 

@@ -566,9 +566,9 @@ _scratch = {}
 
 def _tune_scratch(like):
     """Same-size scratch for candidate timing: those launches must not leave anything in a gradient slot."""
-    buf = _scratch.get((like.device, like.numel()))
+    buf = _scratch.get((like.device, like.numel(), like.dtype))
     if buf is None:
-        buf = _scratch[(like.device, like.numel())] = torch.empty(like.numel(), device=like.device, dtype=like.dtype)
+        buf = _scratch[(like.device, like.numel(), like.dtype)] = torch.empty(like.numel(), device=like.device, dtype=like.dtype)
     return buf
 
 
@@ -1861,13 +1861,20 @@ class _ConvBnAct(torch.autograd.Function):
                 check(lib.hn_conv2d_dgrad_planes(_ptr(dyp), npix * cout, _ptr(dy_slot), _ptr(ctx.wth), _ptr(dx), _ptr(ad), ld,
                                                  ctypes.byref(d), v, s), "hn_conv2d_dgrad_planes")
                 return False
-            var = _pick("dgrad" + tag, d, _plane_variants(cin, cout, kh * kw), lambda v: launch(v, None, 0))
             # dx is the dz of the BatchNorm layer that produced this node's input: its backward reduction rides along
-            il, bn_args = ctx.in_link, None
+            il, bn_args, tune_bn = ctx.in_link, None, None
             if il is not None and il.ws.fused_owner is None and not il.ws.bwd_open and not il.ws.fuse_refused:
                 lmean, linvstd, lscale, lshift = (il.par[i * cin:(i + 1) * cin] for i in range(4))
                 bn_args = _lib.HnBnReduceArgs(_ptr(il.y), cin, int(il.ybf), il.act, 0, _ptr(lscale), _ptr(lshift), _ptr(lmean),
                                               _ptr(linvstd), _ptr(il.rbits), _ptr(il.ws.bwd), None if bf16 else _ptr(il.ws.gmax))
+                # the tuner times the launch AS IT WILL RUN -- the instantiation with the reduction (its own registers and loads)
+                # and the addend -- with the sums going to a scratch copy
+                def tune_bn():
+                    return _lib.HnBnReduceArgs(_ptr(il.y), cin, int(il.ybf), il.act, 0, _ptr(lscale), _ptr(lshift), _ptr(lmean),
+                                               _ptr(linvstd), _ptr(il.rbits), _ptr(_tune_scratch(il.ws.bwd)),
+                                               None if bf16 else _ptr(_tune_scratch(il.ws.gmax)))
+            var = _pick("dgrad" + tag + (".br" if bn_args is not None else "") + (".add" if add is not None else ""), d,
+                        _plane_variants(cin, cout, kh * kw), lambda v: launch(v, add, ldadd, tune_bn() if tune_bn else None))
             extra = bn_extra = 4.0 * n * h * wd * cin if add is not None else 0.0
             if bn_args is not None:  # y of the producing layer (fp32 or bf16) and its byte masks, read by the epilogue
                 bn_extra = extra + ((2.0 if il.ybf else 4.0) + (1.0 if il.rbits is not None else 0.0)) * n * h * wd * cin
@@ -1875,6 +1882,7 @@ class _ConvBnAct(torch.autograd.Function):
                 if launch(var, add, ldadd, bn_args):
                     if tm.on:
                         tm.bytes += bn_extra - extra
+                        tm.kname = _plan_name(1, d, 7, _variant(var & 3, var >> 2, 0, mcode))  # (the instantiation with the reduction)
                     il.ws.fused_owner, il.ws.bwd_open, il.fused_ptr = il, True, dx.data_ptr()
         elif dskip is not None:
             dx = dskip
