@@ -15,6 +15,66 @@
 
 namespace hnconv {
 
+// Accumulators start at zero -- or at the addend (conv_common.h: conv_init_acc), read row by row like everything below: a scalar
+// row base, one lane offset, the column as an immediate.  Rows that land on interleaved pixels (ConvArgs::omap: rowinfo[.][3]) keep
+// a 64-bit address per row.
+template <int TM, int TN, int BM, int BN, class AM>
+__device__ __forceinline__ void conv_init_acc4(const ConvArgs& p, f32x16 (&acc)[TM][TN], const AM& am, const int* rowinfo, int m0,
+                                               float iscale, float iscale2) {
+    constexpr int NC = 2;
+    if (p.addend == nullptr) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        return;
+    }
+    const int col0 = am.col(0, 0), rl = am.row_lane();
+    const bool full = (m0 + BM <= p.M) && (am.n0 + BN <= p.K) && !p.omap;
+    if (full) {
+        const unsigned lo = (unsigned)(rl * p.ldadd + col0) * 4u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int row_u = __builtin_amdgcn_readfirstlane(m0 + am.row_base(i, 8 * rh + r4));
+                    const char* rp = reinterpret_cast<const char*>(p.addend + (size_t)row_u * p.ldadd);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int c2 = 0; c2 < NC; ++c2) {
+                            float v = 0.f;
+                            if (!AM::dead(i, 8 * rh)) v = *reinterpret_cast<const float*>(rp + (size_t)lo + (32 * j + 16 * c2) * 4);
+                            acc[i][j][8 * rh + 4 * c2 + r4] = v * iscale * iscale2;
+                        }
+                }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int row = am.row_base(i, 8 * rh + r4) + rl;
+                const bool rin = !AM::dead(i, 8 * rh) && m0 + row < p.M;
+                const float* rp = p.addend + (size_t)rowinfo[min(row, BM - 1) * 4 + 3] * p.ldadd;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int c2 = 0; c2 < NC; ++c2) {
+                        const int col = col0 + 32 * j + 16 * c2;
+                        float v = 0.f;
+                        if (rin && col < p.K) v = rp[col];
+                        acc[i][j][8 * rh + 4 * c2 + r4] = v * iscale * iscale2;
+                    }
+            }
+}
+
 template <int TM, int TN, int BM, int BN, bool SCALED, bool YB, bool BR, class AM>
 __device__ __forceinline__ void conv_epilogue4(const ConvArgs& p, f32x16 (&acc)[TM][TN], const AM& am, const int* rowinfo,
                                                int m0, int tile_m, float oscale, float oscale2) {

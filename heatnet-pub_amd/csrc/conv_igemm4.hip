@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? ((EPI & 1) && TM * T
 
     const AM am{wm, wn, lane, n0};
     f32x16 acc[TM][TN];
-    conv_init_acc<TM, TN, true, AM>(p, acc, am, rowinfo, m0, i_s, i_s2);
+    conv_init_acc4<TM, TN, BM, BN, AM>(p, acc, am, rowinfo, m0, i_s, i_s2);
 
     const int frag = (lane & 15) * 64 + (((lane >> 4) ^ hsw((lane >> 2) & 3)) * 16);
     const int a_frag = (LIVE > 0 ? wm * 16 * 64 : wm * TM * 32 * 64) + frag;  // (LIVE: the wave's blocks are WM blocks apart)

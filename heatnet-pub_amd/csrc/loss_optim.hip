@@ -558,4 +558,4 @@ extern "C" const char* hn_strerror(int code) {
 }
 
 // bumped whenever kernel tilings / variants change (invalidates heatnet-pub_amd/tune_cache.json)
-extern "C" int hn_version(void) { return 12; }
+extern "C" int hn_version(void) { return 13; }

@@ -1676,7 +1676,9 @@ class _ConvBnAct(torch.autograd.Function):
         def launch(v, st, keys):
             check(lib.hn_conv2d_fwd_planes(_ptr(xp), xplane, _ptr(x_slot), _ptr(wh), _ptr(b), _ptr(y), _ptr(st), _ptr(keys),
                                            ctypes.byref(d), ACT_NONE | ybf, 0.0, v, s), "hn_conv2d_fwd_planes")
-        var = _pick("fwd" + tag, d, _plane_variants(cout, cin, kh * kw), lambda v: launch(v, None, None))
+        # (timed as it will run: with the statistics / range-key epilogue, into scratch copies of the accumulators)
+        var = _pick("fwd" + tag + ".st", d, _plane_variants(cout, cin, kh * kw),
+                    lambda v: launch(v, _tune_scratch(ws.stats), None if bf16 else _tune_scratch(ws.keys)))
         with _ConvTimer("fwd", d, lambda: _plan_name(0, d, 3, _variant(var & 3, var >> 2, 0, mcode))):
             launch(var, ws.stats, None if bf16 else ws.keys)
         # batch statistics -> normalisation constants, and the bound of |z| (the scale z is written with)
