@@ -33,6 +33,9 @@ __global__ __launch_bounds__(256) void grouped_fwd_kernel(const GArgs p) {
     __syncthreads();
     const long long npix = (long long)p.N * p.H * p.W;
     for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long long)gridDim.x * 256) {
+        // (the weights are re-read from LDS for every pixel: left to itself hipcc hoists all 9 * 16 * CG of them out of this loop
+        // -- a thread walks one or two pixels --, 256 registers + 350-630 B of scratch, one wave per SIMD)
+        asm volatile("" ::: "memory");
         const int wq = (int)(pix % p.W);
         const long long t = pix / p.W;
         const int hq = (int)(t % p.H);

@@ -124,7 +124,10 @@ int hn_conv2d_fwd_affine(const float* x, const float* in_scale, const float* in_
 
 /* Which kernel hn_conv2d_fwd (kind 0) / hn_conv2d_dgrad (kind 1) would launch for this geometry and variant, assuming
  * 256-B aligned operands and (has_planes != 0) bf16 weight planes: writes the kernel's name as rocprofv3 prints it into
- * `name`; returns 1 if it is a conv_igemm2 kernel (which hn_conv2d_fwd_affine needs), 0 otherwise, < 0 on error. */
+ * `name`; returns 1 if it is a conv_igemm2 kernel (which hn_conv2d_fwd_affine needs), 0 otherwise, < 0 on error.
+ * has_planes is a bit set: 1 = weight planes, 2 = the gathered operand is a plane tensor (hn_conv2d_fwd_planes /
+ * hn_conv2d_dgrad_planes), 4 = the launch carries a BatchNorm-backward reduction (hn_conv2d_dgrad_planes_bnreduce: the
+ * conv_igemm4_kernel instantiation whose last template argument is 1). */
 int hn_conv2d_plan(int kind, const HnConvDesc* d, int has_planes, int variant, char* name, int name_len);
 
 /* bf16x3 takes the WEIGHT operand pre-split (the activations / gradients are split inside the kernel): `w_x3` of
