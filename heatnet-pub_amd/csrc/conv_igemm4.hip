@@ -290,10 +290,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? ((EPI & 1) && TM * T
     int st_cur = 0, st_free = NST - 1;  // stage of chunk kc; stage that becomes free at the barrier of step kc
     HN_STAMP(p, 3);
     for (int kc = 0; kc < nchunks; ++kc) {
+#ifdef HN_STAMPS
+        if (kc == 3) HN_STAMP(p, 13);  // inside one step (the fourth) of thread 0's wave: 13 -> 14 the counted wait for its own DMAs,
+#endif                                 // 14 -> 15 the barrier (= the other waves' DMAs)
         wait_landed();
+#ifdef HN_STAMPS
+        if (kc == 3) HN_STAMP(p, 14);
+#endif
         barrier();
 #ifdef HN_STAMPS
         if (kc == 0) HN_STAMP(p, 4);
+        if (kc == 3) HN_STAMP(p, 15);
 #endif
         dma_chunk(smem4 + st_free * T::STAGE);
         mfma_phase(smem4 + st_cur * T::STAGE);

@@ -95,6 +95,13 @@ def main():
     for i, name in enumerate(PHASES):
         dtc = (st[:, i + 1] - st[:, i]).astype(np.float64) / (ghz * 1e3)
         print("  %-22s median %6.2f us   p10 %6.2f   p90 %6.2f" % (name, np.median(dtc), np.percentile(dtc, 10), np.percentile(dtc, 90)))
+    # inside the fourth K step of thread 0's wave (layers with at least four): the counted wait for its own DMAs of the chunk, then
+    # the barrier -- i.e. the wait for the other waves' pieces of it
+    ok = (st[:, 13] != 0) & (st[:, 15] != 0)
+    if ok.any():
+        for name, a, b in (("step 3: counted wait (own DMAs)", 13, 14), ("step 3: barrier", 14, 15)):
+            dtc = (st[ok, b] - st[ok, a]).astype(np.float64) / (ghz * 1e3)
+            print("  %-32s median %6.3f us   p10 %6.3f   p90 %6.3f" % (name, np.median(dtc), np.percentile(dtc, 10), np.percentile(dtc, 90)))
     # how the workgroups are spread in time: start offsets relative to the first
     start = (rt0 - rt0.min()) / 100.0
     end = (rt1 - rt0.min()) / 100.0
