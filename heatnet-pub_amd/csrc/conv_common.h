@@ -73,6 +73,9 @@ struct ConvArgs {
     const unsigned char* br_bits = nullptr;  // the forward's byte ReLU masks (a residual was added in front of the ReLU)
     double* br_sums = nullptr;           // [HN_STAT_REPLICAS][2K + 1]
     unsigned* br_gmax = nullptr;         // [HN_STAT_REPLICAS][K] or NULL
+#ifndef HN_STAMP_TID
+#define HN_STAMP_TID 0  // the stamping thread (make STAMPS=1 STAMP_TID=448: the last wave of an eight-wave workgroup)
+#endif
 #ifdef HN_STAMPS
     long long* stamps = nullptr;         // diagnostic build (make STAMPS=1): 16 words per workgroup, tools/stamp_conv.py
 #endif
@@ -81,7 +84,7 @@ struct ConvArgs {
 extern long long* g_hn_stamps;  // conv_igemm.hip, set by hn_debug_set_stamps
 #define HN_STAMP(p, i)                                                                                   \
     do {                                                                                                 \
-        if ((p).stamps != nullptr && threadIdx.x == 0) (p).stamps[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
+        if ((p).stamps != nullptr && threadIdx.x == HN_STAMP_TID) (p).stamps[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define HN_STAMP(p, i) do { } while (0)

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? ((EPI & 1) && TM * T
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     HN_STAMP(p, 0);
 #ifdef HN_STAMPS
-    if (p.stamps != nullptr && tid == 0) {
+    if (p.stamps != nullptr && tid == HN_STAMP_TID) {
         p.stamps[(size_t)blockIdx.x * 16 + 9] = (long long)__builtin_amdgcn_s_memrealtime();
         p.stamps[(size_t)blockIdx.x * 16 + 11] = (long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));   // HW_ID
         p.stamps[(size_t)blockIdx.x * 16 + 12] = (long long)__builtin_amdgcn_s_getreg(20 | (31 << 11));  // XCC_ID
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? ((EPI & 1) && TM * T
     HN_STAMP(p, 7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     HN_STAMP(p, 8);
-    if (p.stamps != nullptr && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 10] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (p.stamps != nullptr && tid == HN_STAMP_TID) p.stamps[(size_t)blockIdx.x * 16 + 10] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
 }
 
