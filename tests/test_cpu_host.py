@@ -265,3 +265,23 @@ def test_data_parallel_replication_is_refused():
         with pytest.raises(RuntimeError, match="DistributedDataParallel"):
             m._replicate_for_data_parallel()
     assert isinstance(HnConv2d(4, 4, 1), torch.nn.Conv2d) and isinstance(HnBatchNorm2d(4), torch.nn.BatchNorm2d)
+
+
+def test_plan_names_the_kernel_instantiation_of_a_launch():
+    """hn_conv2d_plan is host logic only: the name rocprofv3 will print for a plane-tensor launch -- tile code 7 is the 224-row
+    tile (LIVE = 14), and has_planes & 4 names the instantiation whose epilogue carries a BatchNorm-backward reduction (the
+    kernel's last template argument)."""
+    import ctypes
+    from heatnet_amd import _lib, ops
+    lib = _lib.load()
+    d = _lib.HnConvDesc(8, 40, 88, 512, 512, 40, 88, 512, 512, 3, 3, 1, 4, 4)
+
+    def name(kind, has_planes, tile):
+        buf = ctypes.create_string_buffer(128)
+        assert lib.hn_conv2d_plan(kind, ctypes.byref(d), has_planes, ops._variant(tile & 3, tile >> 2, 0, 4), buf, 128) >= 0
+        return buf.value.decode()
+    assert name(0, 3, 7) == "conv_igemm4_kernel<2, 4, 4, 2, 2, 2, 14, 0>"
+    assert name(1, 3, 7) == "conv_igemm4_kernel<2, 4, 4, 2, 2, 2, 14, 0>"
+    assert name(1, 7, 7) == "conv_igemm4_kernel<2, 4, 4, 2, 2, 2, 14, 1>"
+    assert name(1, 7, 2) == "conv_igemm4_kernel<2, 4, 2, 2, 3, 2, 0, 1>"
+    assert name(0, 3, 0) == "conv_igemm4_kernel<2, 2, 2, 2, 2, 2, 0, 0>"
